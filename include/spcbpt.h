@@ -1,0 +1,304 @@
+/*
+ * spcbpt.h — C ABI of the MI355X-native SPCBPT hot path.
+ *
+ * This is the drop-in boundary for the path BASELINE.json's north_star names:
+ * light sub-path tracing -> light-vertex-cache (LVC) sampler build -> eye
+ * sub-path tracing with subspace classification, two-stage resampling through
+ * the subspace sampling matrix, shadow ray, BSDF + recursive-MIS connection,
+ * accumulation.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference checkout's src/ directory).
+ *
+ * The reference dispatches this path by *name* through
+ *   sutil::Scene::switchRaygen("pt" | "light trace" | "SPCBPT_eye" | "pretrace")
+ *   (sutil/Scene.cpp:1642-1789) followed by optixLaunch(pipeline, 0, d_params,
+ *   sizeof(MyParams), sbt, w, h, 1) (OptiXPathTracer/optixPathTracer.cpp:503-512,
+ *   535-544, 623-632).  spcbpt_launch() keeps the same four names.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on
+ * success or a negative spcbpt_status; nothing throws across the ABI; all
+ * device memory is owned by the context; one context per GPU; calls on one
+ * context are not re-entrant.  Launches are asynchronous on the context's HIP
+ * stream; spcbpt_sync() waits.
+ */
+#ifndef SPCBPT_H
+#define SPCBPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Compile-time constants of the reference (OptiXPathTracer/optixPathTracer.h:31-39). */
+#define SPCBPT_NUM_SUBSPACE 1000             /* NUM_SUBSPACE */
+#define SPCBPT_NUM_SUBSPACE_LIGHTSOURCE 200  /* NUM_SUBSPACE_LIGHTSOURCE = int(0.2*NUM_SUBSPACE) */
+#define SPCBPT_CONNECTION_N 3                /* CONNECTION_N */
+#define SPCBPT_MIN_RR_RATE 0.3f              /* MIN_RR_RATE */
+#define SPCBPT_SCENE_EPSILON 1e-3f           /* cuProg.h:39 SCENE_EPSILON */
+
+typedef enum spcbpt_status {
+    SPCBPT_OK = 0,
+    SPCBPT_ERR_INVALID_ARG = -1,
+    SPCBPT_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at create */
+    SPCBPT_ERR_HIP = -3,         /* a HIP call failed; see spcbpt_last_error */
+    SPCBPT_ERR_UNKNOWN_ALG = -4, /* name is not one of the four launch names */
+    SPCBPT_ERR_STATE = -5,       /* call order violated (e.g. SPCBPT_eye before a sampler exists) */
+    SPCBPT_ERR_CAPACITY = -6     /* a caller-provided buffer is too small */
+} spcbpt_status;
+
+/* Disney-principled material; field set of MaterialData::Pbr
+ * (cuda/MaterialData.h:82-100).  albedo_tex is 0 for "none", else texture
+ * index + 1 (OptiXPathTracer/scene_shift.cpp:76-79 uses the same 1-based id). */
+typedef struct spcbpt_material {
+    float base_color[3];
+    float metallic;
+    float roughness;
+    float specular;
+    float specular_tint;
+    float subsurface;
+    float sheen;
+    float sheen_tint;
+    float clearcoat;
+    float clearcoat_gloss;
+    int32_t albedo_tex;
+} spcbpt_material;
+
+/* 8-bit RGBA image, row 0 first, sampled bilinear + wrap, then pow(c, 2.2)
+ * (scene_shift.cpp:40-61, hit_program.cu:182-198, cuProg.h:361-368). */
+typedef struct spcbpt_texture {
+    const uint8_t* rgba;
+    int32_t width;
+    int32_t height;
+} spcbpt_texture;
+
+/* Quad emitter as the `.scene` light{} block gives it
+ * (sceneLoader.cpp:130-193): corner `position`, absolute corner points v1, v2
+ * are stored as edges u = v1-position, v = v2-position.  div_level^2 emitter
+ * patches become light subspaces allocated downward from id 999
+ * (scene_shift.cpp:108-154, cuProg.h:586-589). */
+typedef struct spcbpt_quad_light {
+    float position[3];
+    float u[3];
+    float v[3];
+    float emission[3];
+    int32_t div_level;
+} spcbpt_quad_light;
+
+/* Flat triangle soup.  The library appends two triangles per quad light with
+ * UVs (0,0)(1,0)(0,1)(1,1) and an emissive pseudo-material after the scene
+ * materials, exactly as scene_shift.cpp:92-103, 252-328 does; those triangles
+ * are single-sided for path rays and opaque to shadow rays. */
+typedef struct spcbpt_scene_desc {
+    const float* vertices;        /* 3 * n_vertices */
+    const float* texcoords;       /* 2 * n_vertices, may be NULL (zeros, scene_shift.cpp:204-207) */
+    int32_t n_vertices;
+    const uint32_t* indices;      /* 3 * n_triangles */
+    const int32_t* tri_material;  /* n_triangles, index into materials */
+    int32_t n_triangles;
+    const spcbpt_material* materials;
+    int32_t n_materials;
+    const spcbpt_texture* textures;
+    int32_t n_textures;
+    const spcbpt_quad_light* lights;
+    int32_t n_lights;
+} spcbpt_scene_desc;
+
+/* Octree node of the subspace classifiers; values of classTree::tree_node
+ * (decisionTree/classTree_common.h:11-38).  type: 0 position, 1 normal,
+ * 2 direction.  leaf != 0 -> label is the subspace id. */
+typedef struct spcbpt_tree_node {
+    float mid[3];
+    int32_t child[8];
+    int32_t label;
+    int32_t type;
+    int32_t leaf;
+} spcbpt_tree_node;
+
+/* Launch geometry of the light pass = LightTraceParams
+ * (optixPathTracer.h:52-66; reference values num_core 1000, core_padding 800,
+ * M_per_core 100 from optixPathTracer.cpp:462-468).  Path index p of core c
+ * draws its random numbers from the core's running seed tea<4>(c, frame).
+ * The MI355X default is one light path per lane: num_core = M, M_per_core = 1. */
+typedef struct spcbpt_light_trace_params {
+    int32_t num_core;
+    int32_t core_padding;
+    int32_t m_per_core;
+    int32_t core_begin; /* first core traced by this context (multi-GPU sharding) */
+    int32_t core_count; /* number of cores traced by this context; 0 = all */
+} spcbpt_light_trace_params;
+
+/* One light vertex as exchanged between ranks / checked by tests.  Values of
+ * the BDPTVertex fields the connection code reads (BDPTVertex.h:9-70); the
+ * device layout is the library's own. 96 bytes. */
+typedef struct spcbpt_light_vertex {
+    float position[3];
+    float pdf;
+    float normal[3];
+    float single_pdf;
+    float flux[3];
+    float rmis_pointer;
+    float color[3];
+    float last_lum;
+    float last_position[3];
+    float last_normal_projection;
+    int16_t material_id;
+    int16_t subspace_id;
+    int16_t depth;
+    int16_t last_zone_id;
+    uint32_t path_id;  /* global light path index = core * m_per_core + k */
+    uint32_t pad;
+} spcbpt_light_vertex;
+
+/* Per-subspace record of the sampler = struct Subspace (optixPathTracer.h:43-51). */
+typedef struct spcbpt_subspace {
+    int32_t jump_bias;
+    int32_t id;
+    int32_t size;
+    float sum_pmf;
+    float q;
+} spcbpt_subspace;
+
+/* Event counters behind the algorithmic-bytes roofline. */
+typedef struct spcbpt_counters {
+    uint64_t closest_rays;
+    uint64_t shadow_rays;
+    uint64_t node_visits;
+    uint64_t tri_tests;
+    uint64_t surface_vertices;   /* closest hits that became path vertices */
+    uint64_t textured_hits;
+    uint64_t tree_nodes;         /* octree nodes visited by all classifications */
+    uint64_t cmf_probes;         /* stage-1 + stage-2 binary-search probes */
+    uint64_t connections;        /* light vertices fetched for connection */
+    uint64_t gamma_q_reads;
+    uint64_t lvc_stores;
+    uint64_t pixel_samples;
+    uint64_t eye_paths;
+    uint64_t light_paths;
+} spcbpt_counters;
+
+typedef struct spcbpt_ctx spcbpt_ctx;
+
+/* Replaces LoadScene + LightSource_shift + Scene_shift + sutil::Scene::finalize
+ * (optixPathTracer.cpp:729-741; sutil/Scene.cpp:731-739: context, GAS, IAS,
+ * modules, program groups, pipeline, SBT).  Uploads the scene and builds the
+ * software LBVH.  device = HIP device ordinal. */
+int spcbpt_create(const spcbpt_scene_desc* scene, int device, spcbpt_ctx** out);
+
+/* Frees everything the context owns (the reference never frees). */
+int spcbpt_destroy(spcbpt_ctx* ctx);
+
+/* Last error text for this context (or for a failed create when ctx is NULL). */
+const char* spcbpt_last_error(const spcbpt_ctx* ctx);
+
+/* Replaces handleCameraUpdate: params.eye + Camera::UVWFrame
+ * (optixPathTracer.cpp:352-370; sutil/Camera.cpp:34-45). */
+int spcbpt_set_camera(spcbpt_ctx* ctx, const float eye[3], const float U[3],
+                      const float V[3], const float W[3]);
+
+/* Convenience: derive U,V,W exactly as sutil::Camera::UVWFrame does. */
+int spcbpt_set_camera_lookat(spcbpt_ctx* ctx, const float eye[3], const float lookat[3],
+                             const float up[3], float fov_y_deg, float aspect);
+
+/* Replaces the accum_buffer allocation + params.width/height
+ * (optixPathTracer.cpp:260-265, 319-333).  Clears accumulation. */
+int spcbpt_resize(spcbpt_ctx* ctx, int width, int height);
+
+/* Replaces subspaceInfo.{eye_tree, light_tree, Q, CMFGamma} assignment
+ * (optixPathTracer.cpp:569-572, 606-607).  q has 1000 entries, cmf_gamma
+ * 1000*1000 (row = eye subspace, inclusive CMF over light subspaces).
+ * Passing all-NULL installs the minimal valid tuple of SURVEY.md 7 step 8
+ * (single-leaf trees, Gamma rows proportional to Q estimated from light
+ * passes) instead of the reference's biased null-tree fallback. */
+int spcbpt_set_subspace(spcbpt_ctx* ctx,
+                        const spcbpt_tree_node* eye_tree, int n_eye,
+                        const spcbpt_tree_node* light_tree, int n_light,
+                        const float* q, const float* cmf_gamma);
+
+/* Replaces lt_params_setup (optixPathTracer.cpp:462-477). */
+int spcbpt_set_light_trace(spcbpt_ctx* ctx, const spcbpt_light_trace_params* p);
+
+/* Replaces switchRaygen(name) + optixLaunch (see file header).  name is one of
+ * "pt", "light trace", "SPCBPT_eye", "pretrace".  For "pt" and "SPCBPT_eye"
+ * frame is params.subframe_index and rows [row_begin, row_end) with row stride
+ * row_step are rendered (0, height, 1 = whole image; multi-GPU ranks take
+ * interleaved row blocks).  For "light trace" frame is lt_params.launch_frame
+ * and the row arguments are ignored.  For "pretrace" frame is
+ * pr_params.iteration.  Asynchronous. */
+int spcbpt_launch(spcbpt_ctx* ctx, const char* name, uint32_t frame,
+                  int row_begin, int row_end, int row_step);
+
+/* Replaces MyThrustOp::LVC_Process (cuda_thrust/device_thrust.cu:241-332):
+ * builds cmfs / jump_buffer / Subspace[1000] / vertex_count / path_count from
+ * the LVC currently held by the context, on the device. Asynchronous. */
+int spcbpt_build_sampler(spcbpt_ctx* ctx);
+
+/* Multi-GPU exchange of the compacted LVC shard (no reference counterpart: the
+ * reference is single-GPU).  export: device pointer to the
+ * shard (array of spcbpt_light_vertex) and a device pointer to its int32
+ * count; capacity in vertices.  import: replace the context's LVC by `count`
+ * vertices from a device (is_device != 0) or host buffer. */
+int spcbpt_lvc_export(spcbpt_ctx* ctx, void** d_vertices, void** d_count, int* capacity);
+int spcbpt_lvc_import(spcbpt_ctx* ctx, const void* vertices, int count, int is_device);
+/* Host copy of the LVC in deterministic order (path_id, depth). */
+int spcbpt_lvc_read(spcbpt_ctx* ctx, spcbpt_light_vertex* out, int capacity, int* count);
+
+/* Host copies of the sampler tables (tests, checkpointing). */
+int spcbpt_sampler_read(spcbpt_ctx* ctx, spcbpt_subspace* subspace /*1000*/,
+                        float* cmfs, int32_t* jump, int capacity,
+                        int* vertex_count, int* path_count);
+
+/* accum_buffer (float4 per pixel, row 0 = bottom of the view) and the
+ * tone-mapped sRGB frame (raygen.cu:430-442).  Device pointer variant for
+ * RCCL exchange. */
+int spcbpt_read_accum(spcbpt_ctx* ctx, float* rgba_out);
+int spcbpt_read_frame(spcbpt_ctx* ctx, uint8_t* rgba8_out);
+int spcbpt_accum_device_ptr(spcbpt_ctx* ctx, void** d_accum);
+int spcbpt_clear_accum(spcbpt_ctx* ctx);
+
+int spcbpt_get_counters(spcbpt_ctx* ctx, spcbpt_counters* out);
+int spcbpt_reset_counters(spcbpt_ctx* ctx);
+/* Enable/disable event counting in the kernels (off for timed runs). */
+int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
+
+/* The HIP stream all launches of this context go to (hipStream_t as void*),
+ * so a caller can bracket launches with its own events. */
+int spcbpt_stream(spcbpt_ctx* ctx, void** stream);
+int spcbpt_sync(spcbpt_ctx* ctx);
+
+/* Kernel timing measured with HIP events on the context's stream: average
+ * milliseconds per launch of `name` since the last reset, and launch count. */
+int spcbpt_kernel_time(spcbpt_ctx* ctx, const char* name, double* avg_ms, int* launches);
+int spcbpt_reset_kernel_time(spcbpt_ctx* ctx);
+int spcbpt_enable_kernel_timing(spcbpt_ctx* ctx, int enabled);
+
+/* Standalone traversal entry points (parity tests of the software LBVH
+ * against the oracle's BVH; they are the building block optixTrace is replaced
+ * by: cuProg.h:384-461 closest hit, 463-487 visibilityTest).
+ * rays: n * 8 floats (origin xyz, tmin, direction xyz, tmax).
+ * closest: out_t[n], out_tri[n] (-1 = miss), out_uv[2n]; cull_emitter_backfaces
+ * as OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES acts on the single-sided quads.
+ * any: out_visible[n] = 1 when nothing is hit in (tmin, tmax). */
+int spcbpt_trace_closest(spcbpt_ctx* ctx, const float* rays, int n,
+                         float* out_t, int32_t* out_tri, float* out_uv);
+int spcbpt_trace_any(spcbpt_ctx* ctx, const float* rays, int n, int32_t* out_visible);
+
+/* Host-owned preprocessing = preprocessing() (optixPathTracer.cpp:552-608):
+ * pretrace -> reweight -> subspace trees -> Q -> labels -> Gamma_0 -> Adam
+ * training -> CMF Gamma.  Installs the result with spcbpt_set_subspace.
+ * target_paths / target_q_paths are the reference's 2,000,000 each; smaller
+ * values give a coarser but still valid tuple. */
+int spcbpt_preprocess(spcbpt_ctx* ctx, int target_paths, int target_q_paths, int train);
+
+/* Read back the installed subspace tuple (checkpoint writer the reference lacks). */
+int spcbpt_get_subspace(spcbpt_ctx* ctx,
+                        spcbpt_tree_node* eye_tree, int* n_eye, int cap_eye,
+                        spcbpt_tree_node* light_tree, int* n_light, int cap_light,
+                        float* q, float* cmf_gamma);
+
+/* Scene statistics after create. */
+int spcbpt_scene_info(spcbpt_ctx* ctx, int* n_triangles, int* n_bvh_nodes, int* bvh_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPCBPT_H */

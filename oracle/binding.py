@@ -1,0 +1,253 @@
+"""ORACLE — test infrastructure only.  ctypes binding of oracle/liboracle.so (the
+CPU restatement) and oracle/_ref/libref.so (built from the reference's own
+sources).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this module; nothing under spcbpt-optix7_amd/ does."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "liboracle.so")
+REF_LIB = os.path.join(_HERE, "_ref", "libref.so")
+
+
+def _pkg():
+    import sys
+    root = os.path.dirname(_HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+class EyeVertex(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("normal", C.c_float * 3), ("flux", C.c_float * 3), ("color", C.c_float * 3),
+                ("last_position", C.c_float * 3), ("rmis3", C.c_float * 3), ("pdf", C.c_float), ("single_pdf", C.c_float),
+                ("last_normal_projection", C.c_float), ("material_id", C.c_int32), ("subspace_id", C.c_int32),
+                ("depth", C.c_int32), ("last_zone_id", C.c_int32)]
+
+
+EYE_VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("flux", "<f4", 3), ("color", "<f4", 3),
+                             ("last_position", "<f4", 3), ("rmis3", "<f4", 3), ("pdf", "<f4"), ("single_pdf", "<f4"),
+                             ("last_normal_projection", "<f4"), ("material_id", "<i4"), ("subspace_id", "<i4"),
+                             ("depth", "<i4"), ("last_zone_id", "<i4")])
+assert EYE_VERTEX_DTYPE.itemsize == C.sizeof(EyeVertex)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} not built: make -C oracle")
+        _lib = C.CDLL(LIB)
+        _lib.orc_create.restype = C.c_void_p
+        _lib.orc_rnd.restype = C.c_float
+        _lib.orc_tea4.restype = C.c_uint32
+    return _lib
+
+
+def ref_lib():
+    if not os.path.exists(REF_LIB):
+        return None
+    r = C.CDLL(REF_LIB)
+    r.ref_rnd.restype = C.c_float
+    r.ref_tea4.restype = C.c_uint32
+    r.ref_lcg.restype = C.c_uint32
+    return r
+
+
+class Oracle:
+    """CPU restatement driven like the product Renderer."""
+
+    def __init__(self, scene, nthreads: int = 0):
+        self.pkg = _pkg()
+        self.l = lib()
+        sd, self._keep = scene.desc()
+        self.h = C.c_void_p(self.l.orc_create(C.byref(sd)))
+        self.width = self.height = 0
+        self.nthreads = nthreads or (os.cpu_count() or 1)
+        self.lt = None
+
+    def close(self):
+        if self.h:
+            self.l.orc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, eye, U, V, W):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (eye, U, V, W)]
+        self.l.orc_set_camera(self.h, *[C.c_void_p(x.ctypes.data) for x in a])
+
+    def set_camera_lookat(self, eye, lookat, up, fov, aspect):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (eye, lookat, up)]
+        U, V, W = (np.zeros(3, np.float32) for _ in range(3))
+        self.l.orc_camera_frame(*[C.c_void_p(x.ctypes.data) for x in a], C.c_float(fov), C.c_float(aspect),
+                                C.c_void_p(U.ctypes.data), C.c_void_p(V.ctypes.data), C.c_void_p(W.ctypes.data))
+        self.set_camera(a[0], U, V, W)
+        return U, V, W
+
+    def resize(self, w, h):
+        self.l.orc_resize(self.h, w, h)
+        self.width, self.height = w, h
+
+    def set_subspace(self, eye_tree=None, light_tree=None, q=None, cmf_gamma=None):
+        p = self.pkg
+        if eye_tree is None:
+            self.l.orc_set_subspace(self.h, None, 0, None, 0, None, None)
+            return
+        et = np.ascontiguousarray(eye_tree, dtype=p.TREE_NODE_DTYPE)
+        lt = np.ascontiguousarray(light_tree, dtype=p.TREE_NODE_DTYPE)
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        g = np.ascontiguousarray(cmf_gamma, dtype=np.float32)
+        self._sub_keep = (et, lt, q, g)
+        self.l.orc_set_subspace(self.h, C.c_void_p(et.ctypes.data), et.shape[0], C.c_void_p(lt.ctypes.data), lt.shape[0],
+                                C.c_void_p(q.ctypes.data), C.c_void_p(g.ctypes.data))
+
+    def set_light_trace(self, num_core, core_padding, m_per_core):
+        self.l.orc_set_light_trace(self.h, num_core, core_padding, m_per_core)
+        self.lt = (num_core, core_padding, m_per_core)
+
+    def enable_counters(self, on):
+        self.l.orc_enable_counters(self.h, int(on))
+
+    def launch(self, name, frame, rows=None, nthreads=None):
+        r0, r1, rs = rows if rows is not None else (0, self.height, 1)
+        rc = self.l.orc_launch(self.h, name.encode(), C.c_uint(frame), r0, r1, rs, nthreads or self.nthreads)
+        if rc != 0:
+            raise RuntimeError(f"orc_launch({name}) -> {rc}")
+
+    def build_sampler(self):
+        self.l.orc_build_sampler(self.h)
+
+    def render_frame(self, alg, subframe, launch_frame=None, rows=None):
+        if alg == "SPCBPT_eye":
+            self.launch("light trace", subframe + 1 if launch_frame is None else launch_frame)
+            self.build_sampler()
+        self.launch(alg, subframe, rows)
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self.l.orc_read_accum(self.h, C.c_void_p(out.ctypes.data))
+        return out
+
+    def read_frame(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self.l.orc_read_frame(self.h, C.c_void_p(out.ctypes.data))
+        return out
+
+    def clear_accum(self):
+        self.l.orc_clear_accum(self.h)
+
+    def lvc_read(self):
+        n = C.c_int()
+        self.l.orc_lvc_read(self.h, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=self.pkg.LIGHT_VERTEX_DTYPE)
+        self.l.orc_lvc_read(self.h, C.c_void_p(out.ctypes.data), n.value, C.byref(n))
+        return out
+
+    def lvc_import(self, verts):
+        v = np.ascontiguousarray(verts, dtype=self.pkg.LIGHT_VERTEX_DTYPE)
+        self.l.orc_lvc_import(self.h, C.c_void_p(v.ctypes.data), v.shape[0])
+
+    def sampler_read(self, capacity=1 << 22):
+        p = self.pkg
+        sub = np.zeros(p.NUM_SUBSPACE, dtype=p.SUBSPACE_DTYPE)
+        cmfs = np.zeros(capacity, dtype=np.float32)
+        jump = np.zeros(capacity, dtype=np.int32)
+        vc, pc = C.c_int(), C.c_int()
+        rc = self.l.orc_sampler_read(self.h, C.c_void_p(sub.ctypes.data), C.c_void_p(cmfs.ctypes.data),
+                                     C.c_void_p(jump.ctypes.data), capacity, C.byref(vc), C.byref(pc))
+        if rc != 0:
+            raise RuntimeError(f"orc_sampler_read -> {rc}")
+        return sub, cmfs[:vc.value].copy(), jump[:vc.value].copy(), vc.value, pc.value
+
+    def counters(self):
+        from_api = self.pkg.api.Counters()
+        self.l.orc_get_counters(self.h, C.byref(from_api))
+        return from_api.as_dict()
+
+    def reset_counters(self):
+        self.l.orc_reset_counters(self.h)
+
+    def trace_closest(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        t = np.zeros(n, np.float32)
+        tri = np.zeros(n, np.int32)
+        uv = np.zeros((n, 2), np.float32)
+        self.l.orc_trace_closest(self.h, C.c_void_p(r.ctypes.data), n, C.c_void_p(t.ctypes.data), C.c_void_p(tri.ctypes.data),
+                                 C.c_void_p(uv.ctypes.data), self.nthreads)
+        return t, tri, uv
+
+    def trace_any(self, rays):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        vis = np.zeros(n, np.int32)
+        self.l.orc_trace_any(self.h, C.c_void_p(r.ctypes.data), n, C.c_void_p(vis.ctypes.data), self.nthreads)
+        return vis
+
+    def connect(self, eye_vertices, light_vertices):
+        a = np.ascontiguousarray(eye_vertices, dtype=EYE_VERTEX_DTYPE)
+        b = np.ascontiguousarray(light_vertices, dtype=self.pkg.LIGHT_VERTEX_DTYPE)
+        n = a.shape[0]
+        rgb = np.zeros((n, 3), np.float32)
+        w = np.zeros(n, np.float32)
+        self.l.orc_connect(self.h, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), n, C.c_void_p(rgb.ctypes.data),
+                           C.c_void_p(w.ctypes.data))
+        return rgb, w
+
+
+def material_struct(d):
+    p = _pkg()
+    m = p.api.Material()
+    m.base_color[:] = [float(x) for x in d.get("color", (1, 1, 1))]
+    m.metallic = d.get("metallic", 0.0); m.roughness = d.get("roughness", 0.5); m.specular = d.get("specular", 0.5)
+    m.specular_tint = d.get("specular_tint", 0.0); m.subsurface = d.get("subsurface", 0.0); m.sheen = d.get("sheen", 0.0)
+    m.sheen_tint = d.get("sheen_tint", 0.5); m.clearcoat = d.get("clearcoat", 0.0); m.clearcoat_gloss = d.get("clearcoat_gloss", 1.0)
+    m.albedo_tex = 0
+    return m
+
+
+def bsdf_eval_pdf(mat: dict, nvl: np.ndarray):
+    m = material_struct(mat)
+    a = np.ascontiguousarray(nvl, dtype=np.float32).reshape(-1, 9)
+    f = np.zeros((a.shape[0], 3), np.float32)
+    pdf = np.zeros(a.shape[0], np.float32)
+    lib().orc_bsdf_eval_pdf(C.byref(m), C.c_void_p(a.ctypes.data), a.shape[0], C.c_void_p(f.ctypes.data), C.c_void_p(pdf.ctypes.data))
+    return f, pdf
+
+
+def bsdf_sample(mat: dict, nv: np.ndarray, seeds: np.ndarray):
+    m = material_struct(mat)
+    a = np.ascontiguousarray(nv, dtype=np.float32).reshape(-1, 6)
+    s = np.ascontiguousarray(seeds, dtype=np.uint32).copy()
+    out = np.zeros((a.shape[0], 3), np.float32)
+    lib().orc_bsdf_sample(C.byref(m), C.c_void_p(a.ctypes.data), C.c_void_p(s.ctypes.data), a.shape[0], C.c_void_p(out.ctypes.data))
+    return out, s
+
+
+def binary_sample(cmf: np.ndarray, seed: int):
+    c = np.ascontiguousarray(cmf, dtype=np.float32)
+    s = C.c_uint32(seed)
+    pmf = C.c_float()
+    idx = lib().orc_binary_sample(C.c_void_p(c.ctypes.data), c.shape[0], C.byref(s), C.byref(pmf))
+    return idx, pmf.value, s.value
+
+
+def tree_index(tree: np.ndarray, pnd: np.ndarray):
+    p = _pkg()
+    t = np.ascontiguousarray(tree, dtype=p.TREE_NODE_DTYPE)
+    a = np.ascontiguousarray(pnd, dtype=np.float32).reshape(-1, 9)
+    out = np.zeros(a.shape[0], np.int32)
+    lib().orc_tree_index(C.c_void_p(t.ctypes.data), t.shape[0], C.c_void_p(a.ctypes.data), a.shape[0], C.c_void_p(out.ctypes.data))
+    return out

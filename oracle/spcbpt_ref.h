@@ -1,0 +1,922 @@
+// ORACLE — test infrastructure only (see vec.h).
+// CPU restatement of the SPCBPT hot path of ssufujia/SPCBPT-OptiX7.  Every
+// function cites the reference file:line it follows (paths relative to
+// src/OptiXPathTracer unless prefixed).  Scope: QUAD lights only — the
+// DIRECTION/ENV branches are "unfinished" in the reference (readme.md:29,
+// SURVEY q1) and belong to row f4; `isBrdf/inBrdf/lastBrdf` are never true
+//  so their early-outs are omitted.
+//
+// PARITY STATUS: the reference cannot be built here (needs the OptiX 7.5 SDK
+// headers + nvcc; no stand-ins are written).  Pinned pieces: rng.h against the
+// reference's own cuda/random.h (oracle/_ref), sRGB/quantize and the camera
+// frame against cuda/helpers.h and sutil/Camera.cpp (oracle/_ref), the BSDF
+// against the known answer recorded in SURVEY.md a7.  Everything else in this
+// file is PARITY UNPINNED: a careful restatement with no reference output to
+// check against.
+#pragma once
+#include <cfloat>
+#include <vector>
+
+#include "bsdf.h"
+#include "rng.h"
+#include "scene.h"
+#include "vec.h"
+
+namespace orc {
+
+enum LightType { SPHERE, QUAD, DIRECTION, ENV, HIT_LIGHT_SOURCE, ENV_MISS, NORMALHIT };  // light_parameters.h:8-11
+
+// classTree::tree_node (decisionTree/classTree_common.h:11-38)
+struct tree_node {
+    float3 mid;
+    int child[8];
+    int label;
+    int type;  // 0 position, 1 normal, 2 direction
+    bool leaf;
+    int getChild(float3 p) const {
+        int ind = 0;
+        ind += p.x > mid.x ? 1 : 0;
+        ind += p.y > mid.y ? 2 : 0;
+        ind += p.z > mid.z ? 4 : 0;
+        return child[ind];
+    }
+    int operator()(float3 position, float3 normal, float3 direction) const {
+        return type == 0 ? getChild(position) : (type == 1 ? getChild(normal) : getChild(direction));
+    }
+};
+// classTree::tree_index (classTree_common.h:39-51)
+inline int tree_index(const tree_node* root, float3 position, float3 normal, float3 direction, Counters* c) {
+    int node_id = 0;
+    if (c) c->tree_nodes++;
+    while (root[node_id].leaf == false) {
+        node_id = root[node_id](position, normal, direction);
+        if (c) c->tree_nodes++;
+    }
+    return root[node_id].label;
+}
+
+// BDPTVertex (BDPTVertex.h:9-70), value-initialised
+struct BDPTVertex {
+    float3 position{}, normal{}, flux{}, color{}, lastPosition{}, RMIS_pointer_3{};
+    float2 uv{};
+    float RMIS_pointer = 0, last_lum = 0, lastNormalProjection = 0, pdf = 0, singlePdf = 0, lastSinglePdf = 0;
+    short materialId = 0, subspaceId = 0, depth = 0, lastZoneId = 0, type = QUAD;
+    bool isOrigin = false;
+    uint32_t path_id = 0;  // oracle-only bookkeeping (global light path index)
+};
+
+struct BDPTPath {  // BDPTVertex.h:72-117, 3-slot ring
+    BDPTVertex v[3];
+    int size = 0;
+    BDPTVertex& operator()(int i) { return v[(size - 1 - i) % 3]; }
+    BDPTVertex& currentVertex() { return (*this)(0); }
+    BDPTVertex& nextVertex() { return (*this)(-1); }
+    BDPTVertex& lastVertex() { return (*this)(1); }
+    void clear() { size = 0; }
+    void push() { size++; }
+    bool hit_lightSource() { return currentVertex().type == HIT_LIGHT_SOURCE || currentVertex().type == ENV_MISS; }
+};
+
+struct Subspace { int jump_bias, id, size; float sum_pmf, Q; };  // optixPathTracer.h:43-51
+
+struct LightTraceParams {  // optixPathTracer.h:52-66
+    int num_core = 1000, core_padding = 800, M_per_core = 100, launch_frame = 0;
+    BDPTVertex* ans = nullptr;
+    uint8_t* validState = nullptr;
+    int get_element_count() const { return num_core * core_padding; }
+};
+
+struct SubspaceSampler {  // optixPathTracer.h:89-97
+    const BDPTVertex* LVC = nullptr;
+    const Subspace* subspace = nullptr;
+    const float* cmfs = nullptr;
+    const int* jump_buffer = nullptr;
+    int vertex_count = 0, path_count = 0;
+};
+struct SamplerStorage {  // the function-static thrust vectors of LVC_Process (device_thrust.cu:287-293)
+    std::vector<Subspace> subspace;
+    std::vector<float> cmfs;
+    std::vector<int> jump_buffer;
+};
+
+struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
+    const Scene* scene = nullptr;
+    unsigned width = 0, height = 0, subframe_index = 0;
+    float4* accum_buffer = nullptr;
+    uint32_t* frame_buffer = nullptr;  // uchar4 packed, may be null
+    float3 eye{}, U{}, V{}, W{};
+    LightTraceParams lt;
+    SubspaceSampler sampler;
+    // subspaceMacroInfo (optixPathTracer.h:166-190)
+    const tree_node* eye_tree = nullptr;
+    const tree_node* light_tree = nullptr;
+    const float* Q = nullptr;
+    const float* CMFGamma = nullptr;
+    Counters* counters = nullptr;
+
+    float Gamma(int eye_id, int light_id) const {
+        if (CMFGamma && Q) {
+            if (counters) counters->gamma_q_reads += light_id == 0 ? 1 : 2;
+            return light_id == 0 ? CMFGamma[eye_id * SPCBPT_NUM_SUBSPACE + light_id]
+                                 : CMFGamma[eye_id * SPCBPT_NUM_SUBSPACE + light_id] -
+                                       CMFGamma[eye_id * SPCBPT_NUM_SUBSPACE + light_id - 1];
+        }
+        return 1;
+    }
+    float gamma_ss(int eye_id, int light_id) const {
+        if (CMFGamma && Q) {
+            if (counters) counters->gamma_q_reads++;
+            return Gamma(eye_id, light_id) / Q[light_id];
+        }
+        return 1;
+    }
+};
+
+// labelUnit::getLabel (cuProg.h:1109-1123)
+inline int getLabel(const Params& P, float3 position, float3 normal, float3 dir, bool light_side) {
+    if (light_side) {
+        if (P.light_tree) return tree_index(P.light_tree, position, normal, dir, P.counters);
+    } else {
+        if (P.eye_tree) return tree_index(P.eye_tree, position, normal, dir, P.counters);
+    }
+    return 0;
+}
+
+// connectRate_SOL (cuProg.h:70-78)
+inline float connectRate_SOL(const Params& P, int eye_label, int light_label, float lum_sum) {
+    return P.gamma_ss(eye_label, light_label) * lum_sum * SPCBPT_CONNECTION_N;
+}
+inline float3 connectRate_SOL(const Params& P, int eye_label, int light_label, float3 lum_sum) {
+    return P.gamma_ss(eye_label, light_label) * lum_sum * (float)SPCBPT_CONNECTION_N;
+}
+
+// lightSample (cuProg.h:554-666), QUAD branch
+struct lightSample {
+    float3 position{}, emission{}, direction{};
+    float2 uv{};
+    const Light* bindLight = nullptr;
+    float pdf = 0, dir_pdf = 0;
+    int subspaceId = 0;
+    void ReverseSample(const Params& P, const Light& light, float2 uv_) {  // 571-591
+        bindLight = &light;
+        float r1 = uv_.x, r2 = uv_.y, r3 = 1 - r1 - r2;
+        position = light.u * r1 + light.v * r2 + light.corner * r3;
+        emission = light.emission;
+        pdf = (float)(1.0 / (double)light.area);
+        pdf /= (float)P.scene->lights.size();
+        uv = make_float2(r1, r2);
+        int x_block = clampi((int)floorf(uv.x * light.divLevel), 0, light.divLevel - 1);
+        int y_block = clampi((int)floorf(uv.y * light.divLevel), 0, light.divLevel - 1);
+        int lightSpaceId = light.ssBase + x_block * light.divLevel + y_block;
+        subspaceId = SPCBPT_NUM_SUBSPACE - lightSpaceId - 1;
+    }
+    void sample(const Params& P, const Light& light, uint32_t& seed) {  // 602-621
+        float r1 = rnd(seed);
+        float r2 = rnd(seed);
+        ReverseSample(P, light, make_float2(r1, r2));
+        bindLight = &light;
+    }
+    void sample(const Params& P, uint32_t& seed) {  // 622-627
+        int n = (int)P.scene->lights.size();
+        int light_id = clampi((int)floorf(rnd(seed) * n), 0, n - 1);
+        sample(P, P.scene->lights[light_id], seed);
+    }
+    float3 normal() const { return bindLight ? bindLight->normal : make_float3(0); }  // 628-643
+    float3 trace_direction() const { return direction; }                               // 644-647
+    void traceMode(uint32_t& seed) {                                                   // 648-665
+        float r1 = rnd(seed);
+        float r2 = rnd(seed);
+        Onb onb(bindLight->normal);
+        cosine_sample_hemisphere(r1, r2, direction);
+        onb.inverse_transform(direction);
+        dir_pdf = fabsf(dot(direction, bindLight->normal)) / M_PIf_;
+    }
+};
+
+// PayloadBDPTVertex (cuProg.h:303-323)
+struct PayloadBDPTVertex {
+    BDPTPath path;
+    float3 origin{}, ray_direction{}, throughput{}, result{};
+    float pdf = 0;
+    uint32_t seed = 0;
+    int depth = 0;
+    bool done = false;
+    void clear() {
+        path.clear();
+        depth = 0;
+        done = false;
+        throughput = make_float3(1);
+        result = make_float3(0.0f);
+    }
+};
+// whitted::PayloadRadiance (whitted.h:86-108)
+struct PayloadRadiance {
+    float3 vis_pos_A{}, vis_pos_B{}, currentResult{};
+    float3 result = make_float3(0), origin{}, ray_direction{}, throughput = make_float3(1.0f);
+    float pdf = 0;
+    int depth = 0;
+    uint32_t seed = 0;
+    bool done = false;
+};
+
+// ------------------------------------------------------------------ rmis.h
+namespace rmis {
+inline Pbr getMat(const Params& P, const BDPTVertex& v) {  // rmis.h:16-21
+    Pbr mat = P.scene->materials[v.materialId];
+    mat.base_color = v.color;
+    return mat;
+}
+inline void tracing_init_light(BDPTVertex& Mid, BDPTVertex& Last) {  // 22-26
+    Mid.RMIS_pointer = Last.RMIS_pointer / Last.singlePdf;
+}
+inline float getRR(const BDPTVertex& v) {  // 28-40 ; max(float, 0.3) with the double literal (q10)
+    float rr_rate = fmaxf3(v.color);
+    rr_rate = (float)((double)rr_rate > 0.3 ? (double)rr_rate : 0.3);
+    return rr_rate;
+}
+inline float getLast_pdf(const Params& P, const BDPTVertex& Mid, float3 in_dir) {  // 41-51
+    Pbr mat = getMat(P, Mid);
+    float3 out_vec = Mid.lastPosition - Mid.position;
+    float3 out_dir = normalize(out_vec);
+    float pdf = Pdf(mat, Mid.normal, in_dir, out_dir) / dot(out_vec, out_vec) * Mid.lastNormalProjection;
+    pdf *= getRR(Mid);
+    return pdf;
+}
+inline float getLL_pdf(const Params& P, const BDPTVertex& Mid, const BDPTVertex& Last) {  // 52-57
+    float3 in_dir = normalize(Mid.position - Last.position);
+    return getLast_pdf(P, Last, in_dir);
+}
+inline float tracing_weight_light(const Params& P, const BDPTVertex& Mid, const BDPTVertex& Last) {  // 58-79
+    float3 inver_dir = normalize(Mid.position - Last.position);
+    int eye_label = getLabel(P, Last.position, Last.normal, inver_dir, false);
+    int light_label = Last.lastZoneId;
+    float lum_sum = Last.last_lum;
+    return connectRate_SOL(P, eye_label, light_label, lum_sum);
+}
+inline void tracing_update_light(const Params& P, BDPTVertex& Mid, BDPTVertex& Last) {  // 80-94
+    float LL_pdf = getLL_pdf(P, Mid, Last);
+    float weight = tracing_weight_light(P, Mid, Last);
+    float last_single_pdf = Last.singlePdf;
+    Mid.RMIS_pointer = ((Last.RMIS_pointer * LL_pdf) + weight) / last_single_pdf;
+}
+inline float3 getFluxMultiplier(const Params& P, const BDPTVertex& v, float3 in_dir, float3 out_dir) {  // 102-112
+    Pbr mat = getMat(P, v);
+    float3 flux_ratio = Eval(mat, v.normal, in_dir, out_dir);
+    float pdf_ratio = Pdf(mat, v.normal, in_dir, out_dir);
+    float rr = getRR(v);
+    float cos_theta = fabsf(dot(v.normal, out_dir));
+    return flux_ratio * cos_theta / pdf_ratio / rr;
+}
+inline float3 getFluxMultiplier(const Params& P, const BDPTVertex& v, float3 in_dir) {  // 113-118
+    float3 out_vec = v.lastPosition - v.position;
+    float3 out_dir = normalize(out_vec);
+    return getFluxMultiplier(P, v, in_dir, out_dir);
+}
+inline float3 tracing_weight_eye(const Params& P, const BDPTVertex& Mid, const BDPTVertex& Last) {  // 131-151
+    if (Last.depth == 1) return make_float3(0.0f);
+    float3 inver_dir = normalize(Mid.position - Last.position);
+    int eye_label = Last.lastZoneId;
+    int light_label = getLabel(P, Last.position, Last.normal, inver_dir, true);
+    float3 lum = make_float3(1.0f);
+    return connectRate_SOL(P, eye_label, light_label, lum);
+}
+inline float getPdf(const Params& P, const BDPTVertex& begin, const BDPTVertex& end, float3 in_dir) {  // 153-172
+    Pbr mat = getMat(P, begin);
+    float3 out_vec = end.position - begin.position;
+    float3 out_dir = normalize(out_vec);
+    float pdf = Pdf(mat, begin.normal, in_dir, out_dir) / dot(out_vec, out_vec) * fabsf(dot(out_dir, end.normal));
+    pdf *= getRR(begin);
+    return pdf;
+}
+inline float getPdf_from_light_source(const BDPTVertex& light, const BDPTVertex& end) {  // 173-188 ; M_PI is double
+    float3 conn_vec = end.position - light.position;
+    float3 conn_dir = normalize(conn_vec);
+    float pdf_angle = (float)((double)fabsf(dot(light.normal, conn_dir)) / 3.14159265358979323846);
+    float angle2a = fabsf(dot(end.normal, conn_dir)) / (dot(conn_vec, conn_vec));
+    return pdf_angle * angle2a;
+}
+inline void tracing_update_eye(const Params& P, BDPTVertex& Mid, BDPTVertex& Last) {  // 189-203
+    float LL_pdf = getLL_pdf(P, Mid, Last);
+    float3 weight = tracing_weight_eye(P, Mid, Last);
+    float last_single_pdf = Last.singlePdf;
+    float3 flux_multiplier = getFluxMultiplier(P, Last, normalize(Mid.position - Last.position));
+    Mid.RMIS_pointer_3 = ((Last.RMIS_pointer_3 * LL_pdf * flux_multiplier) + weight) / last_single_pdf;
+}
+inline void tracing_init_eye(BDPTVertex& Mid, BDPTVertex&) { Mid.RMIS_pointer_3 = make_float3(0.0f); }  // 204-207
+
+inline float general_connection(const Params& P, const BDPTVertex& eye, const BDPTVertex& light) {  // 212-247
+    float3 connect_vec = eye.position - light.position;
+    float3 connect_dir = normalize(connect_vec);
+    float3 flux = light.flux / light.pdf;
+
+    float LL_pdf_A = getLL_pdf(P, light, eye);
+    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, -connect_dir);
+    float3 weight_A = tracing_weight_eye(P, light, eye);
+    float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
+
+    float3 LA = normalize(light.lastPosition - light.position);
+    float pdf_A = getPdf(P, light, eye, LA);
+    float3 flux_multiplier_1 = getFluxMultiplier(P, light, LA, connect_dir);
+    float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
+
+    float weight = float3weight(connectRate_SOL(P, eye.subspaceId, light.subspaceId, flux));
+
+    float LL_pdf_B = getLL_pdf(P, eye, light);
+    float weight_B = tracing_weight_light(P, eye, light);
+    float D_B_0 = (light.RMIS_pointer * LL_pdf_B) + weight_B;
+
+    float3 LB = normalize(eye.lastPosition - eye.position);
+    float pdf_B = getPdf(P, eye, light, LB);
+    float D_B = D_B_0 * pdf_B / light.singlePdf;
+    return weight / (weight + D_A + D_B);
+}
+inline float connection_lightSource(const Params& P, const BDPTVertex& eye, const BDPTVertex& light) {  // 281-313
+    float3 connect_vec = eye.position - light.position;
+    float3 connect_dir = normalize(connect_vec);
+    float3 flux = light.flux / light.pdf;
+
+    float LL_pdf_A = getLL_pdf(P, light, eye);
+    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, -connect_dir);
+    float3 weight_A = tracing_weight_eye(P, light, eye);
+    float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
+
+    float pdf_A = getPdf_from_light_source(light, eye);
+    float flux_multiplier_1 = M_PIf_;
+    float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
+
+    float weight = float3weight(connectRate_SOL(P, eye.subspaceId, light.subspaceId, flux));
+
+    float D_B_0 = light.RMIS_pointer;
+    float3 LB = normalize(eye.lastPosition - eye.position);
+    float pdf_B = getPdf(P, eye, light, LB);
+    float D_B = D_B_0 * pdf_B / light.singlePdf;
+    return weight / (weight + D_A + D_B);
+}
+inline float light_hit(const Params& P, BDPTVertex& eye, BDPTVertex& light) {  // 359-389
+    float3 connect_vec = eye.position - light.position;
+    float3 connect_dir = normalize(connect_vec);
+    float3 flux = light.flux / light.pdf;
+
+    float LL_pdf_A = getLL_pdf(P, light, eye);
+    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, -connect_dir);
+    float3 weight_A = tracing_weight_eye(P, light, eye);
+    float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
+
+    float pdf_A = getPdf_from_light_source(light, eye);
+    float flux_multiplier_1 = M_PIf_;
+    float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
+    float weight = float3weight(connectRate_SOL(P, eye.subspaceId, light.subspaceId, flux));
+
+    float D_B = light.RMIS_pointer;
+    float3 LB = normalize(eye.lastPosition - eye.position);
+    float pdf_B = getPdf(P, eye, light, LB);
+    return D_B / ((weight + D_A) / pdf_B * light.singlePdf + D_B);
+}
+}  // namespace rmis
+
+// -------------------------------------------------------------- hit programs
+struct HitInfo {  // what optixGet* hands a closest-hit program
+    int tri;
+    float t_hit;
+    float3 ray_direction;
+    float bu, bv;
+};
+
+inline float rr_rate_of(float3 color) {  // hit_program.cu:325-328 / 423-427
+    float rr_rate = fmaxf3(color);
+    rr_rate = rr_rate < SPCBPT_MIN_RR_RATE ? SPCBPT_MIN_RR_RATE : rr_rate;
+    return rr_rate;
+}
+
+// __closesthit__eyeSubpath (hit_program.cu:246-340) and __closesthit__lightSubpath (341-438)
+inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const HitInfo& h, bool light_side) {
+    const Scene& S = *P.scene;
+    const LocalGeometry geom = getLocalGeometry(S, h.tri, h.bu, h.bv);
+    float t_hit = h.t_hit;
+    float3 ray_direction = h.ray_direction;
+    float3 inver_ray_direction = -ray_direction;
+    Pbr currentPbr = S.materials[S.tri_mat[h.tri]];
+    ColorTexSample(S, geom, currentPbr, P.counters);
+    float3 N = geom.N;
+    if (dot(N, ray_direction) > 0.f) N = -N;
+    prd->ray_direction = Sample(currentPbr, N, inver_ray_direction, prd->seed);
+    prd->pdf = Pdf(currentPbr, N, inver_ray_direction, prd->ray_direction);
+    prd->origin = geom.P;
+    if (!(prd->pdf > 0.0f)) prd->done = true;
+
+    prd->path.push();
+    BDPTVertex& Mid = prd->path.currentVertex();
+    BDPTVertex& Next = prd->path.nextVertex();
+    BDPTVertex& Last = prd->path.lastVertex();
+    Mid.position = geom.P;
+    Mid.normal = N;
+    Mid.type = NORMALHIT;
+    float pdf_G = fabsf(dot(Mid.normal, ray_direction) * dot(Last.normal, ray_direction)) / (t_hit * t_hit);
+    if (Last.isOrigin) Mid.flux = Last.flux * pdf_G;
+    else Mid.flux = Mid.flux * Last.flux * pdf_G;
+    Next.flux = Eval(currentPbr, N, -ray_direction, prd->ray_direction);
+    Next.singlePdf = prd->pdf;
+
+    Mid.lastPosition = Last.position;
+    Mid.color = currentPbr.base_color;
+    Mid.lastNormalProjection = fabsf(dot(Last.normal, ray_direction));
+    Mid.materialId = (short)S.tri_mat[h.tri];
+    Mid.subspaceId = (short)getLabel(P, Mid.position, Mid.normal, -ray_direction, light_side);
+    Mid.lastZoneId = Last.subspaceId;
+    Mid.isOrigin = false;
+    Mid.depth = Last.depth + 1;
+    Mid.uv = geom.UV;
+
+    Mid.singlePdf = Mid.singlePdf * pdf_G / fabsf(dot(Last.normal, ray_direction));
+    Mid.pdf = Last.pdf * Mid.singlePdf;
+    if (light_side) Mid.last_lum = float3weight(Last.flux / Last.pdf);  // 408
+
+    Mid.lastSinglePdf = Last.singlePdf;
+    if (light_side) {
+        if (Last.isOrigin) rmis::tracing_init_light(Mid, Last);
+        else rmis::tracing_update_light(P, Mid, Last);
+    } else {
+        if (Mid.depth == 1) rmis::tracing_init_eye(Mid, Last);
+        else rmis::tracing_update_eye(P, Mid, Last);
+    }
+    if (P.counters) P.counters->surface_vertices++;
+
+    float r = rnd(prd->seed);
+    float rr_rate = rr_rate_of(Mid.color);
+    if (r > rr_rate) {
+        prd->done = true;
+    } else {
+        Next.singlePdf *= rr_rate;
+        if (!light_side) prd->throughput *= Next.flux / prd->pdf / rr_rate * dot(N, prd->ray_direction);
+    }
+}
+
+// __closesthit__eyeSubpath_LightSource (hit_program.cu:62-147)
+inline void closesthit_eyeSubpath_LightSource(const Params& P, PayloadBDPTVertex* prd, const HitInfo& h) {
+    const Scene& S = *P.scene;
+    prd->done = true;
+    const int light_id = S.mat_light_id[S.tri_mat[h.tri]];
+    const Light& light = S.lights[light_id];
+    if (dot(prd->ray_direction, light.normal) > 0) return;
+
+    const LocalGeometry geom = getLocalGeometry(S, h.tri, h.bu, h.bv);
+    float t_hit = h.t_hit;
+    float3 ray_direction = h.ray_direction;
+
+    prd->path.push();
+    BDPTVertex& Mid = prd->path.currentVertex();
+    BDPTVertex& Last = prd->path.lastVertex();
+    Mid.position = geom.P;
+    Mid.normal = light.normal;
+    Mid.type = HIT_LIGHT_SOURCE;
+    Mid.uv = geom.UV;
+    lightSample light_sample;
+    light_sample.ReverseSample(P, light, Mid.uv);
+    float lightPdf = light_sample.pdf;
+
+    float pdf_G = fabsf(dot(Mid.normal, ray_direction) * dot(Last.normal, ray_direction)) / (t_hit * t_hit);
+    if (Last.isOrigin) Mid.flux = Last.flux * pdf_G * light_sample.emission;
+    else Mid.flux = Mid.flux * Last.flux * pdf_G * light_sample.emission;
+
+    Mid.lastPosition = Last.position;
+    Mid.lastNormalProjection = fabsf(dot(Last.normal, ray_direction));
+    Mid.subspaceId = (short)light_sample.subspaceId;
+    Mid.lastZoneId = Last.subspaceId;
+    Mid.singlePdf = Mid.singlePdf * pdf_G / fabsf(dot(Last.normal, ray_direction));
+    Mid.pdf = Last.pdf * Mid.singlePdf;
+    Mid.materialId = (short)light_id;
+    Mid.depth = Last.depth + 1;
+
+    if (Mid.depth == 1) {
+        Mid.RMIS_pointer = 1.0f;
+        return;
+    }
+    BDPTVertex virtual_light;
+    virtual_light.position = Mid.position;
+    virtual_light.RMIS_pointer = 1;
+    virtual_light.normal = Mid.normal;
+    virtual_light.pdf = lightPdf;
+    virtual_light.singlePdf = lightPdf;
+    virtual_light.flux = light_sample.emission;
+    virtual_light.subspaceId = Mid.subspaceId;
+    Mid.RMIS_pointer = (float)(1.0 / (double)rmis::light_hit(P, Last, virtual_light));
+}
+
+// __closesthit__radiance (hit_program.cu:439-552), QUAD branch
+inline void closesthit_radiance(const Params& P, PayloadRadiance* prd, const HitInfo& h) {
+    const Scene& S = *P.scene;
+    const LocalGeometry geom = getLocalGeometry(S, h.tri, h.bu, h.bv);
+    Pbr currentPbr = S.materials[S.tri_mat[h.tri]];
+    ColorTexSample(S, geom, currentPbr, P.counters);
+    float3 N = geom.N;
+    if (dot(N, h.ray_direction) > 0.f) N = -N;
+    float3 in_dir = -prd->ray_direction;
+    float3 result = make_float3(0.0f);
+    // clamp(fmaxf(color), MIN_RR_RATE, 1.0): the only viable overload is vec_math's clamp(float,float,float)
+    float rr_rate = clampf(fmaxf3(currentPbr.base_color), 0.3f, 1.0f);
+    int n_lights = (int)S.lights.size();
+    int light_id = clampi((int)floorf(rnd(prd->seed) * n_lights), 0, n_lights - 1);
+    const Light& light = S.lights[light_id];
+    {
+        lightSample light_sample;
+        light_sample.sample(P, light, prd->seed);
+        const float L_dist = length(light_sample.position - geom.P);
+        const float3 L = (light_sample.position - geom.P) / L_dist;
+        const float3 V = -normalize(h.ray_direction);
+        const float3 LN = light.normal;
+        const float L_dot_LN = dot(-L, LN);
+        const float N_dot_L = dot(N, L);
+        const float N_dot_V = dot(N, V);
+        if (N_dot_L > 0.0f && N_dot_V > 0.0f && L_dot_LN > 0.0f) {
+            prd->vis_pos_A = geom.P;
+            prd->vis_pos_B = light_sample.position;
+            float3 eval = Eval(currentPbr, N, V, L);
+            float MIS_weight;
+            {
+                float pdf_area = light_sample.pdf;
+                float pdf_hit = Pdf(currentPbr, N, V, L) * fabsf(L_dot_LN) / (L_dist * L_dist) * rr_rate;
+                MIS_weight = pdf_area / (pdf_hit + pdf_area);
+            }
+            result += prd->throughput * light_sample.emission * 1.0f / light_sample.pdf * N_dot_L * L_dot_LN /
+                      L_dist / L_dist * eval * MIS_weight;
+        }
+    }
+    prd->currentResult += result;
+    prd->origin = geom.P;
+    if (P.counters) P.counters->surface_vertices++;
+    if (rnd(prd->seed) > rr_rate) {
+        prd->done = true;
+    } else {
+        prd->ray_direction = Sample(currentPbr, N, in_dir, prd->seed);
+        float pdf = Pdf(currentPbr, N, in_dir, prd->ray_direction);
+        if (pdf > 0.0f) {
+            prd->throughput *= Eval(currentPbr, N, in_dir, prd->ray_direction) * fabsf(dot(prd->ray_direction, N)) / pdf / rr_rate;
+            prd->pdf = pdf * rr_rate;
+        } else {
+            prd->done = true;
+        }
+    }
+}
+
+// __closesthit__lightsource (hit_program.cu:148-180)
+inline void closesthit_lightsource(const Params& P, PayloadRadiance* prd, const HitInfo& h) {
+    const Scene& S = *P.scene;
+    const Light& light = S.lights[S.mat_light_id[S.tri_mat[h.tri]]];
+    const LocalGeometry geom = getLocalGeometry(S, h.tri, h.bu, h.bv);
+    lightSample light_sample;
+    light_sample.ReverseSample(P, light, geom.UV);
+    float t_hit = h.t_hit;
+    float3 ray_direction = h.ray_direction;
+    if (dot(prd->ray_direction, light_sample.normal()) <= 0) {
+        float MIS_weight = 1;
+        if (prd->depth != 0) {
+            float pdf_hit = prd->pdf * fabsf(dot(ray_direction, light_sample.normal())) / (t_hit * t_hit);
+            float pdf_area = light_sample.pdf;
+            MIS_weight = pdf_hit / (pdf_area + pdf_hit);
+        }
+        prd->result += prd->throughput * light_sample.emission * MIS_weight;
+    }
+    prd->done = true;
+}
+
+// ---------------------------------------------------------------- raygen.cu
+inline bool is_invalid(float3 a) {  // ISINVALIDVALUE raygen.cu:43
+    return a.x > 100000.0f || std::isnan(a.x) || a.y > 100000.0f || std::isnan(a.y) || a.z > 100000.0f || std::isnan(a.z);
+}
+inline float4 ToneMap(float3 c, float limit) {  // raygen.cu:50-58
+    float luminance = 0.3f * c.x + 0.6f * c.y + 0.1f * c.z;
+    float s = 1.0f / (1.0f + 1 * luminance / limit);
+    // `c * 1.0f / (...)`: (c*1.0f) / x  == c * (1/x) with vec_math's operator/(float4,float)
+    return {c.x * s, c.y * s, c.z * s, 1.0f};
+}
+inline float3 toSRGB(float3 c) {  // cuda/helpers.h:35-43
+    float invGamma = 1.0f / 2.4f;
+    float3 p = make_float3(powf(c.x, invGamma), powf(c.y, invGamma), powf(c.z, invGamma));
+    return make_float3(c.x < 0.0031308f ? 12.92f * c.x : 1.055f * p.x - 0.055f,
+                       c.y < 0.0031308f ? 12.92f * c.y : 1.055f * p.y - 0.055f,
+                       c.z < 0.0031308f ? 12.92f * c.z : 1.055f * p.z - 0.055f);
+}
+inline unsigned char quantizeUnsigned8Bits(float x) {  // cuda/helpers.h:50-55
+    x = clampf(x, 0.0f, 1.0f);
+    unsigned v = (unsigned)(x * 256.0f);
+    return (unsigned char)(v < 255u ? v : 255u);
+}
+inline uint32_t make_color(float3 c) {  // cuda/helpers.h:57-62
+    float3 srgb = toSRGB(clamp3(c, 0.0f, 1.0f));
+    return (uint32_t)quantizeUnsigned8Bits(srgb.x) | ((uint32_t)quantizeUnsigned8Bits(srgb.y) << 8) |
+           ((uint32_t)quantizeUnsigned8Bits(srgb.z) << 16) | (255u << 24);
+}
+
+// camera ray (raygen.cu:100-112 == 332-344)
+inline float3 camera_ray(const Params& P, unsigned x, unsigned y, uint32_t& seed) {
+    const int subframe_index = (int)P.subframe_index;
+    seed = tea<4>(y * P.width + x, (uint32_t)subframe_index);
+    float jx, jy;
+    if (subframe_index == 0) { jx = 0.5f; jy = 0.5f; }
+    else { jx = rnd(seed); jy = rnd(seed); }
+    const float dx = 2.0f * (((float)x + jx) / (float)P.width) - 1.0f;
+    const float dy = 2.0f * (((float)y + jy) / (float)P.height) - 1.0f;
+    return normalize(dx * P.U + dy * P.V + P.W);
+}
+inline void accumulate(const Params& P, unsigned x, unsigned y, float3 result) {  // raygen.cu:157-169 / 430-442
+    const unsigned image_index = y * P.width + x;
+    float3 accum_color = result;
+    if (P.subframe_index > 0) {
+        const float a = 1.0f / (float)(P.subframe_index + 1);
+        const float4 prev = P.accum_buffer[image_index];
+        accum_color = lerp(make_float3(prev.x, prev.y, prev.z), accum_color, a);
+    }
+    P.accum_buffer[image_index] = {accum_color.x, accum_color.y, accum_color.z, 1.0f};
+    float4 val = ToneMap(accum_color, 1.5f);
+    if (P.frame_buffer) P.frame_buffer[image_index] = make_color(make_float3(val.x, val.y, val.z));
+}
+
+// __raygen__pinhole (raygen.cu:71-170)
+inline void raygen_pinhole(const Params& P, unsigned x, unsigned y) {
+    const Scene& S = *P.scene;
+    uint32_t seed;
+    float3 ray_direction = camera_ray(P, x, y, seed);
+    float3 ray_origin = P.eye;
+    PayloadRadiance payload;
+    payload.seed = seed;
+    payload.origin = P.eye;
+    payload.ray_direction = ray_direction;
+    payload.currentResult = make_float3(0);
+    if (P.counters) { P.counters->pixel_samples++; P.counters->eye_paths++; }
+    while (true) {
+        ray_direction = payload.ray_direction;
+        ray_origin = payload.origin;
+        Hit h = S.closest_hit(ray_origin, ray_direction, SPCBPT_SCENE_EPSILON, 1e16f, P.counters);
+        if (h.tri < 0) {  // __miss__constant_radiance (raygen.cu:687-697), no env map
+            payload.done = true;
+            payload.currentResult = make_float3(0);
+        } else {
+            HitInfo hi{h.tri, h.t, ray_direction, h.bu, h.bv};
+            if (S.tri_is_emitter(h.tri)) closesthit_lightsource(P, &payload, hi);
+            else closesthit_radiance(P, &payload, hi);
+        }
+        if (float3weight(payload.currentResult) > 0.0f) {
+            if (S.visibilityTest(payload.vis_pos_A, payload.vis_pos_B, P.counters)) payload.result += payload.currentResult;
+            payload.currentResult = make_float3(0);
+        }
+        if (payload.done || payload.depth > 30) break;
+        payload.depth += 1;
+    }
+    accumulate(P, x, y, payload.result);
+}
+
+// init_vertex_from_lightSample / init_lightSubPath_from_lightSample / init_EyeSubpath (raygen.cu:172-231)
+inline void init_vertex_from_lightSample(lightSample& ls, BDPTVertex& v) {
+    v.position = ls.position;
+    v.normal = ls.normal();
+    v.flux = ls.emission;
+    v.pdf = ls.pdf;
+    v.singlePdf = v.pdf;
+    v.isOrigin = true;
+    v.subspaceId = (short)ls.subspaceId;
+    v.depth = 0;
+    v.materialId = (short)ls.bindLight->id;
+    v.RMIS_pointer = 1;
+    v.uv = ls.uv;
+    v.type = QUAD;
+}
+inline void init_lightSubPath_from_lightSample(lightSample& ls, BDPTPath& p) {
+    p.clear();
+    p.push();
+    BDPTVertex& v = p.currentVertex();
+    p.nextVertex().singlePdf = ls.dir_pdf;
+    init_vertex_from_lightSample(ls, v);
+}
+inline void init_EyeSubpath(BDPTPath& p, float3 origin, float3 direction) {
+    p.push();
+    p.currentVertex().position = origin;
+    p.currentVertex().flux = make_float3(1.0f);
+    p.currentVertex().pdf = 1.0f;
+    p.currentVertex().RMIS_pointer = 0;
+    p.currentVertex().normal = direction;
+    p.currentVertex().isOrigin = true;
+    p.currentVertex().depth = 0;
+    p.currentVertex().singlePdf = 1.0f;
+    p.nextVertex().singlePdf = 1.0f;
+}
+
+// traceEyeSubPath / traceLightSubPath + SBT dispatch (cuProg.h:409-461; sutil/Scene.cpp:1642-1691)
+inline void trace_subpath(const Params& P, float3 o, float3 d, PayloadBDPTVertex* prd, bool light_side) {
+    const Scene& S = *P.scene;
+    Hit h = S.closest_hit(o, d, SPCBPT_SCENE_EPSILON, 1e16f, P.counters);
+    if (h.tri < 0) { prd->done = true; return; }  // __miss__BDPTVertex raygen.cu:699-704
+    HitInfo hi{h.tri, h.t, d, h.bu, h.bv};
+    if (S.tri_is_emitter(h.tri)) {
+        if (light_side) prd->done = true;  // __closesthit__lightSource_subpath hit_program.cu:239-244
+        else closesthit_eyeSubpath_LightSource(P, prd, hi);
+    } else {
+        closesthit_subpath(P, prd, hi, light_side);
+    }
+}
+
+// binary_sample (cuProg.h:245-264) — bespoke bisection, restated exactly (q9)
+inline int binary_sample(const Params& P, const float* cmf, int size, uint32_t& seed, float& pmf) {
+    float index = rnd(seed) * 1.0f;
+    int mid = size / 2 - 1, l = 0, r = size;
+    while (r - l > 1) {
+        if (P.counters) P.counters->cmf_probes++;
+        if (index < cmf[mid]) r = mid + 1;
+        else l = mid + 1;
+        mid = (l + r) / 2 - 1;
+    }
+    pmf = l == 0 ? cmf[l] : cmf[l] - cmf[l - 1];
+    return l;
+}
+inline const BDPTVertex& sampleSecondStage(const Params& P, int subspaceId, uint32_t& seed, float& sample_pmf) {  // cuProg.h:268-280
+    const SubspaceSampler& s = P.sampler;
+    int begin_index = s.subspace[subspaceId].jump_bias;
+    int index = binary_sample(P, s.cmfs + begin_index, s.subspace[subspaceId].size, seed, sample_pmf) + begin_index;
+    return s.LVC[s.jump_buffer[index]];
+}
+inline int sampleFirstStage(const Params& P, int eye_subspace, uint32_t& seed, float& sample_pmf) {  // cuProg.h:290-301
+    int begin_index = eye_subspace * SPCBPT_NUM_SUBSPACE;
+    return binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf);
+}
+
+// connectVertex_SPCBPT (raygen.cu:253-303)
+inline float3 connectVertex_SPCBPT(const Params& P, const BDPTVertex& a, const BDPTVertex& b) {
+    const Scene& S = *P.scene;
+    float3 connectVec = a.position - b.position;
+    float3 connectDir = normalize(connectVec);
+    float G = fabsf(dot(a.normal, connectDir)) * fabsf(dot(b.normal, connectDir)) / dot(connectVec, connectVec);
+    float3 LA_DIR = normalize(a.lastPosition - a.position);
+    float3 LB_DIR = normalize(b.lastPosition - b.position);
+    float3 fa, fb;
+    Pbr mat_a = S.materials[a.materialId];
+    mat_a.base_color = a.color;
+    fa = Eval(mat_a, a.normal, -connectDir, LA_DIR);
+    if (!b.isOrigin) {
+        Pbr mat_b = S.materials[b.materialId];
+        mat_b.base_color = b.color;
+        fb = Eval(mat_b, b.normal, connectDir, LB_DIR);
+    } else {
+        if (dot(b.normal, -connectDir) > 0.0f) fb = make_float3(0.0f);
+        else fb = make_float3(1.0f);
+    }
+    float3 contri = a.flux * b.flux * fa * fb * G;
+    float pdf = a.pdf * b.pdf;
+    float3 ans = contri / pdf * (b.depth == 0 ? rmis::connection_lightSource(P, a, b) : rmis::general_connection(P, a, b));
+    if (is_invalid(ans)) return make_float3(0.0f);
+    return ans;
+}
+inline float3 lightStraghtHit(BDPTVertex& a) {  // raygen.cu:305-317
+    float3 ans = a.flux / a.pdf / a.RMIS_pointer;
+    if (is_invalid(ans)) return make_float3(0.0f);
+    return ans;
+}
+
+// __raygen__SPCBPT (raygen.cu:319-443); returns the pixel-sample radiance
+inline float3 spcbpt_sample(const Params& P, unsigned x, unsigned y) {
+    const Scene& S = *P.scene;
+    uint32_t seed;
+    float3 ray_direction = camera_ray(P, x, y, seed);
+    float3 ray_origin = P.eye;
+    float3 result = make_float3(0);
+    PayloadBDPTVertex payload;
+    payload.clear();
+    payload.seed = seed;
+    payload.ray_direction = ray_direction;
+    payload.origin = ray_origin;
+    init_EyeSubpath(payload.path, ray_origin, ray_direction);
+    if (P.counters) { P.counters->pixel_samples++; P.counters->eye_paths++; }
+    while (true) {
+        ray_direction = payload.ray_direction;
+        ray_origin = payload.origin;
+        if (payload.done || payload.depth > 50) break;
+        int begin_depth = payload.path.size;
+        trace_subpath(P, ray_origin, ray_direction, &payload, false);
+        if (payload.path.size == begin_depth) break;
+        payload.depth += 1;
+        if (payload.path.hit_lightSource()) {
+            result += lightStraghtHit(payload.path.currentVertex());
+            break;
+        }
+        BDPTVertex& eye_subpath = payload.path.currentVertex();
+        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+            int light_id = 0;
+            float pmf_firstStage = 1;
+            if (P.light_tree) light_id = sampleFirstStage(P, eye_subpath.subspaceId, payload.seed, pmf_firstStage);
+            if (P.sampler.subspace[light_id].size == 0) continue;
+            float pmf_secondStage;
+            const BDPTVertex& light_subpath = sampleSecondStage(P, light_id, payload.seed, pmf_secondStage);
+            if (P.counters) P.counters->connections++;
+            if (S.visibilityTest(eye_subpath.position, light_subpath.position, P.counters)) {
+                float pmf = P.sampler.path_count * pmf_secondStage * pmf_firstStage;
+                float3 res = connectVertex_SPCBPT(P, eye_subpath, light_subpath) / pmf;
+                if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+            }
+        }
+    }
+    result += payload.result;
+    return result;
+}
+inline void raygen_SPCBPT(const Params& P, unsigned x, unsigned y) { accumulate(P, x, y, spcbpt_sample(P, x, y)); }
+
+// __raygen__lightTrace (raygen.cu:620-685) for one core (= one OptiX thread)
+inline void raygen_lightTrace(const Params& P, int launch_index) {
+    const LightTraceParams& lt = P.lt;
+    const Scene& S = *P.scene;
+    uint32_t seed = tea<4>((uint32_t)launch_index, (uint32_t)lt.launch_frame);
+    PayloadBDPTVertex payload;
+    payload.seed = seed;
+    unsigned bufferBias = (unsigned)lt.core_padding * (unsigned)launch_index;
+    unsigned lightVertexCount = 0, lightPathCount = 0;
+    auto push = [&](BDPTVertex& v) {  // pushVertexToLVC raygen.cu:613-619
+        lt.ans[lightVertexCount + bufferBias] = v;
+        lt.ans[lightVertexCount + bufferBias].path_id = (uint32_t)launch_index * (uint32_t)lt.M_per_core + lightPathCount;
+        lt.validState[lightVertexCount + bufferBias] = 1;
+        lightVertexCount++;
+        if (P.counters) P.counters->lvc_stores++;
+    };
+#define ORC_CHECK_LIGHT_BUFFER if (!(lightVertexCount < (unsigned)lt.core_padding)) break;
+    while (true) {
+        payload.clear();
+        int n_lights = (int)S.lights.size();
+        int light_id = clampi((int)floorf(rnd(seed) * n_lights), 0, n_lights - 1);
+        const Light& light = S.lights[light_id];
+        lightSample light_sample;
+        light_sample.sample(P, light, seed);
+        light_sample.traceMode(seed);
+        float3 ray_direction = light_sample.trace_direction();
+        float3 ray_origin = light_sample.position;
+        init_lightSubPath_from_lightSample(light_sample, payload.path);
+        if (P.counters) P.counters->light_paths++;
+        push(payload.path.currentVertex());
+        ORC_CHECK_LIGHT_BUFFER;
+        while (true) {
+            int begin_depth = payload.path.size;
+            trace_subpath(P, ray_origin, ray_direction, &payload, true);
+            if (payload.path.size > begin_depth) {
+                push(payload.path.currentVertex());
+                ORC_CHECK_LIGHT_BUFFER;
+            }
+            ray_direction = payload.ray_direction;
+            ray_origin = payload.origin;
+            if (payload.done || payload.depth > 50) break;
+            payload.depth += 1;
+        }
+        lightPathCount++;
+        if (lightPathCount >= (unsigned)lt.M_per_core) break;
+        ORC_CHECK_LIGHT_BUFFER;
+    }
+#undef ORC_CHECK_LIGHT_BUFFER
+    for (int i = (int)lightVertexCount; i < lt.core_padding; i++) lt.validState[i + bufferBias] = 0;
+}
+
+// MyThrustOp::LVC_Process (cuda_thrust/device_thrust.cu:241-332)
+inline void LVC_Process(Params& P, SamplerStorage& st) {
+    const LightTraceParams& lt = P.lt;
+    const int countRange = lt.get_element_count();
+    SubspaceSampler& sampler = P.sampler;
+    std::vector<int> num(SPCBPT_NUM_SUBSPACE, 0);
+    std::vector<float> Qs(SPCBPT_NUM_SUBSPACE, 0.0f);
+    std::vector<std::vector<int>> jump(SPCBPT_NUM_SUBSPACE);
+    std::vector<std::vector<float>> pmf(SPCBPT_NUM_SUBSPACE);
+    int valid_count = 0, path_count = 0;
+    for (int i = 0; i < countRange; i++) {
+        if (!lt.validState[i]) continue;
+        valid_count++;
+        const BDPTVertex& v = lt.ans[i];
+        if (v.depth == 0) path_count++;
+        float res = float3weight(v.flux) / v.pdf;  // LVCSubspaceInfoCopy 191-212
+        res = std::isinf(res) ? 0 : res;
+        float w = std::isnan(res) ? 0 : res;
+        int s = v.subspaceId;
+        num[s] += 1;
+        Qs[s] += w;
+        jump[s].push_back(i);
+        pmf[s].push_back(w);
+        if (pmf[s].size() > 1) pmf[s][pmf[s].size() - 1] += pmf[s][pmf[s].size() - 2];
+    }
+    st.cmfs.resize(valid_count);
+    st.jump_buffer.resize(valid_count);
+    st.subspace.resize(SPCBPT_NUM_SUBSPACE);
+    int acc = 0, jump_bias = 0;
+    for (int i = 0; i < SPCBPT_NUM_SUBSPACE; i++) {
+        Subspace& ss = st.subspace[i];
+        ss.id = i;
+        ss.jump_bias = jump_bias;
+        ss.size = (int)jump[i].size();
+        ss.sum_pmf = Qs[i];
+        ss.Q = 0;
+        jump_bias += ss.size;
+        for (int j = 0; j < ss.size; j++) {
+            st.jump_buffer[acc] = jump[i][j];
+            st.cmfs[acc] = pmf[i][j] / ss.sum_pmf;  // q11: NaN when sum_pmf == 0 — kept as in the reference
+            acc++;
+        }
+    }
+    sampler.vertex_count = valid_count;
+    sampler.path_count = path_count;
+    sampler.LVC = lt.ans;
+    sampler.subspace = st.subspace.data();
+    sampler.cmfs = st.cmfs.data();
+    sampler.jump_buffer = st.jump_buffer.data();
+}
+
+}  // namespace orc

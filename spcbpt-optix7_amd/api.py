@@ -1,0 +1,451 @@
+"""ctypes binding of include/spcbpt.h — the C ABI of the MI355X SPCBPT hot path.
+
+The host-side mirror of the reference's driver (optixPathTracer.cpp:491-635):
+``Renderer.launch("light trace" | "SPCBPT_eye" | "pt" | "pretrace")`` keeps the
+four names `sutil::Scene::switchRaygen` dispatches on (sutil/Scene.cpp:1642-1789).
+Nothing here falls back to a CPU path: if libspcbpt_hip.so is missing or no HIP
+device is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+NUM_SUBSPACE = 1000
+NUM_SUBSPACE_LIGHTSOURCE = 200
+CONNECTION_N = 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libspcbpt_hip.so")
+
+
+class Material(C.Structure):
+    _fields_ = [("base_color", C.c_float * 3), ("metallic", C.c_float), ("roughness", C.c_float),
+                ("specular", C.c_float), ("specular_tint", C.c_float), ("subsurface", C.c_float),
+                ("sheen", C.c_float), ("sheen_tint", C.c_float), ("clearcoat", C.c_float),
+                ("clearcoat_gloss", C.c_float), ("albedo_tex", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class QuadLight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3),
+                ("emission", C.c_float * 3), ("div_level", C.c_int32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("texcoords", C.c_void_p), ("n_vertices", C.c_int32),
+                ("indices", C.c_void_p), ("tri_material", C.c_void_p), ("n_triangles", C.c_int32),
+                ("materials", C.POINTER(Material)), ("n_materials", C.c_int32),
+                ("textures", C.POINTER(Texture)), ("n_textures", C.c_int32),
+                ("lights", C.POINTER(QuadLight)), ("n_lights", C.c_int32)]
+
+
+class TreeNode(C.Structure):
+    _fields_ = [("mid", C.c_float * 3), ("child", C.c_int32 * 8), ("label", C.c_int32),
+                ("type", C.c_int32), ("leaf", C.c_int32)]
+
+
+class LightTraceParams(C.Structure):
+    _fields_ = [("num_core", C.c_int32), ("core_padding", C.c_int32), ("m_per_core", C.c_int32),
+                ("core_begin", C.c_int32), ("core_count", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "closest_rays", "shadow_rays", "node_visits", "tri_tests", "surface_vertices", "textured_hits",
+        "tree_nodes", "cmf_probes", "connections", "gamma_q_reads", "lvc_stores", "pixel_samples",
+        "eye_paths", "light_paths")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+# numpy views of the POD records
+LIGHT_VERTEX_DTYPE = np.dtype([
+    ("position", "<f4", 3), ("pdf", "<f4"), ("normal", "<f4", 3), ("single_pdf", "<f4"),
+    ("flux", "<f4", 3), ("rmis_pointer", "<f4"), ("color", "<f4", 3), ("last_lum", "<f4"),
+    ("last_position", "<f4", 3), ("last_normal_projection", "<f4"),
+    ("material_id", "<i2"), ("subspace_id", "<i2"), ("depth", "<i2"), ("last_zone_id", "<i2"),
+    ("path_id", "<u4"), ("pad", "<u4")])
+assert LIGHT_VERTEX_DTYPE.itemsize == 96
+SUBSPACE_DTYPE = np.dtype([("jump_bias", "<i4"), ("id", "<i4"), ("size", "<i4"), ("sum_pmf", "<f4"), ("q", "<f4")])
+TREE_NODE_DTYPE = np.dtype([("mid", "<f4", 3), ("child", "<i4", 8), ("label", "<i4"), ("type", "<i4"), ("leaf", "<i4")])
+assert TREE_NODE_DTYPE.itemsize == C.sizeof(TreeNode)
+
+# Algorithmic byte constants of SURVEY.md 8(d) (fixed by the survey, not tuned).
+BYTES = dict(node=64, tri=48, hit=72, mat=144, tex=16, tree=56, cmf=4, sub=20, jump=4, lvc=120, gq=4, lvcw=121, fb=36)
+
+
+def algorithmic_bytes(c: dict) -> int:
+    """bytes = sum_e count_e * B_e  (SURVEY.md 8(d))."""
+    b = BYTES
+    return (c["node_visits"] * b["node"] + c["tri_tests"] * b["tri"] + c["surface_vertices"] * (b["hit"] + b["mat"])
+            + c["textured_hits"] * b["tex"] + c["tree_nodes"] * b["tree"] + c["cmf_probes"] * b["cmf"]
+            + c["connections"] * (b["sub"] + b["jump"] + b["lvc"] + 2 * b["mat"]) + c["gamma_q_reads"] * b["gq"]
+            + c["lvc_stores"] * b["lvcw"] + c["pixel_samples"] * b["fb"])
+
+
+@dataclass
+class Scene:
+    """Flat triangle soup + materials + quad lights, as the C ABI takes it."""
+    vertices: np.ndarray            # (nv, 3) f32
+    indices: np.ndarray             # (nt, 3) u32
+    tri_material: np.ndarray        # (nt,) i32
+    materials: List[dict]
+    lights: List[dict]
+    texcoords: Optional[np.ndarray] = None   # (nv, 2) f32
+    textures: List[np.ndarray] = field(default_factory=list)  # (h, w, 4) u8
+    camera: dict = field(default_factory=dict)  # eye, lookat, up, fov
+    name: str = "scene"
+
+    def desc(self):
+        """Returns (SceneDesc, keepalive)."""
+        v = np.ascontiguousarray(self.vertices, dtype=np.float32)
+        i = np.ascontiguousarray(self.indices, dtype=np.uint32)
+        m = np.ascontiguousarray(self.tri_material, dtype=np.int32)
+        assert v.ndim == 2 and v.shape[1] == 3 and i.ndim == 2 and i.shape[1] == 3 and m.shape[0] == i.shape[0]
+        assert int(i.max(initial=0)) < v.shape[0] and int(m.max(initial=0)) < len(self.materials)
+        t = None if self.texcoords is None else np.ascontiguousarray(self.texcoords, dtype=np.float32)
+        mats = (Material * max(1, len(self.materials)))()
+        for k, d in enumerate(self.materials):
+            mm = mats[k]
+            mm.base_color[:] = [float(x) for x in d.get("color", (1, 1, 1))]
+            mm.metallic = d.get("metallic", 0.0)
+            mm.roughness = d.get("roughness", 0.5)
+            # q17: the .scene hand-off keeps MaterialData() defaults for the other Disney parameters
+            mm.specular = d.get("specular", 0.5)
+            mm.specular_tint = d.get("specular_tint", 0.0)
+            mm.subsurface = d.get("subsurface", 0.0)
+            mm.sheen = d.get("sheen", 0.0)
+            mm.sheen_tint = d.get("sheen_tint", 0.5)
+            mm.clearcoat = d.get("clearcoat", 0.0)
+            mm.clearcoat_gloss = d.get("clearcoat_gloss", 1.0)
+            mm.albedo_tex = d.get("albedo_tex", 0)
+            assert 0 <= mm.albedo_tex <= len(self.textures)
+        texs = (Texture * max(1, len(self.textures)))()
+        tex_keep = []
+        for k, im in enumerate(self.textures):
+            im = np.ascontiguousarray(im, dtype=np.uint8)
+            assert im.ndim == 3 and im.shape[2] == 4
+            tex_keep.append(im)
+            texs[k].rgba = im.ctypes.data
+            texs[k].height, texs[k].width = im.shape[0], im.shape[1]
+        ls = (QuadLight * max(1, len(self.lights)))()
+        for k, d in enumerate(self.lights):
+            ls[k].position[:] = [float(x) for x in d["position"]]
+            ls[k].u[:] = [float(x) for x in d["u"]]
+            ls[k].v[:] = [float(x) for x in d["v"]]
+            ls[k].emission[:] = [float(x) for x in d["emission"]]
+            ls[k].div_level = int(d.get("div_level", 1))
+        assert sum(int(d.get("div_level", 1)) ** 2 for d in self.lights) <= NUM_SUBSPACE_LIGHTSOURCE
+        sd = SceneDesc()
+        sd.vertices = v.ctypes.data
+        sd.texcoords = None if t is None else t.ctypes.data
+        sd.n_vertices = v.shape[0]
+        sd.indices = i.ctypes.data
+        sd.tri_material = m.ctypes.data
+        sd.n_triangles = i.shape[0]
+        sd.materials = mats
+        sd.n_materials = len(self.materials)
+        sd.textures = texs
+        sd.n_textures = len(self.textures)
+        sd.lights = ls
+        sd.n_lights = len(self.lights)
+        return sd, (v, i, m, t, mats, texs, tex_keep, ls)
+
+
+def camera_frame(eye, lookat, up, fov_y_deg, aspect):
+    """sutil::Camera::UVWFrame (sutil/Camera.cpp:34-45) in float32."""
+    f = np.float32
+    eye, lookat, up = (np.asarray(a, dtype=f) for a in (eye, lookat, up))
+    W = lookat - eye
+    wlen = np.sqrt(np.dot(W, W), dtype=f)
+    U = np.cross(W, up).astype(f)
+    U = U * (f(1.0) / np.sqrt(np.dot(U, U), dtype=f))
+    V = np.cross(U, W).astype(f)
+    V = V * (f(1.0) / np.sqrt(np.dot(V, V), dtype=f))
+    vlen = wlen * f(np.tan(f(0.5) * f(fov_y_deg) * f(np.pi) / f(180.0)))
+    V = V * vlen
+    U = U * (vlen * f(aspect))
+    return U.astype(f), V.astype(f), W.astype(f)
+
+
+def single_leaf_tree(label=0):
+    t = np.zeros(1, dtype=TREE_NODE_DTYPE)
+    t[0]["leaf"] = 1
+    t[0]["label"] = label
+    return t
+
+
+class SpcbptError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """Loads libspcbpt_hip.so.  Raises if it has not been built — there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise SpcbptError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    lib = C.CDLL(path)
+    vp, i32, u32, f32p = C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_float)
+    sig = {
+        "spcbpt_create": [C.POINTER(SceneDesc), i32, C.POINTER(vp)],
+        "spcbpt_destroy": [vp],
+        "spcbpt_set_camera": [vp, f32p, f32p, f32p, f32p],
+        "spcbpt_set_camera_lookat": [vp, f32p, f32p, f32p, C.c_float, C.c_float],
+        "spcbpt_resize": [vp, i32, i32],
+        "spcbpt_set_subspace": [vp, vp, i32, vp, i32, vp, vp],
+        "spcbpt_set_light_trace": [vp, C.POINTER(LightTraceParams)],
+        "spcbpt_launch": [vp, C.c_char_p, u32, i32, i32, i32],
+        "spcbpt_build_sampler": [vp],
+        "spcbpt_lvc_export": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)],
+        "spcbpt_lvc_import": [vp, vp, i32, i32],
+        "spcbpt_lvc_read": [vp, vp, i32, C.POINTER(i32)],
+        "spcbpt_sampler_read": [vp, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)],
+        "spcbpt_read_accum": [vp, vp],
+        "spcbpt_read_frame": [vp, vp],
+        "spcbpt_accum_device_ptr": [vp, C.POINTER(vp)],
+        "spcbpt_clear_accum": [vp],
+        "spcbpt_get_counters": [vp, C.POINTER(Counters)],
+        "spcbpt_reset_counters": [vp],
+        "spcbpt_enable_counters": [vp, i32],
+        "spcbpt_stream": [vp, C.POINTER(vp)],
+        "spcbpt_sync": [vp],
+        "spcbpt_kernel_time": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i32)],
+        "spcbpt_reset_kernel_time": [vp],
+        "spcbpt_enable_kernel_timing": [vp, i32],
+        "spcbpt_trace_closest": [vp, vp, i32, vp, vp, vp],
+        "spcbpt_trace_any": [vp, vp, i32, vp],
+        "spcbpt_preprocess": [vp, i32, i32, i32],
+        "spcbpt_get_subspace": [vp, vp, C.POINTER(i32), i32, vp, C.POINTER(i32), i32, vp, vp],
+        "spcbpt_scene_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.spcbpt_last_error.argtypes = [vp]
+    lib.spcbpt_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "spcbpt_create", "spcbpt_destroy", "spcbpt_last_error", "spcbpt_set_camera", "spcbpt_set_camera_lookat",
+    "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_build_sampler",
+    "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
+    "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
+    "spcbpt_reset_counters", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_kernel_time",
+    "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
+    "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info",
+]
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Renderer:
+    """One context per GPU (the `sutil::Scene` + `MyParams` pair of the reference driver)."""
+
+    def __init__(self, scene: Scene, device: int = 0):
+        self.lib = load_library()
+        self.scene = scene
+        sd, keep = scene.desc()
+        h = C.c_void_p()
+        rc = self.lib.spcbpt_create(C.byref(sd), device, C.byref(h))
+        if rc != 0:
+            msg = self.lib.spcbpt_last_error(None)
+            raise SpcbptError(f"spcbpt_create failed ({rc}): {msg.decode() if msg else ''}")
+        self.h = h
+        self.width = self.height = 0
+        self.lt = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            msg = self.lib.spcbpt_last_error(self.h)
+            raise SpcbptError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.spcbpt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state --------------------------------------------------------------
+    def set_camera(self, eye, U, V, W):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (eye, U, V, W)]
+        self._chk(self.lib.spcbpt_set_camera(self.h, *[_fp(x) for x in a]), "set_camera")
+
+    def set_camera_lookat(self, eye, lookat, up, fov, aspect):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (eye, lookat, up)]
+        self._chk(self.lib.spcbpt_set_camera_lookat(self.h, *[_fp(x) for x in a], fov, aspect), "set_camera_lookat")
+
+    def resize(self, w, h):
+        self._chk(self.lib.spcbpt_resize(self.h, w, h), "resize")
+        self.width, self.height = w, h
+
+    def set_subspace(self, eye_tree=None, light_tree=None, q=None, cmf_gamma=None):
+        if eye_tree is None and light_tree is None and q is None and cmf_gamma is None:
+            self._chk(self.lib.spcbpt_set_subspace(self.h, None, 0, None, 0, None, None), "set_subspace")
+            return
+        et = np.ascontiguousarray(eye_tree, dtype=TREE_NODE_DTYPE)
+        lt = np.ascontiguousarray(light_tree, dtype=TREE_NODE_DTYPE)
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        g = np.ascontiguousarray(cmf_gamma, dtype=np.float32)
+        assert q.size == NUM_SUBSPACE and g.size == NUM_SUBSPACE * NUM_SUBSPACE
+        self._chk(self.lib.spcbpt_set_subspace(self.h, et.ctypes.data, et.shape[0], lt.ctypes.data, lt.shape[0],
+                                               q.ctypes.data, g.ctypes.data), "set_subspace")
+
+    def get_subspace(self, cap=1 << 20):
+        et = np.zeros(cap, dtype=TREE_NODE_DTYPE)
+        lt = np.zeros(cap, dtype=TREE_NODE_DTYPE)
+        q = np.zeros(NUM_SUBSPACE, dtype=np.float32)
+        g = np.zeros(NUM_SUBSPACE * NUM_SUBSPACE, dtype=np.float32)
+        ne, nl = C.c_int(), C.c_int()
+        self._chk(self.lib.spcbpt_get_subspace(self.h, et.ctypes.data, C.byref(ne), cap, lt.ctypes.data, C.byref(nl), cap,
+                                               q.ctypes.data, g.ctypes.data), "get_subspace")
+        return et[:ne.value].copy(), lt[:nl.value].copy(), q, g.reshape(NUM_SUBSPACE, NUM_SUBSPACE)
+
+    def set_light_trace(self, num_core, core_padding, m_per_core, core_begin=0, core_count=0):
+        p = LightTraceParams(num_core, core_padding, m_per_core, core_begin, core_count)
+        self._chk(self.lib.spcbpt_set_light_trace(self.h, C.byref(p)), "set_light_trace")
+        self.lt = p
+
+    # -- launches -----------------------------------------------------------
+    def launch(self, name: str, frame: int, rows=None):
+        r0, r1, rs = rows if rows is not None else (0, self.height, 1)
+        self._chk(self.lib.spcbpt_launch(self.h, name.encode(), frame, r0, r1, rs), f"launch({name})")
+
+    def build_sampler(self):
+        self._chk(self.lib.spcbpt_build_sampler(self.h), "build_sampler")
+
+    def sync(self):
+        self._chk(self.lib.spcbpt_sync(self.h), "sync")
+
+    def preprocess(self, target_paths=2_000_000, target_q_paths=2_000_000, train=True):
+        self._chk(self.lib.spcbpt_preprocess(self.h, target_paths, target_q_paths, int(train)), "preprocess")
+
+    # -- readback -----------------------------------------------------------
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._chk(self.lib.spcbpt_read_accum(self.h, out.ctypes.data), "read_accum")
+        return out
+
+    def read_frame(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._chk(self.lib.spcbpt_read_frame(self.h, out.ctypes.data), "read_frame")
+        return out
+
+    def clear_accum(self):
+        self._chk(self.lib.spcbpt_clear_accum(self.h), "clear_accum")
+
+    def lvc_read(self, capacity=None):
+        if capacity is None:
+            capacity = self.lt.num_core * self.lt.core_padding if self.lt else 1 << 22
+        out = np.zeros(capacity, dtype=LIGHT_VERTEX_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.spcbpt_lvc_read(self.h, out.ctypes.data, capacity, C.byref(n)), "lvc_read")
+        return out[:n.value].copy()
+
+    def lvc_import(self, verts: np.ndarray):
+        v = np.ascontiguousarray(verts, dtype=LIGHT_VERTEX_DTYPE)
+        self._chk(self.lib.spcbpt_lvc_import(self.h, v.ctypes.data, v.shape[0], 0), "lvc_import")
+
+    def lvc_import_device(self, d_ptr: int, count: int):
+        self._chk(self.lib.spcbpt_lvc_import(self.h, C.c_void_p(d_ptr), count, 1), "lvc_import")
+
+    def lvc_export(self):
+        dv, dc, cap = C.c_void_p(), C.c_void_p(), C.c_int()
+        self._chk(self.lib.spcbpt_lvc_export(self.h, C.byref(dv), C.byref(dc), C.byref(cap)), "lvc_export")
+        return dv.value, dc.value, cap.value
+
+    def sampler_read(self, capacity=None):
+        if capacity is None:
+            capacity = self.lt.num_core * self.lt.core_padding if self.lt else 1 << 22
+        sub = np.zeros(NUM_SUBSPACE, dtype=SUBSPACE_DTYPE)
+        cmfs = np.zeros(capacity, dtype=np.float32)
+        jump = np.zeros(capacity, dtype=np.int32)
+        vc, pc = C.c_int(), C.c_int()
+        self._chk(self.lib.spcbpt_sampler_read(self.h, sub.ctypes.data, cmfs.ctypes.data, jump.ctypes.data, capacity,
+                                               C.byref(vc), C.byref(pc)), "sampler_read")
+        return sub, cmfs[:vc.value].copy(), jump[:vc.value].copy(), vc.value, pc.value
+
+    def accum_device_ptr(self):
+        p = C.c_void_p()
+        self._chk(self.lib.spcbpt_accum_device_ptr(self.h, C.byref(p)), "accum_device_ptr")
+        return p.value
+
+    def stream(self):
+        p = C.c_void_p()
+        self._chk(self.lib.spcbpt_stream(self.h, C.byref(p)), "stream")
+        return p.value or 0
+
+    # -- instrumentation ----------------------------------------------------
+    def counters(self):
+        c = Counters()
+        self._chk(self.lib.spcbpt_get_counters(self.h, C.byref(c)), "get_counters")
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._chk(self.lib.spcbpt_reset_counters(self.h), "reset_counters")
+
+    def enable_counters(self, on: bool):
+        self._chk(self.lib.spcbpt_enable_counters(self.h, int(on)), "enable_counters")
+
+    def enable_kernel_timing(self, on: bool):
+        self._chk(self.lib.spcbpt_enable_kernel_timing(self.h, int(on)), "enable_kernel_timing")
+
+    def reset_kernel_time(self):
+        self._chk(self.lib.spcbpt_reset_kernel_time(self.h), "reset_kernel_time")
+
+    def kernel_time(self, name: str):
+        ms, n = C.c_double(), C.c_int()
+        self._chk(self.lib.spcbpt_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n)), "kernel_time")
+        return ms.value, n.value
+
+    def scene_info(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.spcbpt_scene_info(self.h, C.byref(a), C.byref(b), C.byref(c)), "scene_info")
+        return dict(n_triangles=a.value, n_bvh_nodes=b.value, bvh_depth=c.value)
+
+    def trace_closest(self, rays: np.ndarray):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        t = np.zeros(n, dtype=np.float32)
+        tri = np.zeros(n, dtype=np.int32)
+        uv = np.zeros((n, 2), dtype=np.float32)
+        self._chk(self.lib.spcbpt_trace_closest(self.h, r.ctypes.data, n, t.ctypes.data, tri.ctypes.data, uv.ctypes.data),
+                  "trace_closest")
+        return t, tri, uv
+
+    def trace_any(self, rays: np.ndarray):
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        vis = np.zeros(n, dtype=np.int32)
+        self._chk(self.lib.spcbpt_trace_any(self.h, r.ctypes.data, n, vis.ctypes.data), "trace_any")
+        return vis
+
+    # -- the reference's per-frame sequence (optixPathTracer.cpp:791-822) ------
+    def render_frame(self, alg: str, subframe: int, launch_frame: Optional[int] = None, rows=None):
+        if alg == "SPCBPT_eye":
+            self.launch("light trace", subframe + 1 if launch_frame is None else launch_frame)
+            self.build_sampler()
+        self.launch(alg, subframe, rows)

@@ -1,0 +1,59 @@
+"""Helpers shared by the parity tests, smoke() and bench.py (test infrastructure)."""
+from __future__ import annotations
+
+import numpy as np
+
+FLT_MAX = np.float32(3.4028234663852886e38)
+
+
+def q_from_lvc(lvc: np.ndarray, n_sub: int = 1000):
+    """Q[s] = E[sum_{v in s} flux/pdf per light path] (preprocess_getQ, device_thrust.cu:347-409) for one pass."""
+    w = lvc["flux"].sum(axis=1, dtype=np.float32) / lvc["pdf"]
+    w = np.where(np.isfinite(w), w, 0).astype(np.float32)
+    q = np.bincount(lvc["subspace_id"].astype(np.int64), weights=w.astype(np.float64), minlength=n_sub)
+    paths = int((lvc["depth"] == 0).sum())
+    return (q / max(paths, 1)), paths
+
+
+def minimal_tuple(oracle, frames: int = 4, first_frame: int = 10_000):
+    """The cheapest VALID subspace tuple: single-leaf trees, Q from a few
+    light passes, every Gamma row proportional to Q.  Returns (eye_tree, light_tree, q, cmf_gamma)."""
+    pkg = oracle.pkg
+    n = pkg.NUM_SUBSPACE
+    acc = np.zeros(n, dtype=np.float64)
+    tot = 0
+    for f in range(frames):
+        oracle.launch("light trace", first_frame + f)
+        q, paths = q_from_lvc(oracle.lvc_read(), n)
+        acc += q * paths
+        tot += paths
+    return tuple_from_q(pkg, acc / max(tot, 1))
+
+
+def tuple_from_q(pkg, q64):
+    n = pkg.NUM_SUBSPACE
+    q = q64.astype(np.float32)
+    row = q64 / q64.sum()
+    cmf = np.cumsum(row).astype(np.float32)
+    cmf[-1] = 1.0
+    # monotone, and zero-mass bins keep pmf exactly 0
+    cmf = np.maximum.accumulate(cmf)
+    q = np.where(q == 0, FLT_MAX, q).astype(np.float32)  # Q_zero_handle device_thrust.cu:335-346
+    gamma = np.tile(cmf[None, :], (n, 1)).astype(np.float32)
+    return pkg.single_leaf_tree(0), pkg.single_leaf_tree(0), q, gamma
+
+
+def image_parity(a: np.ndarray, b: np.ndarray, rel: float = 2e-3, abs_: float = 1e-4):
+    """Per-pixel comparison of two linear accum images rendered with the same seeds."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    d = np.abs(a - b)
+    close = (d <= abs_ + rel * np.abs(b)).all(axis=-1)
+    l2 = np.sqrt((d ** 2).sum(axis=-1))
+    return dict(frac_close=float(close.mean()), mean_a=float(a.mean()), mean_b=float(b.mean()),
+                mean_rel=float(abs(a.mean() - b.mean()) / max(b.mean(), 1e-12)),
+                rmse=float(np.sqrt((d ** 2).mean())), max_l2=float(l2.max()), p99_l2=float(np.percentile(l2, 99)))
+
+
+def rmse(a, b):
+    return float(np.sqrt(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean()))

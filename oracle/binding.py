@@ -117,6 +117,10 @@ class Oracle:
         self.l.orc_set_light_trace(self.h, num_core, core_padding, m_per_core)
         self.lt = (num_core, core_padding, m_per_core)
 
+    def set_cmf_double(self, on):
+        """Test knob: double-precision CMF accumulation (product behaviour) instead of the reference's float prefix sums."""
+        self.l.orc_set_cmf_double(self.h, int(on))
+
     def enable_counters(self, on):
         self.l.orc_enable_counters(self.h, int(on))
 

@@ -113,6 +113,9 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
     const float* Q = nullptr;
     const float* CMFGamma = nullptr;
     Counters* counters = nullptr;
+    // test knob, NOT reference behaviour: accumulate the per-subspace CMFs in double (the product's device scan does);
+    // false = the reference's serial float prefix sums (device_thrust.cu:273-286)
+    bool cmf_double = false;
 
     float Gamma(int eye_id, int light_id) const {
         if (CMFGamma && Q) {
@@ -877,6 +880,7 @@ inline void LVC_Process(Params& P, SamplerStorage& st) {
     std::vector<float> Qs(SPCBPT_NUM_SUBSPACE, 0.0f);
     std::vector<std::vector<int>> jump(SPCBPT_NUM_SUBSPACE);
     std::vector<std::vector<float>> pmf(SPCBPT_NUM_SUBSPACE);
+    std::vector<std::vector<double>> pmfd(SPCBPT_NUM_SUBSPACE);
     int valid_count = 0, path_count = 0;
     for (int i = 0; i < countRange; i++) {
         if (!lt.validState[i]) continue;
@@ -892,6 +896,7 @@ inline void LVC_Process(Params& P, SamplerStorage& st) {
         jump[s].push_back(i);
         pmf[s].push_back(w);
         if (pmf[s].size() > 1) pmf[s][pmf[s].size() - 1] += pmf[s][pmf[s].size() - 2];
+        if (P.cmf_double) pmfd[s].push_back((pmfd[s].empty() ? 0.0 : pmfd[s].back()) + (double)w);
     }
     st.cmfs.resize(valid_count);
     st.jump_buffer.resize(valid_count);
@@ -908,6 +913,11 @@ inline void LVC_Process(Params& P, SamplerStorage& st) {
         for (int j = 0; j < ss.size; j++) {
             st.jump_buffer[acc] = jump[i][j];
             st.cmfs[acc] = pmf[i][j] / ss.sum_pmf;  // q11: NaN when sum_pmf == 0 — kept as in the reference
+            if (P.cmf_double) {
+                const double tot = pmfd[i].back();
+                st.cmfs[acc] = tot > 0.0 ? (float)(pmfd[i][j] / tot) : (float)(j + 1) / (float)ss.size;
+                if (j == ss.size - 1) { st.cmfs[acc] = 1.0f; ss.sum_pmf = (float)tot; }
+            }
             acc++;
         }
     }

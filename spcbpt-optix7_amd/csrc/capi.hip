@@ -1,0 +1,725 @@
+// C ABI (include/spcbpt.h) over the HIP kernels: context, HBM-resident buffers, launches by name,
+// device-side sampler build, LVC exchange, instrumentation.  The host side of the reference this
+// replaces is cited per function in include/spcbpt.h.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spcbpt.h"
+#include "context.h"
+#include "kernels.h"
+#include "lbvh.h"
+
+using namespace spc;
+
+static thread_local std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e__);                   \
+            return SPCBPT_ERR_HIP;                                                               \
+        }                                                                                        \
+    } while (0)
+
+namespace spc {
+
+template <class T>
+static hipError_t dev_alloc(T** p, size_t n) {
+    *p = nullptr;
+    if (n == 0) n = 1;
+    return hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+}
+template <class T>
+static void dev_free(T*& p) {
+    if (p) (void)hipFree((void*)p);
+    p = nullptr;
+}
+
+void Context::time_begin(const char* name) {
+    if (!timing) return;
+    TimedSpan sp;
+    sp.name = name;
+    (void)hipEventCreate(&sp.a);
+    (void)hipEventCreate(&sp.b);
+    (void)hipEventRecord(sp.a, stream);
+    spans.push_back(sp);
+}
+void Context::time_end() {
+    if (!timing || spans.empty()) return;
+    (void)hipEventRecord(spans.back().b, stream);
+}
+void Context::resolve_spans() {
+    for (auto& sp : spans) {
+        (void)hipEventSynchronize(sp.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            auto& acc = times[sp.name];
+            acc.first += ms;
+            acc.second += 1;
+        }
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    spans.clear();
+}
+
+int Context::ensure_spill(size_t threads) {
+    const int entries = std::max(0, bvh_depth - kStackLds);
+    kp.spill_entries = entries;
+    if (entries == 0) { kp.spill = nullptr; return 0; }
+    const size_t need = threads * (size_t)entries;
+    if (need > spill_capacity) {
+        dev_free(d_spill);
+        HIP_TRY(this, dev_alloc(&d_spill, need));
+        spill_capacity = need;
+    }
+    kp.spill = d_spill;
+    return 0;
+}
+
+int Context::upload_tree(const spcbpt_tree_node* t, int n, float*& d_tree, std::vector<spcbpt_tree_node>& host_copy) {
+    host_copy.assign(t, t + n);
+    std::vector<float> packed((size_t)n * 12);
+    for (int i = 0; i < n; i++) {
+        float* q = &packed[(size_t)i * 12];
+        q[0] = t[i].mid[0]; q[1] = t[i].mid[1]; q[2] = t[i].mid[2];
+        uint32_t meta = ((uint32_t)t[i].type & 3u) | (t[i].leaf ? 4u : 0u) | ((uint32_t)t[i].label << 3);
+        memcpy(q + 3, &meta, 4);
+        for (int k = 0; k < 8; k++) {
+            int c = t[i].child[k];
+            if (!t[i].leaf && (c < 0 || c >= n)) { error = "tree child index out of range"; return SPCBPT_ERR_INVALID_ARG; }
+            memcpy(q + 4 + k, &c, 4);
+        }
+        if (t[i].leaf && (t[i].label < 0 || t[i].label >= SPCBPT_NUM_SUBSPACE)) { error = "tree label out of range"; return SPCBPT_ERR_INVALID_ARG; }
+    }
+    dev_free(d_tree);
+    HIP_TRY(this, dev_alloc(&d_tree, packed.size()));
+    HIP_TRY(this, hipMemcpyAsync(d_tree, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    return 0;
+}
+
+int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_tree_node* lt, int nl, const float* q, const float* g) {
+    if (!et || !lt || !q || !g || ne < 1 || nl < 1) { error = "set_subspace: all four of eye_tree, light_tree, q, cmf_gamma are required"; return SPCBPT_ERR_INVALID_ARG; }
+    int rc = upload_tree(et, ne, d_eye_tree, h_eye_tree);
+    if (rc) return rc;
+    rc = upload_tree(lt, nl, d_light_tree, h_light_tree);
+    if (rc) return rc;
+    h_Q.assign(q, q + SPCBPT_NUM_SUBSPACE);
+    h_gamma.assign(g, g + (size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE);
+    if (!d_Q) HIP_TRY(this, dev_alloc(&d_Q, SPCBPT_NUM_SUBSPACE));
+    if (!d_gamma) HIP_TRY(this, dev_alloc(&d_gamma, (size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE));
+    HIP_TRY(this, hipMemcpyAsync(d_Q, h_Q.data(), h_Q.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipMemcpyAsync(d_gamma, h_gamma.data(), h_gamma.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    kp.eye_tree = d_eye_tree; kp.light_tree = d_light_tree; kp.Q = d_Q; kp.cmf_gamma = d_gamma;
+    have_subspace = true;
+    return 0;
+}
+
+int Context::set_light_trace(const spcbpt_light_trace_params& p) {
+    if (p.num_core < 1 || p.core_padding < 1 || p.m_per_core < 1) { error = "set_light_trace: sizes must be positive"; return SPCBPT_ERR_INVALID_ARG; }
+    int begin = p.core_begin, count = p.core_count == 0 ? p.num_core - p.core_begin : p.core_count;
+    if (begin < 0 || count < 1 || begin + count > p.num_core) { error = "set_light_trace: core range out of bounds"; return SPCBPT_ERR_INVALID_ARG; }
+    lt = p;
+    lt.core_count = count;
+    const size_t slots = (size_t)count * p.core_padding;
+    if (slots > scratch_capacity) {
+        dev_free(d_scratch);
+        HIP_TRY(this, dev_alloc(&d_scratch, slots));
+        scratch_capacity = slots;
+    }
+    if ((size_t)count + 1 > counts_capacity) {
+        dev_free(d_core_counts); dev_free(d_core_offsets);
+        HIP_TRY(this, dev_alloc(&d_core_counts, (size_t)count + 1));
+        HIP_TRY(this, dev_alloc(&d_core_offsets, (size_t)count + 1));
+        counts_capacity = (size_t)count + 1;
+    }
+    // the compact LVC must hold every rank's shard after an all-gather: full num_core * core_padding
+    return ensure_lvc_capacity((size_t)p.num_core * p.core_padding);
+}
+
+int Context::ensure_lvc_capacity(size_t n) {
+    if (n <= lvc_capacity) return 0;
+    dev_free(d_lvc); dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_vals2); dev_free(d_weights);
+    dev_free(d_wsorted); dev_free(d_prefix); dev_free(d_cmfs);
+    HIP_TRY(this, dev_alloc(&d_lvc, n));
+    HIP_TRY(this, dev_alloc(&d_keys, n)); HIP_TRY(this, dev_alloc(&d_keys2, n));
+    HIP_TRY(this, dev_alloc(&d_vals, n)); HIP_TRY(this, dev_alloc(&d_vals2, n));
+    HIP_TRY(this, dev_alloc(&d_weights, n));
+    HIP_TRY(this, dev_alloc(&d_wsorted, n)); HIP_TRY(this, dev_alloc(&d_prefix, n));
+    HIP_TRY(this, dev_alloc(&d_cmfs, n));
+    lvc_capacity = n;
+    lvc_count = 0;
+    have_sampler = false;
+    return 0;
+}
+
+int Context::ensure_temp(size_t bytes) {
+    if (bytes <= temp_capacity) return 0;
+    dev_free(d_temp);
+    HIP_TRY(this, dev_alloc(&d_temp, bytes));
+    temp_capacity = bytes;
+    return 0;
+}
+
+// "light trace": k_light_trace into the padded scratch, then compaction into the deterministic (core, slot) order
+int Context::launch_light(uint32_t frame) {
+    if (!have_subspace) { error = "light trace needs a subspace tuple (spcbpt_set_subspace)"; return SPCBPT_ERR_STATE; }
+    if (!d_scratch) {
+        spcbpt_light_trace_params d = {100000, 52, 1, 0, 0};
+        int rc = set_light_trace(d);
+        if (rc) return rc;
+    }
+    kp.num_core = lt.num_core; kp.core_padding = lt.core_padding; kp.m_per_core = lt.m_per_core;
+    kp.core_begin = lt.core_begin; kp.core_count = lt.core_count; kp.launch_frame = frame;
+    kp.lvc_scratch = d_scratch; kp.core_counts = d_core_counts;
+    int rc = ensure_spill(((size_t)lt.core_count + 255) / 256 * 256);
+    if (rc) return rc;
+    kp.counters = counting ? d_counters : nullptr;
+    HIP_TRY(this, hipMemsetAsync(d_core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), stream));
+    time_begin("light_trace");
+    launch_light_trace(kp, counting, stream);
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    // compaction: exclusive scan of per-core counts (+1 sentinel gives the total) -> offsets
+    time_begin("lvc_compact");
+    size_t tb = 0;
+    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_core_counts, d_core_offsets, lt.core_count + 1, stream));
+    rc = ensure_temp(tb);
+    if (rc) return rc;
+    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(d_temp, tb, d_core_counts, d_core_offsets, lt.core_count + 1, stream));
+    HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), stream));
+    HIP_TRY(this, hipMemcpyAsync(d_sampler_counts, d_core_offsets + lt.core_count, sizeof(int), hipMemcpyDeviceToDevice, stream));
+    launch_lvc_compact(d_scratch, d_core_counts, d_core_offsets, lt.core_count, lt.core_padding, d_lvc, d_keys, d_vals, d_weights,
+                       d_sampler_counts, stream);
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    keys_ready = true;
+    lvc_count = -1;  // known on the device only until the next host read
+    have_sampler = false;
+    return 0;
+}
+
+int Context::fetch_counts() {
+    int h[2] = {0, 0};
+    HIP_TRY(this, hipMemcpyAsync(h, d_sampler_counts, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    lvc_count = h[0];
+    path_count = h[1];
+    return 0;
+}
+
+// LVC_Process on the device
+int Context::build_sampler() {
+    if (!d_lvc) { error = "build_sampler: no light-vertex cache (run \"light trace\" or spcbpt_lvc_import first)"; return SPCBPT_ERR_STATE; }
+    int rc = fetch_counts();  // the radix sort needs its item count on the host: one 8-byte readback per frame
+    if (rc) return rc;
+    const int n = lvc_count;
+    time_begin("sampler_build");
+    if (!keys_ready) {
+        HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
+        launch_fill_keys(d_lvc, n, d_keys, d_vals, d_weights, d_sampler_counts, stream);
+        keys_ready = true;
+    }
+    HIP_TRY(this, hipMemsetAsync(d_subspace, 0, SPCBPT_NUM_SUBSPACE * sizeof(DSubspace), stream));
+    if (n > 0) {
+        size_t tb = 0, tb2 = 0;
+        HIP_TRY(this, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 10, stream));
+        HIP_TRY(this, hipcub::DeviceScan::InclusiveSum(nullptr, tb2, d_wsorted, d_prefix, n, stream));
+        rc = ensure_temp(std::max(tb, tb2));
+        if (rc) return rc;
+        HIP_TRY(this, hipcub::DeviceRadixSort::SortPairs(d_temp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 10, stream));
+        launch_subspace_ranges(d_keys2, d_sampler_counts, d_subspace, n, stream);
+        launch_gather_weights(d_weights, d_vals2, d_sampler_counts, d_wsorted, n, stream);
+        HIP_TRY(this, hipcub::DeviceScan::InclusiveSum(d_temp, tb2, d_wsorted, d_prefix, n, stream));
+        launch_cmf(d_prefix, d_keys2, d_sampler_counts, d_subspace, d_cmfs, n, stream);
+    }
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    if (fetch_counts()) return SPCBPT_ERR_HIP;
+    kp.lvc = d_lvc; kp.subspace = d_subspace; kp.cmfs = d_cmfs; kp.jump = reinterpret_cast<const int32_t*>(d_vals2);
+    kp.sampler_counts = d_sampler_counts;
+    have_sampler = true;
+    return 0;
+}
+
+int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs) {
+    if (!d_accum) { error = "render before spcbpt_resize"; return SPCBPT_ERR_STATE; }
+    if (!have_camera) { error = "render before spcbpt_set_camera"; return SPCBPT_ERR_STATE; }
+    if (spcbpt_alg && (!have_sampler || !have_subspace)) { error = "SPCBPT_eye needs a subspace tuple and a built sampler"; return SPCBPT_ERR_STATE; }
+    if (rs < 1) rs = 1;
+    if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }
+    kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
+    kp.counters = counting ? d_counters : nullptr;
+    int rc = ensure_spill((size_t)render_thread_count(kp));
+    if (rc) return rc;
+    time_begin(name);
+    if (spcbpt_alg) launch_spcbpt(kp, counting, stream);
+    else launch_pt(kp, counting, stream);
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    return 0;
+}
+
+// The minimal VALID subspace tuple: single-leaf trees, Q from a few light passes, Gamma rows ~ Q.
+int Context::install_minimal_tuple() {
+    spcbpt_tree_node leaf;
+    memset(&leaf, 0, sizeof(leaf));
+    leaf.leaf = 1; leaf.label = 0;
+    std::vector<float> q(SPCBPT_NUM_SUBSPACE, 1.0f), g((size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE);
+    for (int e = 0; e < SPCBPT_NUM_SUBSPACE; e++)
+        for (int l = 0; l < SPCBPT_NUM_SUBSPACE; l++) g[(size_t)e * SPCBPT_NUM_SUBSPACE + l] = (float)(l + 1) / SPCBPT_NUM_SUBSPACE;
+    int rc = install_subspace(&leaf, 1, &leaf, 1, q.data(), g.data());
+    if (rc) return rc;
+    std::vector<double> acc(SPCBPT_NUM_SUBSPACE, 0.0);
+    long long paths = 0;
+    std::vector<LightVertex> host;
+    for (int f = 0; f < 4; f++) {
+        rc = launch_light(10000u + f);
+        if (rc) return rc;
+        rc = fetch_counts();
+        if (rc) return rc;
+        host.resize(lvc_count);
+        HIP_TRY(this, hipMemcpy(host.data(), d_lvc, (size_t)lvc_count * sizeof(LightVertex), hipMemcpyDeviceToHost));
+        for (const auto& v : host) {
+            float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;
+            if (std::isnan(w) || std::isinf(w)) w = 0;
+            acc[v.subspace_id] += w;
+            if (v.depth == 0) paths++;
+        }
+    }
+    double total = 0;
+    for (int s = 0; s < SPCBPT_NUM_SUBSPACE; s++) { acc[s] /= (double)std::max(1LL, paths); total += acc[s]; }
+    if (!(total > 0)) { error = "minimal tuple: the light pass produced no weight (no emitters?)"; return SPCBPT_ERR_STATE; }
+    double run = 0;
+    std::vector<float> row(SPCBPT_NUM_SUBSPACE);
+    for (int s = 0; s < SPCBPT_NUM_SUBSPACE; s++) { run += acc[s] / total; row[s] = (float)run; q[s] = acc[s] == 0 ? FLT_MAX : (float)acc[s]; }
+    row[SPCBPT_NUM_SUBSPACE - 1] = 1.0f;
+    for (int s = 1; s < SPCBPT_NUM_SUBSPACE; s++) row[s] = std::max(row[s], row[s - 1]);
+    for (int e = 0; e < SPCBPT_NUM_SUBSPACE; e++) memcpy(&g[(size_t)e * SPCBPT_NUM_SUBSPACE], row.data(), SPCBPT_NUM_SUBSPACE * sizeof(float));
+    return install_subspace(&leaf, 1, &leaf, 1, q.data(), g.data());
+}
+
+Context::~Context() {
+    resolve_spans();
+    dev_free(d_nodes); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
+    for (auto p : d_tex_data) (void)hipFree(p);
+    dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);
+    dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_lvc); dev_free(d_keys); dev_free(d_keys2);
+    dev_free(d_vals); dev_free(d_vals2); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix); dev_free(d_cmfs);
+    dev_free(d_subspace); dev_free(d_sampler_counts); dev_free(d_counters); dev_free(d_spill); dev_free(d_temp);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace spc
+
+struct spcbpt_ctx : public spc::Context {};
+
+extern "C" {
+
+int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
+    if (!sc || !out) { g_create_error = "null argument"; return SPCBPT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!sc->vertices || !sc->indices || !sc->tri_material || sc->n_vertices < 3 || sc->n_triangles < 1 || sc->n_materials < 1 ||
+        !sc->materials || sc->n_lights < 1 || !sc->lights) {
+        g_create_error = "scene needs vertices, indices, tri_material, >=1 material and >=1 quad light";
+        return SPCBPT_ERR_INVALID_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (the MI355X path has no CPU fallback)"; return SPCBPT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { g_create_error = "device ordinal out of range"; return SPCBPT_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return SPCBPT_ERR_NO_DEVICE; }
+    // validate indices before anything reaches a kernel
+    for (int t = 0; t < sc->n_triangles; t++) {
+        for (int k = 0; k < 3; k++)
+            if (sc->indices[3 * (size_t)t + k] >= (uint32_t)sc->n_vertices) { g_create_error = "vertex index out of range"; return SPCBPT_ERR_INVALID_ARG; }
+        if (sc->tri_material[t] < 0 || sc->tri_material[t] >= sc->n_materials) { g_create_error = "material index out of range"; return SPCBPT_ERR_INVALID_ARG; }
+    }
+    int patches = 0;
+    for (int i = 0; i < sc->n_lights; i++) {
+        if (sc->lights[i].div_level < 1) { g_create_error = "light div_level must be >= 1"; return SPCBPT_ERR_INVALID_ARG; }
+        patches += sc->lights[i].div_level * sc->lights[i].div_level;
+    }
+    if (patches > SPCBPT_NUM_SUBSPACE_LIGHTSOURCE) { g_create_error = "sum of div_level^2 exceeds NUM_SUBSPACE_LIGHTSOURCE (200)"; return SPCBPT_ERR_INVALID_ARG; }
+    if (sc->n_materials + sc->n_lights > 32767) { g_create_error = "too many materials (int16 material ids)"; return SPCBPT_ERR_INVALID_ARG; }
+
+    spcbpt_ctx* c = new spcbpt_ctx();
+    c->device = device;
+#define CREATE_TRY(expr)                                                                                           \
+    do {                                                                                                           \
+        hipError_t e__ = (expr);                                                                                   \
+        if (e__ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e__); delete c; return SPCBPT_ERR_HIP; } \
+    } while (0)
+    CREATE_TRY(hipStreamCreate(&c->stream));
+
+    // ---- scene assembly (scene_shift.cpp:64-154, 184-328)
+    std::vector<float> V(sc->vertices, sc->vertices + 3 * (size_t)sc->n_vertices);
+    std::vector<float> UV(2 * (size_t)sc->n_vertices, 0.0f);
+    if (sc->texcoords) UV.assign(sc->texcoords, sc->texcoords + 2 * (size_t)sc->n_vertices);
+    std::vector<uint32_t> I(sc->indices, sc->indices + 3 * (size_t)sc->n_triangles);
+    std::vector<int32_t> TM(sc->tri_material, sc->tri_material + sc->n_triangles);
+    std::vector<uint8_t> EM(sc->n_triangles, 0);
+    std::vector<DMaterial> mats;
+    for (int i = 0; i < sc->n_materials; i++) {
+        const spcbpt_material& m = sc->materials[i];
+        if (m.albedo_tex < 0 || m.albedo_tex > sc->n_textures) { g_create_error = "albedo_tex out of range"; delete c; return SPCBPT_ERR_INVALID_ARG; }
+        DMaterial d;
+        memset(&d, 0, sizeof(d));
+        memcpy(d.base_color, m.base_color, 12);
+        d.metallic = m.metallic; d.roughness = m.roughness; d.specular = m.specular; d.specular_tint = m.specular_tint;
+        d.subsurface = m.subsurface; d.sheen = m.sheen; d.sheen_tint = m.sheen_tint; d.clearcoat = m.clearcoat;
+        d.clearcoat_gloss = m.clearcoat_gloss; d.albedo_tex = m.albedo_tex; d.light_id = -1;
+        mats.push_back(d);
+    }
+    std::vector<DLight> lights;
+    int ss_base = 0;
+    for (int i = 0; i < sc->n_lights; i++) {
+        const spcbpt_quad_light& s = sc->lights[i];
+        DLight L;
+        memset(&L, 0, sizeof(L));
+        float cr[3] = {s.u[1] * s.v[2] - s.u[2] * s.v[1], s.u[2] * s.v[0] - s.u[0] * s.v[2], s.u[0] * s.v[1] - s.u[1] * s.v[0]};
+        float len = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+        if (!(len > 0)) { g_create_error = "degenerate quad light"; delete c; return SPCBPT_ERR_INVALID_ARG; }
+        float inv = 1.0f / len;
+        for (int k = 0; k < 3; k++) {
+            L.corner[k] = s.position[k]; L.u[k] = s.position[k] + s.u[k]; L.v[k] = s.position[k] + s.v[k];
+            L.emission[k] = s.emission[k]; L.normal[k] = cr[k] * inv;
+        }
+        L.area = len; L.div_level = s.div_level; L.ss_base = ss_base; L.id = (int)lights.size();
+        ss_base += s.div_level * s.div_level;
+        lights.push_back(L);
+        DMaterial d;  // emissive pseudo-material with MaterialData() defaults
+        memset(&d, 0, sizeof(d));
+        d.base_color[0] = d.base_color[1] = d.base_color[2] = 1.0f; d.metallic = 1.0f; d.roughness = 1.0f; d.specular = 0.5f;
+        d.sheen_tint = 0.5f; d.clearcoat_gloss = 1.0f; d.light_id = i;
+        mats.push_back(d);
+        uint32_t base = (uint32_t)(V.size() / 3);
+        float p3[3] = {L.u[0] + L.v[0] - L.corner[0], L.u[1] + L.v[1] - L.corner[1], L.u[2] + L.v[2] - L.corner[2]};
+        V.insert(V.end(), L.corner, L.corner + 3); V.insert(V.end(), L.u, L.u + 3); V.insert(V.end(), L.v, L.v + 3); V.insert(V.end(), p3, p3 + 3);
+        const float quv[8] = {0, 0, 1, 0, 0, 1, 1, 1};
+        UV.insert(UV.end(), quv, quv + 8);
+        const uint32_t qi[6] = {base, base + 1, base + 3, base, base + 3, base + 2};
+        I.insert(I.end(), qi, qi + 6);
+        TM.push_back((int)mats.size() - 1); TM.push_back((int)mats.size() - 1);
+        EM.push_back(1); EM.push_back(1);
+    }
+    HostMesh mesh;
+    mesh.vertices = V.data(); mesh.texcoords = UV.data(); mesh.indices = I.data(); mesh.tri_material = TM.data(); mesh.tri_emitter = EM.data();
+    mesh.n_vertices = (int)(V.size() / 3); mesh.n_triangles = (int)(I.size() / 3);
+    Lbvh bvh;
+    build_lbvh(mesh, bvh);
+    c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 16); c->bvh_depth = bvh.depth;
+    c->n_lights = (int)lights.size(); c->n_mats = (int)mats.size();
+
+    CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size()));
+    CREATE_TRY(dev_alloc(&c->d_tris, bvh.tris.size()));
+    CREATE_TRY(dev_alloc(&c->d_tri_orig, bvh.tri_orig.size()));
+    CREATE_TRY(dev_alloc(&c->d_mats, mats.size()));
+    CREATE_TRY(dev_alloc(&c->d_lights, lights.size()));
+    CREATE_TRY(hipMemcpy(c->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_tris, bvh.tris.data(), bvh.tris.size() * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_tri_orig, bvh.tri_orig.data(), bvh.tri_orig.size() * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    std::vector<DTexture> texs;
+    for (int i = 0; i < sc->n_textures; i++) {
+        const spcbpt_texture& t = sc->textures[i];
+        if (!t.rgba || t.width < 1 || t.height < 1) { g_create_error = "bad texture"; delete c; return SPCBPT_ERR_INVALID_ARG; }
+        uint32_t* d = nullptr;
+        CREATE_TRY(dev_alloc(&d, (size_t)t.width * t.height));
+        c->d_tex_data.push_back(d);
+        CREATE_TRY(hipMemcpy(d, t.rgba, (size_t)t.width * t.height * 4, hipMemcpyHostToDevice));
+        texs.push_back(DTexture{d, t.width, t.height});
+    }
+    CREATE_TRY(dev_alloc(&c->d_tex, texs.size()));
+    if (!texs.empty()) CREATE_TRY(hipMemcpy(c->d_tex, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
+    CREATE_TRY(dev_alloc(&c->d_subspace, (size_t)SPCBPT_NUM_SUBSPACE));
+    CREATE_TRY(dev_alloc(&c->d_sampler_counts, (size_t)2));
+    CREATE_TRY(hipMemset(c->d_sampler_counts, 0, 2 * sizeof(int)));
+    CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
+    CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
+    memset(&c->kp, 0, sizeof(c->kp));
+    c->kp.scene.nodes = c->d_nodes; c->kp.scene.tris = c->d_tris; c->kp.scene.tri_orig = c->d_tri_orig; c->kp.scene.mats = c->d_mats;
+    c->kp.scene.lights = c->d_lights; c->kp.scene.tex = c->d_tex; c->kp.scene.n_lights = c->n_lights; c->kp.scene.n_mats = c->n_mats;
+    c->kp.sampler_counts = c->d_sampler_counts;
+    c->kp.row_step = 1;
+#undef CREATE_TRY
+    *out = c;
+    return SPCBPT_OK;
+}
+
+int spcbpt_destroy(spcbpt_ctx* c) {
+    if (!c) return SPCBPT_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    delete c;
+    return SPCBPT_OK;
+}
+
+const char* spcbpt_last_error(const spcbpt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+#define CTX_CHECK(c)                                  \
+    if (!(c)) return SPCBPT_ERR_INVALID_ARG;          \
+    if (hipSetDevice((c)->device) != hipSuccess) { (c)->error = "hipSetDevice failed"; return SPCBPT_ERR_HIP; }
+
+int spcbpt_set_camera(spcbpt_ctx* c, const float eye[3], const float U[3], const float V[3], const float W[3]) {
+    CTX_CHECK(c);
+    if (!eye || !U || !V || !W) { c->error = "null camera vector"; return SPCBPT_ERR_INVALID_ARG; }
+    memcpy(c->kp.eye, eye, 12); memcpy(c->kp.U, U, 12); memcpy(c->kp.V, V, 12); memcpy(c->kp.W, W, 12);
+    c->have_camera = true;
+    return SPCBPT_OK;
+}
+
+int spcbpt_set_camera_lookat(spcbpt_ctx* c, const float eye[3], const float lookat[3], const float up[3], float fov, float aspect) {
+    CTX_CHECK(c);
+    if (!eye || !lookat || !up) { c->error = "null camera vector"; return SPCBPT_ERR_INVALID_ARG; }
+    // sutil::Camera::UVWFrame (sutil/Camera.cpp:34-45)
+    auto cross = [](const float* a, const float* b, float* r) { r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0]; };
+    auto norm = [](float* v) { float inv = 1.0f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] *= inv; v[1] *= inv; v[2] *= inv; };
+    float W[3] = {lookat[0] - eye[0], lookat[1] - eye[1], lookat[2] - eye[2]}, U[3], V[3];
+    float wlen = sqrtf(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]);
+    cross(W, up, U); norm(U);
+    cross(U, W, V); norm(V);
+    float vlen = wlen * tanf(0.5f * fov * 3.14159265358979323846f / 180.0f);
+    for (int k = 0; k < 3; k++) V[k] *= vlen;
+    float ulen = vlen * aspect;
+    for (int k = 0; k < 3; k++) U[k] *= ulen;
+    return spcbpt_set_camera(c, eye, U, V, W);
+}
+
+int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
+    CTX_CHECK(c);
+    if (w < 1 || h < 1 || (long long)w * h > (1ll << 28)) { c->error = "bad image size"; return SPCBPT_ERR_INVALID_ARG; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    dev_free(c->d_accum); dev_free(c->d_frame);
+    HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
+    HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
+    HIP_TRY(c, hipMemset(c->d_accum, 0, (size_t)w * h * 16));
+    HIP_TRY(c, hipMemset(c->d_frame, 0, (size_t)w * h * 4));
+    c->kp.width = w; c->kp.height = h; c->kp.accum = c->d_accum; c->kp.frame = c->d_frame;
+    return SPCBPT_OK;
+}
+
+int spcbpt_set_subspace(spcbpt_ctx* c, const spcbpt_tree_node* et, int ne, const spcbpt_tree_node* lt, int nl, const float* q, const float* g) {
+    CTX_CHECK(c);
+    if (!et && !lt && !q && !g) return c->install_minimal_tuple();
+    return c->install_subspace(et, ne, lt, nl, q, g);
+}
+
+int spcbpt_set_light_trace(spcbpt_ctx* c, const spcbpt_light_trace_params* p) {
+    CTX_CHECK(c);
+    if (!p) { c->error = "null params"; return SPCBPT_ERR_INVALID_ARG; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return c->set_light_trace(*p);
+}
+
+int spcbpt_launch(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r1, int rs) {
+    CTX_CHECK(c);
+    if (!name) { c->error = "null algorithm name"; return SPCBPT_ERR_INVALID_ARG; }
+    const std::string alg(name);
+    if (alg == "light trace") return c->launch_light(frame);
+    if (alg == "SPCBPT_eye") return c->launch_render("spcbpt_render", true, frame, r0, r1, rs);
+    if (alg == "pt") return c->launch_render("pt", false, frame, r0, r1, rs);
+    if (alg == "pretrace") return c->launch_pretrace(frame);
+    c->error = "unknown algorithm '" + alg + "' (expected \"pt\", \"light trace\", \"SPCBPT_eye\" or \"pretrace\")";
+    return SPCBPT_ERR_UNKNOWN_ALG;
+}
+
+int spcbpt_build_sampler(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    return c->build_sampler();
+}
+
+int spcbpt_lvc_export(spcbpt_ctx* c, void** dv, void** dc, int* cap) {
+    CTX_CHECK(c);
+    if (!dv || !dc || !cap) return SPCBPT_ERR_INVALID_ARG;
+    if (!c->d_lvc) { c->error = "no LVC allocated"; return SPCBPT_ERR_STATE; }
+    *dv = c->d_lvc; *dc = c->d_sampler_counts; *cap = (int)c->lvc_capacity;
+    return SPCBPT_OK;
+}
+
+int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device) {
+    CTX_CHECK(c);
+    if (!verts || count < 0) { c->error = "bad LVC import"; return SPCBPT_ERR_INVALID_ARG; }
+    int rc = c->ensure_lvc_capacity((size_t)std::max(count, 1));
+    if (rc) return rc;
+    if ((const void*)c->d_lvc != verts)
+        HIP_TRY(c, hipMemcpyAsync(c->d_lvc, verts, (size_t)count * sizeof(LightVertex), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    int h[2] = {count, 0};
+    HIP_TRY(c, hipMemcpyAsync(c->d_sampler_counts, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->lvc_count = count;
+    c->keys_ready = false;
+    c->have_sampler = false;
+    return SPCBPT_OK;
+}
+
+int spcbpt_lvc_read(spcbpt_ctx* c, spcbpt_light_vertex* out, int capacity, int* count) {
+    CTX_CHECK(c);
+    if (!count) return SPCBPT_ERR_INVALID_ARG;
+    if (!c->d_lvc) { c->error = "no LVC"; return SPCBPT_ERR_STATE; }
+    int rc = c->fetch_counts();
+    if (rc) return rc;
+    *count = c->lvc_count;
+    if (!out) return SPCBPT_OK;
+    if (capacity < c->lvc_count) { c->error = "lvc_read: buffer too small"; return SPCBPT_ERR_CAPACITY; }
+    HIP_TRY(c, hipMemcpy(out, c->d_lvc, (size_t)c->lvc_count * sizeof(LightVertex), hipMemcpyDeviceToHost));
+    return SPCBPT_OK;
+}
+
+int spcbpt_sampler_read(spcbpt_ctx* c, spcbpt_subspace* sub, float* cmfs, int32_t* jump, int capacity, int* vc, int* pc) {
+    CTX_CHECK(c);
+    if (!c->have_sampler) { c->error = "no sampler built"; return SPCBPT_ERR_STATE; }
+    if (!sub || !vc || !pc) return SPCBPT_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<DSubspace> h(SPCBPT_NUM_SUBSPACE);
+    HIP_TRY(c, hipMemcpy(h.data(), c->d_subspace, h.size() * sizeof(DSubspace), hipMemcpyDeviceToHost));
+    for (int i = 0; i < SPCBPT_NUM_SUBSPACE; i++) {
+        sub[i].jump_bias = h[i].jump_bias; sub[i].id = i; sub[i].size = h[i].size; sub[i].sum_pmf = h[i].sum_pmf; sub[i].q = 0;
+    }
+    *vc = c->lvc_count; *pc = c->path_count;
+    if (cmfs && jump) {
+        if (capacity < c->lvc_count) { c->error = "sampler_read: buffer too small"; return SPCBPT_ERR_CAPACITY; }
+        HIP_TRY(c, hipMemcpy(cmfs, c->d_cmfs, (size_t)c->lvc_count * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(jump, c->d_vals2, (size_t)c->lvc_count * 4, hipMemcpyDeviceToHost));
+    }
+    return SPCBPT_OK;
+}
+
+int spcbpt_read_accum(spcbpt_ctx* c, float* out) {
+    CTX_CHECK(c);
+    if (!out || !c->d_accum) { c->error = "no accum buffer"; return SPCBPT_ERR_STATE; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_accum, (size_t)c->kp.width * c->kp.height * 16, hipMemcpyDeviceToHost));
+    return SPCBPT_OK;
+}
+int spcbpt_read_frame(spcbpt_ctx* c, uint8_t* out) {
+    CTX_CHECK(c);
+    if (!out || !c->d_frame) { c->error = "no frame buffer"; return SPCBPT_ERR_STATE; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_frame, (size_t)c->kp.width * c->kp.height * 4, hipMemcpyDeviceToHost));
+    return SPCBPT_OK;
+}
+int spcbpt_accum_device_ptr(spcbpt_ctx* c, void** p) {
+    CTX_CHECK(c);
+    if (!p || !c->d_accum) return SPCBPT_ERR_STATE;
+    *p = c->d_accum;
+    return SPCBPT_OK;
+}
+int spcbpt_clear_accum(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    if (!c->d_accum) return SPCBPT_ERR_STATE;
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->kp.width * c->kp.height * 16, c->stream));
+    return SPCBPT_OK;
+}
+
+int spcbpt_get_counters(spcbpt_ctx* c, spcbpt_counters* o) {
+    CTX_CHECK(c);
+    if (!o) return SPCBPT_ERR_INVALID_ARG;
+    unsigned long long h[C_COUNT];
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    o->closest_rays = h[C_CLOSEST]; o->shadow_rays = h[C_SHADOW]; o->node_visits = h[C_NODE]; o->tri_tests = h[C_TRI];
+    o->surface_vertices = h[C_VERTEX]; o->textured_hits = h[C_TEX]; o->tree_nodes = h[C_TREE]; o->cmf_probes = h[C_CMF];
+    o->connections = h[C_CONN]; o->gamma_q_reads = h[C_GQ]; o->lvc_stores = h[C_LVCW]; o->pixel_samples = h[C_PIX];
+    o->eye_paths = h[C_EYE]; o->light_paths = h[C_LIGHT];
+    return SPCBPT_OK;
+}
+int spcbpt_reset_counters(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, C_COUNT * sizeof(unsigned long long), c->stream));
+    return SPCBPT_OK;
+}
+int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; return SPCBPT_OK; }
+
+int spcbpt_stream(spcbpt_ctx* c, void** s) { CTX_CHECK(c); if (!s) return SPCBPT_ERR_INVALID_ARG; *s = (void*)c->stream; return SPCBPT_OK; }
+int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SPCBPT_OK; }
+
+int spcbpt_kernel_time(spcbpt_ctx* c, const char* name, double* avg_ms, int* launches) {
+    CTX_CHECK(c);
+    if (!name || !avg_ms || !launches) return SPCBPT_ERR_INVALID_ARG;
+    c->resolve_spans();
+    auto it = c->times.find(name);
+    if (it == c->times.end() || it->second.second == 0) { *avg_ms = 0; *launches = 0; return SPCBPT_OK; }
+    *avg_ms = it->second.first / it->second.second;
+    *launches = it->second.second;
+    return SPCBPT_OK;
+}
+int spcbpt_reset_kernel_time(spcbpt_ctx* c) { CTX_CHECK(c); c->resolve_spans(); c->times.clear(); return SPCBPT_OK; }
+int spcbpt_enable_kernel_timing(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->timing = on != 0; return SPCBPT_OK; }
+
+static int trace_common(spcbpt_ctx* c, const float* rays, int n, float** d_rays) {
+    if (!rays || n < 0) { c->error = "bad rays"; return SPCBPT_ERR_INVALID_ARG; }
+    for (size_t i = 0; i < (size_t)n * 8; i++)
+        if (!std::isfinite(rays[i]) && !(i % 8 == 7)) { c->error = "non-finite ray component"; return SPCBPT_ERR_INVALID_ARG; }
+    HIP_TRY(c, dev_alloc(d_rays, (size_t)n * 8));
+    HIP_TRY(c, hipMemcpy(*d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice));
+    return c->ensure_spill(((size_t)n + 255) / 256 * 256);
+}
+int spcbpt_trace_closest(spcbpt_ctx* c, const float* rays, int n, float* out_t, int32_t* out_tri, float* out_uv) {
+    CTX_CHECK(c);
+    if (!out_t || !out_tri || !out_uv) return SPCBPT_ERR_INVALID_ARG;
+    float* d_rays = nullptr; float* d_t = nullptr; int* d_tri = nullptr; float* d_uv = nullptr;
+    int rc = trace_common(c, rays, n, &d_rays);
+    if (rc) { dev_free(d_rays); return rc; }
+    HIP_TRY(c, dev_alloc(&d_t, (size_t)n)); HIP_TRY(c, dev_alloc(&d_tri, (size_t)n)); HIP_TRY(c, dev_alloc(&d_uv, (size_t)n * 2));
+    launch_trace_closest(c->kp, d_rays, n, d_t, d_tri, d_uv, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost);
+    dev_free(d_rays); dev_free(d_t); dev_free(d_tri); dev_free(d_uv);
+    if (e != hipSuccess) { c->error = hipGetErrorString(e); return SPCBPT_ERR_HIP; }
+    return SPCBPT_OK;
+}
+int spcbpt_trace_any(spcbpt_ctx* c, const float* rays, int n, int32_t* out_visible) {
+    CTX_CHECK(c);
+    if (!out_visible) return SPCBPT_ERR_INVALID_ARG;
+    float* d_rays = nullptr; int* d_vis = nullptr;
+    int rc = trace_common(c, rays, n, &d_rays);
+    if (rc) { dev_free(d_rays); return rc; }
+    HIP_TRY(c, dev_alloc(&d_vis, (size_t)n));
+    launch_trace_any(c->kp, d_rays, n, d_vis, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_visible, d_vis, (size_t)n * 4, hipMemcpyDeviceToHost);
+    dev_free(d_rays); dev_free(d_vis);
+    if (e != hipSuccess) { c->error = hipGetErrorString(e); return SPCBPT_ERR_HIP; }
+    return SPCBPT_OK;
+}
+
+int spcbpt_preprocess(spcbpt_ctx* c, int target_paths, int target_q_paths, int train) {
+    CTX_CHECK(c);
+    return c->preprocess(target_paths, target_q_paths, train != 0);
+}
+
+int spcbpt_get_subspace(spcbpt_ctx* c, spcbpt_tree_node* et, int* ne, int cap_e, spcbpt_tree_node* lt, int* nl, int cap_l, float* q, float* g) {
+    CTX_CHECK(c);
+    if (!c->have_subspace) { c->error = "no subspace tuple installed"; return SPCBPT_ERR_STATE; }
+    if (!ne || !nl) return SPCBPT_ERR_INVALID_ARG;
+    *ne = (int)c->h_eye_tree.size(); *nl = (int)c->h_light_tree.size();
+    if (et) { if (cap_e < *ne) return SPCBPT_ERR_CAPACITY; memcpy(et, c->h_eye_tree.data(), c->h_eye_tree.size() * sizeof(spcbpt_tree_node)); }
+    if (lt) { if (cap_l < *nl) return SPCBPT_ERR_CAPACITY; memcpy(lt, c->h_light_tree.data(), c->h_light_tree.size() * sizeof(spcbpt_tree_node)); }
+    if (q) memcpy(q, c->h_Q.data(), c->h_Q.size() * 4);
+    if (g) memcpy(g, c->h_gamma.data(), c->h_gamma.size() * 4);
+    return SPCBPT_OK;
+}
+
+int spcbpt_scene_info(spcbpt_ctx* c, int* nt, int* nn, int* depth) {
+    CTX_CHECK(c);
+    if (nt) *nt = c->n_triangles;
+    if (nn) *nn = c->n_nodes;
+    if (depth) *depth = c->bvh_depth;
+    return SPCBPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// Per-GPU context: owns every HBM buffer of the path (the reference leaves ownership to function-static
+// thrust vectors and never frees, device_thrust.cu:287-293).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "layout.h"
+
+namespace spc {
+
+struct TimedSpan {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    KParams kp;
+    // scene
+    float* d_nodes = nullptr;
+    float* d_tris = nullptr;
+    int32_t* d_tri_orig = nullptr;
+    DMaterial* d_mats = nullptr;
+    DLight* d_lights = nullptr;
+    DTexture* d_tex = nullptr;
+    std::vector<uint32_t*> d_tex_data;
+    int n_triangles = 0, n_nodes = 0, bvh_depth = 0, n_lights = 0, n_mats = 0;
+    // film
+    float* d_accum = nullptr;
+    uint32_t* d_frame = nullptr;
+    bool have_camera = false;
+    // subspace tuple
+    float* d_eye_tree = nullptr;
+    float* d_light_tree = nullptr;
+    float* d_Q = nullptr;
+    float* d_gamma = nullptr;
+    std::vector<spcbpt_tree_node> h_eye_tree, h_light_tree;
+    std::vector<float> h_Q, h_gamma;
+    bool have_subspace = false;
+    // light pass + LVC + sampler
+    spcbpt_light_trace_params lt = {100000, 52, 1, 0, 100000};
+    LightVertex* d_scratch = nullptr;
+    size_t scratch_capacity = 0;
+    int* d_core_counts = nullptr;
+    int* d_core_offsets = nullptr;
+    size_t counts_capacity = 0;
+    LightVertex* d_lvc = nullptr;
+    size_t lvc_capacity = 0;
+    uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
+    float* d_weights = nullptr;
+    double *d_wsorted = nullptr, *d_prefix = nullptr;
+    float* d_cmfs = nullptr;
+    DSubspace* d_subspace = nullptr;
+    int* d_sampler_counts = nullptr;  // [0] vertex_count, [1] path_count
+    int lvc_count = 0, path_count = 0;
+    bool keys_ready = false, have_sampler = false;
+    // scratch
+    unsigned char* d_temp = nullptr;
+    size_t temp_capacity = 0;
+    uint32_t* d_spill = nullptr;
+    size_t spill_capacity = 0;
+    // instrumentation
+    unsigned long long* d_counters = nullptr;
+    bool counting = false, timing = false;
+    std::vector<TimedSpan> spans;
+    std::map<std::string, std::pair<double, int>> times;
+
+    ~Context();
+    void time_begin(const char* name);
+    void time_end();
+    void resolve_spans();
+    int ensure_spill(size_t threads);
+    int ensure_temp(size_t bytes);
+    int ensure_lvc_capacity(size_t n);
+    int upload_tree(const spcbpt_tree_node* t, int n, float*& d_tree, std::vector<spcbpt_tree_node>& host_copy);
+    int install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_tree_node* lt, int nl, const float* q, const float* g);
+    int install_minimal_tuple();
+    int set_light_trace(const spcbpt_light_trace_params& p);
+    int launch_light(uint32_t frame);
+    int fetch_counts();
+    int build_sampler();
+    int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs);
+    // preprocess.hip
+    int launch_pretrace(uint32_t iteration);
+    int preprocess(int target_paths, int target_q_paths, bool train);
+};
+
+}  // namespace spc

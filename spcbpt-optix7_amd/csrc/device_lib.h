@@ -1,0 +1,593 @@
+// Device library of the MI355X SPCBPT hot path (gfx950, wave64).  Scalar branchy FP32 — no MFMA.
+// What each block replaces in the reference (paths relative to src/OptiXPathTracer):
+//   traversal      -> optixTrace closest / terminate-on-first-hit (cuProg.h:384-487)
+//   hit geometry   -> getLocalGeometry (../cuda/LocalGeometry.h:59-175), ColorTexSample (hit_program.cu:182-198)
+//   bsdf_*         -> Tracer::Eval / Sample / Pdf (cuProg.h:735-899)
+//   tree_label     -> classTree::tree_index (decisionTree/classTree_common.h:39-51)
+//   rmis_*         -> rmis.h:16-389
+//   binary_sample  -> cuProg.h:245-264
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace spc {
+
+#define SPC_DEV __device__ __forceinline__
+static constexpr float kPi = 3.14159265358979323846f;
+static constexpr float kInvPi = 1.0f / 3.14159265358979323846f;
+static constexpr float kEps = SPCBPT_SCENE_EPSILON;
+
+struct f3 { float x, y, z; };
+SPC_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+SPC_DEV f3 mk3(float s) { return mk3(s, s, s); }
+SPC_DEV f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+SPC_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SPC_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SPC_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+SPC_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+SPC_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+SPC_DEV f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+SPC_DEV f3 operator/(f3 a, float s) { float inv = 1.0f / s; return a * inv; }
+SPC_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+SPC_DEV f3& operator+=(f3& a, f3 b) { a = a + b; return a; }
+SPC_DEV f3& operator*=(f3& a, f3 b) { a = a * b; return a; }
+SPC_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SPC_DEV f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+SPC_DEV f3 normalize(f3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv; }
+SPC_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
+SPC_DEV f3 lerp3(f3 a, f3 b, float t) { return a + t * (b - a); }
+SPC_DEV float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+SPC_DEV float max3(f3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+SPC_DEV float sum3(f3 a) { return a.x + a.y + a.z; }
+SPC_DEV float4 ldq(const float* base, size_t quad) { return reinterpret_cast<const float4*>(base)[quad]; }
+
+// ---- RNG (../cuda/random.h:31-67) -------------------------------------------
+SPC_DEV uint32_t tea4(uint32_t v0, uint32_t v1) {
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+SPC_DEV float rnd(uint32_t& s) {
+    s = 1664525u * s + 1013904223u;
+    return (float)(s & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+// ---- event counters ----------------------------------------------------------
+template <bool ON>
+struct Counts {
+    unsigned v[ON ? C_COUNT : 1];
+    SPC_DEV void clear() { if (ON) { for (int i = 0; i < C_COUNT; i++) v[i] = 0; } }
+    SPC_DEV void add(int slot, unsigned n = 1) { if (ON) v[slot] += n; }
+    SPC_DEV void flush(unsigned long long* g) {
+        if (ON && g) {
+#pragma unroll
+            for (int i = 0; i < C_COUNT; i++) {
+                unsigned x = v[i];
+                for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+                if ((threadIdx.x & 63) == 0 && x) atomicAdd(&g[i], (unsigned long long)x);
+            }
+        }
+    }
+};
+
+// ---- software LBVH traversal: per-lane stack in LDS --------------------------
+// The stack is laid out entry-major ([entry][thread]) so the 64 lanes of a wave hit 64 consecutive
+// dwords = all LDS banks, conflict-free.  Entries beyond STACK_LDS spill to HBM (rare: LBVH depth).
+template <int BLOCK, int STACK_LDS>
+struct TravStack {
+    uint32_t* lds;    // BLOCK * STACK_LDS dwords
+    uint32_t* spill;  // per-thread spill area or null
+    int spill_entries;
+    int sp;
+    SPC_DEV void init(uint32_t* l, uint32_t* s, int se, size_t gtid) {
+        lds = l + threadIdx.x;
+        spill = s ? s + gtid * (size_t)se : nullptr;
+        spill_entries = se;
+        sp = 0;
+    }
+    SPC_DEV void push(uint32_t v) {
+        if (sp < STACK_LDS) lds[sp * BLOCK] = v;
+        else if (spill && sp - STACK_LDS < spill_entries) spill[sp - STACK_LDS] = v;
+        sp++;
+    }
+    SPC_DEV uint32_t pop() {
+        sp--;
+        if (sp < STACK_LDS) return lds[sp * BLOCK];
+        if (spill && sp - STACK_LDS < spill_entries) return spill[sp - STACK_LDS];
+        return 0xffffffffu;  // dropped subtree (stack deeper than LDS + spill): never reached when sized from the build depth
+    }
+};
+
+struct HitRec { float t; int tri; float u, v; };
+
+SPC_DEV f3 safe_inv(f3 d) {
+    const float tiny = 1e-20f;
+    f3 r;
+    r.x = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+    r.y = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+    r.z = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+    return r;
+}
+SPC_DEV bool slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float tmax, float& tnear) {
+    float tx0 = (lo.x - o.x) * inv.x, tx1 = (hi.x - o.x) * inv.x;
+    float ty0 = (lo.y - o.y) * inv.y, ty1 = (hi.y - o.y) * inv.y;
+    float tz0 = (lo.z - o.z) * inv.z, tz1 = (hi.z - o.z) * inv.z;
+    float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    float t1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    tnear = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+// Moller-Trumbore on (P0, P1, P2); accepts tmin < t < tmax; culls the back face when asked (emitter quads).
+SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, float tmax, bool cull, float& ot, float& ou, float& ov) {
+    const f3 v0 = mk3(q0.x, q0.y, q0.z);
+    const f3 e1 = mk3(q1.x, q1.y, q1.z) - v0, e2 = mk3(q2.x, q2.y, q2.z) - v0;
+    if (cull && dot(cross(e1, e2), d) > 0.0f) return false;
+    const f3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const f3 tv = o - v0;
+    const float u = dot(tv, p) * inv;
+    if (u < 0.0f || u > 1.0f) return false;
+    const f3 q = cross(tv, e1);
+    const float v = dot(d, q) * inv;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float t = dot(e2, q) * inv;
+    if (!(t > tmin && t < tmax)) return false;
+    ot = t; ou = u; ov = v;
+    return true;
+}
+
+// ANY = terminate on first hit, no culling (visibilityTest); else nearest hit with emitter back-face culling.
+template <bool ANY, bool COUNT, int BLOCK, int STACK_LDS>
+SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 o, f3 d, float tmin, float tmax, HitRec& hit,
+                      Counts<COUNT>& cn) {
+    const f3 inv = safe_inv(d);
+    hit.t = tmax; hit.tri = -1; hit.u = hit.v = 0.0f;
+    st.sp = 0;
+    int node = 0;  // root is always an internal node
+    int leaf_count = 0;
+    while (true) {
+        if (node >= 0) {
+            const float4 q0 = ldq(S.nodes, (size_t)node * 4 + 0), q1 = ldq(S.nodes, (size_t)node * 4 + 1);
+            const float4 q2 = ldq(S.nodes, (size_t)node * 4 + 2), q3 = ldq(S.nodes, (size_t)node * 4 + 3);
+            cn.add(C_NODE);
+            float t0, t1;
+            const bool h0 = slab(q0, q1, o, inv, tmin, hit.t, t0);
+            const bool h1 = slab(q2, q3, o, inv, tmin, hit.t, t1);
+            const int c0 = __float_as_int(q0.w), c1 = __float_as_int(q1.w);
+            const int n0 = __float_as_int(q2.w), n1 = __float_as_int(q3.w);
+            if (h0 && h1) {
+                const bool first0 = ANY ? true : (t0 <= t1);
+                const int near_c = first0 ? c0 : c1, far_c = first0 ? c1 : c0;
+                const int near_n = first0 ? n0 : n1, far_n = first0 ? n1 : n0;
+                // leaf refs carry their count in the low bits of the pushed word: ref<<3 | count (count<=4)
+                st.push(far_c >= 0 ? (uint32_t)far_c : (0x80000000u | ((uint32_t)(~far_c) << 3) | (uint32_t)far_n));
+                node = near_c; leaf_count = near_n;
+            } else if (h0) {
+                node = c0; leaf_count = n0;
+            } else if (h1) {
+                node = c1; leaf_count = n1;
+            } else {
+                if (st.sp == 0) break;
+                uint32_t w = st.pop();
+                if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
+                else node = (int)w;
+            }
+        } else {
+            const int first = ~node;
+            for (int i = 0; i < leaf_count; i++) {
+                const size_t base = (size_t)(first + i) * 4;
+                const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
+                cn.add(C_TRI);
+                bool cull = false;
+                if (!ANY) {
+                    // emitter flag lives in quad 3; only fetched for closest-hit rays
+                    cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
+                }
+                float t, u, v;
+                if (tri_test(a, b, c, o, d, tmin, hit.t, cull, t, u, v)) {
+                    hit.t = t; hit.tri = first + i; hit.u = u; hit.v = v;
+                    if (ANY) return true;
+                }
+            }
+            if (st.sp == 0) break;
+            uint32_t w = st.pop();
+            if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
+            else node = (int)w;
+        }
+    }
+    return hit.tri >= 0;
+}
+
+// ---- materials / textures / hit geometry -------------------------------------
+struct Pbr {
+    f3 base;
+    float metallic, roughness, specular, specularTint, subsurface, sheen, sheenTint, clearcoat, clearcoatGloss;
+    int albedo_tex, light_id;
+};
+SPC_DEV Pbr load_pbr(const DeviceScene& S, int id) {
+    const float4* p = reinterpret_cast<const float4*>(S.mats + id);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Pbr m;
+    m.base = mk3(a.x, a.y, a.z); m.metallic = a.w;
+    m.roughness = b.x; m.specular = b.y; m.specularTint = b.z; m.subsurface = b.w;
+    m.sheen = c.x; m.sheenTint = c.y; m.clearcoat = c.z; m.clearcoatGloss = c.w;
+    m.albedo_tex = __float_as_int(d.x); m.light_id = __float_as_int(d.y);
+    return m;
+}
+SPC_DEV Pbr load_pbr_colored(const DeviceScene& S, int id, f3 color) {  // rmis::getMat (rmis.h:16-21)
+    Pbr m = load_pbr(S, id);
+    m.base = color;
+    return m;
+}
+// bilinear + wrap RGBA8 fetch (cudaReadModeNormalizedFloat semantics; exact-fraction weights)
+SPC_DEV f3 tex_fetch_rgb(const DTexture& T, float u, float v) {
+    const float x = u * (float)T.width - 0.5f, y = v * (float)T.height - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx % T.width, y0 = (int)fy % T.height;
+    if (x0 < 0) x0 += T.width;
+    if (y0 < 0) y0 += T.height;
+    int x1 = x0 + 1 == T.width ? 0 : x0 + 1, y1 = y0 + 1 == T.height ? 0 : y0 + 1;
+    const uint32_t t00 = T.rgba[(size_t)y0 * T.width + x0], t10 = T.rgba[(size_t)y0 * T.width + x1];
+    const uint32_t t01 = T.rgba[(size_t)y1 * T.width + x0], t11 = T.rgba[(size_t)y1 * T.width + x1];
+    const float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
+    const float s = 1.0f / 255.0f;
+    f3 r;
+    r.x = w00 * ((t00 & 255u) * s) + w10 * ((t10 & 255u) * s) + w01 * ((t01 & 255u) * s) + w11 * ((t11 & 255u) * s);
+    r.y = w00 * (((t00 >> 8) & 255u) * s) + w10 * (((t10 >> 8) & 255u) * s) + w01 * (((t01 >> 8) & 255u) * s) + w11 * (((t11 >> 8) & 255u) * s);
+    r.z = w00 * (((t00 >> 16) & 255u) * s) + w10 * (((t10 >> 16) & 255u) * s) + w01 * (((t01 >> 16) & 255u) * s) + w11 * (((t11 >> 16) & 255u) * s);
+    return r;
+}
+struct Geom { f3 P, N; float u, v; int mat; bool emitter; };
+SPC_DEV Geom local_geometry(const DeviceScene& S, const HitRec& h) {
+    const size_t base = (size_t)h.tri * 4;
+    const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2), d = ldq(S.tris, base + 3);
+    const f3 P0 = mk3(a.x, a.y, a.z), P1 = mk3(b.x, b.y, b.z), P2 = mk3(c.x, c.y, c.z);
+    Geom g;
+    const float w = 1.0f - h.u - h.v;
+    g.P = w * P0 + h.u * P1 + h.v * P2;
+    g.N = normalize(cross(P1 - P0, P2 - P0));
+    g.u = w * a.w + h.u * c.w + h.v * d.y;
+    g.v = w * b.w + h.u * d.x + h.v * d.z;
+    const uint32_t meta = __float_as_uint(d.w);
+    g.mat = (int)(meta & 0x7fffffffu);
+    g.emitter = (meta & 0x80000000u) != 0;
+    return g;
+}
+template <bool COUNT>
+SPC_DEV void color_tex_sample(const DeviceScene& S, const Geom& g, Pbr& m, Counts<COUNT>& cn) {  // hit_program.cu:182-198
+    if (m.albedo_tex > 0) {
+        const f3 t = tex_fetch_rgb(S.tex[m.albedo_tex - 1], g.u, g.v);
+        m.base = mk3(powf(t.x, 2.2f), powf(t.y, 2.2f), powf(t.z, 2.2f));  // linearize cuProg.h:361-368
+        cn.add(C_TEX);
+    }
+}
+
+// ---- Disney BSDF (cuProg.h:686-899) ---------------------------------------------
+struct Onb {
+    f3 t, b, n;
+    SPC_DEV explicit Onb(f3 normal) {
+        n = normal;
+        if (fabsf(n.x) > fabsf(n.z)) b = mk3(-n.y, n.x, 0.0f);
+        else b = mk3(0.0f, -n.z, n.y);
+        b = normalize(b);
+        t = cross(b, n);
+    }
+    SPC_DEV f3 to_world(f3 p) const { return p.x * t + p.y * b + p.z * n; }
+};
+SPC_DEV f3 cosine_sample_hemisphere(float u1, float u2) {
+    const float r = sqrtf(u1);
+    const float phi = 2.0f * kPi * u2;
+    float s, c;
+    sincosf(phi, &s, &c);
+    f3 p;
+    p.x = r * c; p.y = r * s;
+    p.z = sqrtf(fmaxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+    return p;
+}
+SPC_DEV float schlick(float u) { float m = clampf(1.0f - u, 0.0f, 1.0f); float m2 = m * m; return m2 * m2 * m; }
+SPC_DEV float gtr1(float NdH, float a) {
+    if (a >= 1.0f) return kInvPi;
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * NdH * NdH;
+    return (a2 - 1.0f) / (kPi * logf(a2) * t);
+}
+SPC_DEV float gtr2(float NdH, float a) {
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * NdH * NdH;
+    return a2 / (kPi * t * t);
+}
+SPC_DEV float smith_ggx(float NdV, float alphaG) {
+    float a = alphaG * alphaG, b = NdV * NdV;
+    return 1.0f / (NdV + sqrtf(a + b - a * b));
+}
+SPC_DEV f3 bsdf_eval(const Pbr& m, f3 N, f3 V, f3 L) {
+    const float NdL = dot(N, L), NdV = dot(N, V);
+    if (NdL <= 0.0f || NdV <= 0.0f) return mk3(0.0f);
+    const f3 H = normalize(L + V);
+    const float NdH = dot(N, H), LdH = dot(L, H);
+    const f3 Cd = m.base;
+    const float lum = 0.3f * Cd.x + 0.6f * Cd.y + 0.1f * Cd.z;
+    const f3 Ctint = lum > 0.0f ? Cd / lum : mk3(1.0f);
+    const f3 Cspec0 = lerp3(m.specular * 0.08f * lerp3(mk3(1.0f), Ctint, m.specularTint), Cd, m.metallic);
+    const float FL = schlick(NdL), FV = schlick(NdV);
+    const float Fd90 = 0.5f + 2.0f * LdH * LdH * m.roughness;
+    const float Fd = lerpf(1.0f, Fd90, FL) * lerpf(1.0f, Fd90, FV);
+    const float Fss90 = LdH * LdH * m.roughness;
+    const float Fss = lerpf(1.0f, Fss90, FL) * lerpf(1.0f, Fss90, FV);
+    const float ss = 1.25f * (Fss * (1.0f / (NdL + NdV) - 0.5f) + 0.5f);
+    const float a = fmaxf(0.001f, m.roughness);
+    const float Ds = gtr2(NdH, a);
+    const float FH = schlick(LdH);
+    const f3 Fs = lerp3(Cspec0, mk3(1.0f), FH);
+    const float rg = (m.roughness * 0.5f + 0.5f) * (m.roughness * 0.5f + 0.5f);
+    const float Gs = smith_ggx(NdL, rg) * smith_ggx(NdV, rg);
+    f3 out = ((kInvPi * lerpf(Fd, ss, m.subsurface)) * Cd) * (1.0f - m.metallic) + Gs * Fs * Ds;
+    if (m.sheen != 0.0f) {  // sheen term is exactly zero for sheen == 0
+        const f3 Csheen = lerp3(mk3(1.0f), Ctint, m.sheenTint);
+        out = ((kInvPi * lerpf(Fd, ss, m.subsurface)) * Cd + FH * m.sheen * Csheen) * (1.0f - m.metallic) + Gs * Fs * Ds;
+    }
+    if (m.clearcoat != 0.0f) {  // clearcoat term is exactly zero for clearcoat == 0
+        const float Dr = gtr1(NdH, lerpf(0.1f, 0.001f, m.clearcoatGloss));
+        const float Fr = lerpf(0.04f, 1.0f, FH);
+        const float Gr = smith_ggx(NdL, 0.25f) * smith_ggx(NdV, 0.25f);
+        out = out + mk3(0.25f * m.clearcoat * Gr * Fr * Dr);
+    }
+    return out;
+}
+SPC_DEV f3 bsdf_sample(const Pbr& m, f3 N, f3 V, uint32_t& seed) {
+    const float probability = rnd(seed);
+    const float diffuseRatio = 0.5f * (1.0f - m.metallic);
+    const float r1 = rnd(seed), r2 = rnd(seed);
+    const Onb onb(N);
+    if (probability < diffuseRatio) return onb.to_world(cosine_sample_hemisphere(r1, r2));
+    const float a = fmaxf(0.001f, m.roughness);
+    const float phi = r1 * 2.0f * kPi;
+    const float cosTheta = sqrtf((1.0f - r2) / (1.0f + (a * a - 1.0f) * r2));
+    const float sinTheta = sqrtf(1.0f - cosTheta * cosTheta);
+    float sinPhi, cosPhi;
+    sincosf(phi, &sinPhi, &cosPhi);
+    const f3 half = onb.to_world(mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+    return 2.0f * dot(V, half) * half - V;
+}
+SPC_DEV float bsdf_pdf(const Pbr& m, f3 n, f3 V, f3 L) {
+    const float specularAlpha = fmaxf(0.001f, m.roughness);
+    const float diffuseRatio = 0.5f * (1.0f - m.metallic);
+    const float specularRatio = 1.0f - diffuseRatio;
+    const f3 half = normalize(L + V);
+    const float cosTheta = fabsf(dot(half, n));
+    const float pdfGTR2 = gtr2(cosTheta, specularAlpha) * cosTheta;
+    // kept as written in the reference even for clearcoat == 0: lerp(g1, g2, 1) = g1 + (g2 - g1) is NOT g2 in fp32
+    const float pdfGTR1 = gtr1(cosTheta, lerpf(0.1f, 0.001f, m.clearcoatGloss)) * cosTheta;
+    const float mix = lerpf(pdfGTR1, pdfGTR2, 1.0f / (1.0f + m.clearcoat));
+    const float pdfSpec = mix / (4.0f * fabsf(dot(L, half)));
+    const float pdfDiff = fabsf(dot(L, n)) * kInvPi;
+    return diffuseRatio * pdfDiff + specularRatio * pdfSpec;
+}
+
+// ---- subspace classification ---------------------------------------------------
+template <bool COUNT>
+SPC_DEV int tree_label(const float* tree, f3 position, f3 normal, f3 dir, Counts<COUNT>& cn) {
+    if (!tree) return 0;
+    int node = 0;
+    while (true) {
+        const float4 q0 = ldq(tree, (size_t)node * TREE_QUADS);
+        cn.add(C_TREE);
+        const uint32_t meta = __float_as_uint(q0.w);
+        if (meta & 4u) return (int)(meta >> 3);
+        const uint32_t type = meta & 3u;
+        const f3 p = type == 0 ? position : (type == 1 ? normal : dir);
+        const int ind = (p.x > q0.x ? 1 : 0) + (p.y > q0.y ? 2 : 0) + (p.z > q0.z ? 4 : 0);
+        node = reinterpret_cast<const int*>(tree)[(size_t)node * (TREE_QUADS * 4) + 4 + ind];
+    }
+}
+
+// Gamma(e,l)/Q[l] (optixPathTracer.h:173-189); the product always runs with a full tuple installed
+template <bool COUNT>
+SPC_DEV float gamma_ss(const KParams& p, int e, int l, Counts<COUNT>& cn) {
+    const float* row = p.cmf_gamma + (size_t)e * SPCBPT_NUM_SUBSPACE;
+    const float g = l == 0 ? row[0] : row[l] - row[l - 1];
+    cn.add(C_GQ, l == 0 ? 2 : 3);
+    return g / p.Q[l];
+}
+
+// binary_sample (cuProg.h:245-264): bespoke bisection restated exactly
+template <bool COUNT>
+SPC_DEV int binary_sample(const float* cmf, int size, uint32_t& seed, float& pmf, Counts<COUNT>& cn) {
+    const float index = rnd(seed);
+    int mid = size / 2 - 1, l = 0, r = size;
+    while (r - l > 1) {
+        cn.add(C_CMF);
+        if (index < cmf[mid]) r = mid + 1;
+        else l = mid + 1;
+        mid = (l + r) / 2 - 1;
+    }
+    pmf = l == 0 ? cmf[l] : cmf[l] - cmf[l - 1];
+    return l;
+}
+
+// ---- recursive MIS (rmis.h) ------------------------------------------------------
+// The fields of a path vertex the RMIS recursions read, shared by eye and light vertices.
+struct VCore {
+    f3 pos, n, color, lastPos;
+    float lnp;  // lastNormalProjection
+    int mat;
+};
+SPC_DEV float rr_of(f3 color) { return fmaxf(max3(color), SPCBPT_MIN_RR_RATE); }  // getRR rmis.h:28-40 (q10)
+
+// getLast_pdf (rmis.h:41-51): pdf of stepping from v back to its predecessor given arrival from in_dir
+SPC_DEV float rmis_last_pdf(const Pbr& mat, const VCore& v, f3 in_dir) {
+    const f3 out_vec = v.lastPos - v.pos;
+    const f3 out_dir = normalize(out_vec);
+    float pdf = bsdf_pdf(mat, v.n, in_dir, out_dir) / dot(out_vec, out_vec) * v.lnp;
+    return pdf * rr_of(v.color);
+}
+// getFluxMultiplier (rmis.h:102-118)
+SPC_DEV f3 rmis_flux_multiplier(const Pbr& mat, const VCore& v, f3 in_dir, f3 out_dir) {
+    const f3 flux_ratio = bsdf_eval(mat, v.n, in_dir, out_dir);
+    const float pdf_ratio = bsdf_pdf(mat, v.n, in_dir, out_dir);
+    const float rr = rr_of(v.color);
+    const float cos_theta = fabsf(dot(v.n, out_dir));
+    return flux_ratio * cos_theta / pdf_ratio / rr;
+}
+// getPdf (rmis.h:153-172): pdf of generating `end` from `begin` given arrival from in_dir
+SPC_DEV float rmis_get_pdf(const Pbr& mat, const VCore& begin, f3 end_pos, f3 end_n, f3 in_dir) {
+    const f3 out_vec = end_pos - begin.pos;
+    const f3 out_dir = normalize(out_vec);
+    float pdf = bsdf_pdf(mat, begin.n, in_dir, out_dir) / dot(out_vec, out_vec) * fabsf(dot(out_dir, end_n));
+    return pdf * rr_of(begin.color);
+}
+// getPdf_from_light_source (rmis.h:173-188)
+SPC_DEV float rmis_pdf_from_light(f3 light_pos, f3 light_n, f3 end_pos, f3 end_n) {
+    const f3 conn_vec = end_pos - light_pos;
+    const f3 conn_dir = normalize(conn_vec);
+    const float pdf_angle = fabsf(dot(light_n, conn_dir)) * kInvPi;
+    const float angle2a = fabsf(dot(end_n, conn_dir)) / dot(conn_vec, conn_vec);
+    return pdf_angle * angle2a;
+}
+
+// Eye-side vertex kept in registers while walking (the live BDPTVertex fields of the eye sub-path)
+struct EyeVertex {
+    VCore c;
+    f3 flux, R3;       // flux, RMIS_pointer_3
+    float pdf, singlePdf;
+    int sub, lastZone, depth;
+};
+
+// tracing_weight_eye (rmis.h:131-151) with Last = `last`, Mid at `mid_pos`
+template <bool COUNT>
+SPC_DEV float rmis_weight_eye(const KParams& p, const VCore& last, int last_depth, int last_lastZone, f3 mid_pos, Counts<COUNT>& cn) {
+    if (last_depth == 1) return 0.0f;
+    const f3 inver_dir = normalize(mid_pos - last.pos);
+    const int light_label = tree_label(p.light_tree, last.pos, last.n, inver_dir, cn);
+    return gamma_ss(p, last_lastZone, light_label, cn) * (float)SPCBPT_CONNECTION_N;
+}
+// tracing_weight_light (rmis.h:58-79) with Last = light vertex `last`
+template <bool COUNT>
+SPC_DEV float rmis_weight_light(const KParams& p, const VCore& last, int last_lastZone, float last_lum, f3 mid_pos, Counts<COUNT>& cn) {
+    const f3 inver_dir = normalize(mid_pos - last.pos);
+    const int eye_label = tree_label(p.eye_tree, last.pos, last.n, inver_dir, cn);
+    return gamma_ss(p, eye_label, last_lastZone, cn) * last_lum * (float)SPCBPT_CONNECTION_N;
+}
+
+SPC_DEV VCore core_of(const LightVertex& b) {
+    VCore c;
+    c.pos = ld3(b.position); c.n = ld3(b.normal); c.color = ld3(b.color); c.lastPos = ld3(b.last_position);
+    c.lnp = b.last_normal_projection; c.mat = b.material_id;
+    return c;
+}
+
+// connectVertex_SPCBPT (raygen.cu:253-303) with rmis::general_connection / connection_lightSource
+// (rmis.h:212-247 / 281-313) fused: every BSDF lobe is fetched once.
+template <bool COUNT>
+SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn) {
+    const DeviceScene& S = p.scene;
+    const f3 bpos = ld3(b.position), bn = ld3(b.normal), bflux = ld3(b.flux);
+    const f3 connectVec = a.c.pos - bpos;
+    const f3 connectDir = normalize(connectVec);
+    const float r2 = dot(connectVec, connectVec);
+    const float G = fabsf(dot(a.c.n, connectDir)) * fabsf(dot(bn, connectDir)) / r2;
+    const f3 LA_DIR = normalize(a.c.lastPos - a.c.pos);
+    const Pbr mat_a = load_pbr_colored(S, a.c.mat, a.c.color);
+    const f3 fa = bsdf_eval(mat_a, a.c.n, -connectDir, LA_DIR);
+    const f3 lflux = bflux / b.pdf;  // `flux` of the rmis functions
+
+    // ---- eye side terms shared by both connection kinds
+    const float LL_pdf_A = rmis_last_pdf(mat_a, a.c, -connectDir);                 // getLL_pdf(light, eye)
+    const f3 fm0 = rmis_flux_multiplier(mat_a, a.c, -connectDir, LA_DIR);           // getFluxMultiplier(eye, -connect_dir)
+    const float wA = rmis_weight_eye(p, a.c, a.depth, a.lastZone, bpos, cn);        // tracing_weight_eye(light, eye)
+    const f3 D_A_0 = a.R3 * LL_pdf_A * fm0 + mk3(wA);
+    const float weight = sum3(gamma_ss(p, a.sub, b.subspace_id, cn) * lflux * (float)SPCBPT_CONNECTION_N);
+    const float pdf_B = rmis_get_pdf(mat_a, a.c, bpos, bn, LA_DIR);                 // getPdf(eye, light, LB)
+
+    f3 fb;
+    float D_A, D_B;
+    if (b.depth == 0) {  // connection_lightSource
+        fb = dot(bn, -connectDir) > 0.0f ? mk3(0.0f) : mk3(1.0f);
+        const float pdf_A = rmis_pdf_from_light(bpos, bn, a.c.pos, a.c.n);
+        D_A = sum3(D_A_0 * pdf_A * kPi * lflux / a.singlePdf);
+        D_B = b.rmis_pointer * pdf_B / b.single_pdf;
+    } else {  // general_connection
+        const VCore bc = core_of(b);
+        const Pbr mat_b = load_pbr_colored(S, bc.mat, bc.color);
+        const f3 LB_DIR = normalize(bc.lastPos - bc.pos);
+        fb = bsdf_eval(mat_b, bn, connectDir, LB_DIR);
+        const float pdf_A = rmis_get_pdf(mat_b, bc, a.c.pos, a.c.n, LB_DIR);        // getPdf(light, eye, LA)
+        const f3 fm1 = rmis_flux_multiplier(mat_b, bc, LB_DIR, connectDir);
+        D_A = sum3(D_A_0 * pdf_A * fm1 * lflux / a.singlePdf);
+        const float LL_pdf_B = rmis_last_pdf(mat_b, bc, connectDir);               // getLL_pdf(eye, light)
+        const float wB = rmis_weight_light(p, bc, b.last_zone_id, b.last_lum, a.c.pos, cn);
+        D_B = (b.rmis_pointer * LL_pdf_B + wB) * pdf_B / b.single_pdf;
+    }
+    const float w_rmis = weight / (weight + D_A + D_B);
+    const f3 contri = a.flux * bflux * fa * fb * G;
+    const f3 ans = contri / (a.pdf * b.pdf) * w_rmis;
+    return ans;
+}
+
+SPC_DEV bool is_invalid(f3 a) {  // ISINVALIDVALUE raygen.cu:43
+    return a.x > 100000.0f || isnan(a.x) || a.y > 100000.0f || isnan(a.y) || a.z > 100000.0f || isnan(a.z);
+}
+
+// ---- light sampling (cuProg.h:554-666, QUAD) ------------------------------------
+struct LightSampleD { f3 position, emission, normal; float pdf; int subspace; };
+SPC_DEV LightSampleD light_reverse_sample(const DeviceScene& S, const DLight& L, float r1, float r2) {
+    LightSampleD s;
+    const float r3 = 1 - r1 - r2;
+    s.position = ld3(L.u) * r1 + ld3(L.v) * r2 + ld3(L.corner) * r3;
+    s.emission = ld3(L.emission);
+    s.normal = ld3(L.normal);
+    s.pdf = (1.0f / L.area) / (float)S.n_lights;
+    const int xb = min(max((int)floorf(r1 * L.div_level), 0), L.div_level - 1);
+    const int yb = min(max((int)floorf(r2 * L.div_level), 0), L.div_level - 1);
+    s.subspace = SPCBPT_NUM_SUBSPACE - (L.ss_base + xb * L.div_level + yb) - 1;
+    return s;
+}
+SPC_DEV int pick_light(const DeviceScene& S, uint32_t& seed) {
+    return min(max((int)floorf(rnd(seed) * S.n_lights), 0), S.n_lights - 1);
+}
+
+// ---- film (raygen.cu:45-68, 430-442; ../cuda/helpers.h:35-67) ------------------------
+SPC_DEV float to_srgb(float c) {
+    return c < 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+}
+SPC_DEV uint32_t quant8(float x) {
+    x = clampf(x, 0.0f, 1.0f);
+    return min((uint32_t)(x * 256.0f), 255u);
+}
+SPC_DEV void film_write(const KParams& p, uint32_t x, uint32_t y, f3 result) {
+    const size_t idx = (size_t)y * p.width + x;
+    float4* acc = reinterpret_cast<float4*>(p.accum);
+    f3 c = result;
+    if (p.subframe > 0) {
+        const float a = 1.0f / (float)(p.subframe + 1);
+        const float4 prev = acc[idx];
+        c = lerp3(mk3(prev.x, prev.y, prev.z), c, a);
+    }
+    acc[idx] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (p.frame) {
+        const float lum = 0.3f * c.x + 0.6f * c.y + 0.1f * c.z;
+        const float s = 1.0f / (1.0f + lum / 1.5f);
+        const f3 t = c * s;
+        p.frame[idx] = quant8(to_srgb(clampf(t.x, 0.f, 1.f))) | (quant8(to_srgb(clampf(t.y, 0.f, 1.f))) << 8) |
+                       (quant8(to_srgb(clampf(t.z, 0.f, 1.f))) << 16) | (255u << 24);
+    }
+}
+SPC_DEV f3 camera_ray(const KParams& p, uint32_t x, uint32_t y, uint32_t& seed) {  // raygen.cu:332-343
+    seed = tea4(y * p.width + x, p.subframe);
+    float jx = 0.5f, jy = 0.5f;
+    if (p.subframe != 0) { jx = rnd(seed); jy = rnd(seed); }
+    const float dx = 2.0f * (((float)x + jx) / (float)p.width) - 1.0f;
+    const float dy = 2.0f * (((float)y + jy) / (float)p.height) - 1.0f;
+    return normalize(dx * ld3(p.U) + dy * ld3(p.V) + ld3(p.W));
+}
+
+}  // namespace spc

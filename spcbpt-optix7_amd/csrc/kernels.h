@@ -1,0 +1,25 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "layout.h"
+
+namespace spc {
+
+int render_thread_count(const KParams& p);
+void launch_spcbpt(const KParams& p, bool count, hipStream_t s);
+void launch_pt(const KParams& p, bool count, hipStream_t s);
+void launch_light_trace(const KParams& p, bool count, hipStream_t s);
+void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
+                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
+void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
+void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s);
+void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s);
+void launch_cmf(const double* prefix, const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, float* cmfs, int capacity, hipStream_t s);
+void launch_trace_closest(const KParams& p, const float* rays, int n, float* t, int* tri, float* uv, hipStream_t s);
+void launch_trace_any(const KParams& p, const float* rays, int n, int* vis, hipStream_t s);
+
+static const int kStackLds = 24;  // must match STACK_LDS in kernels.hip
+
+}  // namespace spc

@@ -1,0 +1,607 @@
+// HIP kernels of the SPCBPT hot path for gfx950 (wave64).  One lane = one pixel-sample (eye pass) or one
+// light-trace core (light pass); a wave covers an 8x8 pixel tile so primary rays stay coherent.
+//   k_spcbpt      <- __raygen__SPCBPT + __closesthit__eyeSubpath(+_LightSource) + __miss__BDPTVertex +
+//                    __closesthit__occlusion (raygen.cu:319-443, hit_program.cu:58-147, 246-340)  [megakernel]
+//   k_light_trace <- __raygen__lightTrace + __closesthit__lightSubpath (raygen.cu:620-685, hit_program.cu:341-438)
+//   k_pt          <- __raygen__pinhole + __closesthit__radiance/lightsource (raygen.cu:71-170, hit_program.cu:148-180, 439-552)
+//   sampler build <- MyThrustOp::LVC_Process (cuda_thrust/device_thrust.cu:241-332), on device
+#include <hip/hip_runtime.h>
+
+#include "device_lib.h"
+#include "kernels.h"
+
+namespace spc {
+
+static constexpr int BLOCK = 256;
+static constexpr int STACK_LDS = 24;  // 24 KB of LDS per block; deeper entries spill (TravStack)
+
+// pixel of this lane: 8x8 tile per wave, 4 tiles (in x) per block, bands of 8 rows selected by (row_begin, row_step)
+SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
+    const uint32_t tiles_x = (p.width + 7) / 8;
+    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const uint32_t tile_x = wave % tiles_x, band_k = wave / tiles_x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t band = (uint32_t)(p.row_begin / 8) + band_k * (uint32_t)p.row_step;
+    x = tile_x * 8 + (lane & 7);
+    y = band * 8 + (lane >> 3);
+    return x < p.width && y < p.height && (int)y < p.row_end && (int)y >= p.row_begin;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Eye-walk step shared by k_spcbpt and the pretrace kernel: build the vertex at a surface hit
+// (hit_program.cu:246-340).  `last` is the previous vertex (camera when last.depth == 0).
+struct WalkState {
+    f3 origin, dir;        // next ray
+    f3 next_flux;          // NextVertex.flux  = BSDF value of the sampled direction
+    float next_single_pdf; // NextVertex.singlePdf = solid-angle pdf (x RR once survived)
+    uint32_t seed;
+    bool done;
+};
+
+template <bool COUNT>
+SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
+                             WalkState& w, EyeVertex& mid, Counts<COUNT>& cn) {
+    const DeviceScene& S = p.scene;
+    Pbr pbr = load_pbr(S, g.mat);
+    color_tex_sample(S, g, pbr, cn);
+    f3 N = g.N;
+    if (dot(N, ray_dir) > 0.f) N = -N;
+    const f3 inv_dir = -ray_dir;
+    const f3 new_dir = bsdf_sample(pbr, N, inv_dir, w.seed);
+    const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
+    if (!(pdf > 0.0f)) w.done = true;
+
+    mid.c.pos = g.P;
+    mid.c.n = N;
+    const float pdf_G = fabsf(dot(N, ray_dir) * dot(last.c.n, ray_dir)) / (t_hit * t_hit);
+    mid.flux = last_is_origin ? last.flux * pdf_G : w.next_flux * last.flux * pdf_G;
+    mid.c.lastPos = last.c.pos;
+    mid.c.color = pbr.base;
+    mid.c.lnp = fabsf(dot(last.c.n, ray_dir));
+    mid.c.mat = g.mat;
+    mid.sub = tree_label(p.eye_tree, g.P, N, inv_dir, cn);
+    mid.lastZone = last.sub;
+    mid.depth = last.depth + 1;
+    mid.singlePdf = w.next_single_pdf * pdf_G / fabsf(dot(last.c.n, ray_dir));
+    mid.pdf = last.pdf * mid.singlePdf;
+    // recursive MIS (rmis.h:189-207)
+    if (mid.depth == 1) {
+        mid.R3 = mk3(0.0f);
+    } else {
+        const Pbr mat_last = load_pbr_colored(S, last.c.mat, last.c.color);
+        const f3 in_dir = normalize(mid.c.pos - last.c.pos);
+        const float LL_pdf = rmis_last_pdf(mat_last, last.c, in_dir);
+        const float wgt = rmis_weight_eye(p, last.c, last.depth, last.lastZone, mid.c.pos, cn);
+        const f3 fm = rmis_flux_multiplier(mat_last, last.c, in_dir, normalize(last.c.lastPos - last.c.pos));
+        mid.R3 = (last.R3 * LL_pdf * fm + mk3(wgt)) / last.singlePdf;
+    }
+    cn.add(C_VERTEX);
+    // next segment + Russian roulette (the vertex itself is kept; hit_program.cu:324-337)
+    w.next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
+    w.next_single_pdf = pdf;
+    w.origin = g.P;
+    w.dir = new_dir;
+    const float r = rnd(w.seed);
+    const float rr = rr_of(mid.c.color);
+    if (r > rr) w.done = true;
+    else w.next_single_pdf *= rr;
+}
+
+// __closesthit__eyeSubpath_LightSource + rmis::light_hit + lightStraghtHit (hit_program.cu:62-147, rmis.h:359-389,
+// raygen.cu:305-317): contribution of an eye path that runs into an emitter.
+template <bool COUNT>
+SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
+                           const WalkState& w, Counts<COUNT>& cn) {
+    const DeviceScene& S = p.scene;
+    const int light_id = load_pbr(S, g.mat).light_id;
+    const DLight& L = S.lights[light_id];
+    const f3 ln = ld3(L.normal);
+    if (dot(ray_dir, ln) > 0) return mk3(0.0f);
+    const LightSampleD ls = light_reverse_sample(S, L, g.u, g.v);
+    const float pdf_G = fabsf(dot(ln, ray_dir) * dot(last.c.n, ray_dir)) / (t_hit * t_hit);
+    const f3 flux = last_is_origin ? last.flux * pdf_G * ls.emission : w.next_flux * last.flux * pdf_G * ls.emission;
+    const float singlePdf = w.next_single_pdf * pdf_G / fabsf(dot(last.c.n, ray_dir));
+    const float pdf = last.pdf * singlePdf;
+    float rmis_pointer = 1.0f;
+    if (last.depth + 1 != 1) {
+        // light_hit(eye = last, light = virtual vertex at the hit point)
+        const f3 lpos = g.P;
+        const f3 connect_dir = normalize(last.c.pos - lpos);
+        const f3 lflux = ls.emission / ls.pdf;
+        const Pbr mat_e = load_pbr_colored(S, last.c.mat, last.c.color);
+        const f3 LB = normalize(last.c.lastPos - last.c.pos);
+        const float LL_pdf_A = rmis_last_pdf(mat_e, last.c, -connect_dir);
+        const f3 fm0 = rmis_flux_multiplier(mat_e, last.c, -connect_dir, LB);
+        const float wA = rmis_weight_eye(p, last.c, last.depth, last.lastZone, lpos, cn);
+        const f3 D_A_0 = last.R3 * LL_pdf_A * fm0 + mk3(wA);
+        const float pdf_A = rmis_pdf_from_light(lpos, ln, last.c.pos, last.c.n);
+        const float D_A = sum3(D_A_0 * pdf_A * kPi * lflux / last.singlePdf);
+        const float weight = sum3(gamma_ss(p, last.sub, ls.subspace, cn) * lflux * (float)SPCBPT_CONNECTION_N);
+        const float D_B = 1.0f;
+        const float pdf_B = rmis_get_pdf(mat_e, last.c, lpos, ln, LB);
+        const float lh = D_B / ((weight + D_A) / pdf_B * ls.pdf + D_B);
+        rmis_pointer = 1.0f / lh;
+    }
+    const f3 ans = flux / pdf / rmis_pointer;
+    return is_invalid(ans) ? mk3(0.0f) : ans;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_spcbpt(const KParams p) {
+    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    uint32_t x, y;
+    const bool active = lane_pixel(p, x, y);
+    Counts<COUNT> cn;
+    cn.clear();
+    if (active) {
+        const DeviceScene& S = p.scene;
+        TravStack<BLOCK, STACK_LDS> st;
+        st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
+        WalkState w;
+        w.dir = camera_ray(p, x, y, w.seed);
+        w.origin = ld3(p.eye);
+        w.done = false;
+        w.next_flux = mk3(0.0f);
+        w.next_single_pdf = 1.0f;
+        // init_EyeSubpath (raygen.cu:216-231)
+        EyeVertex cur;
+        cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
+        cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0;
+        f3 result = mk3(0.0f);
+        const int path_count = p.sampler_counts[1];
+        cn.add(C_PIX); cn.add(C_EYE);
+        int depth = 0;
+        while (true) {
+            if (w.done || depth > 50) break;
+            HitRec h;
+            cn.add(C_CLOSEST);
+            if (!traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn)) break;  // __miss__BDPTVertex
+            const Geom g = local_geometry(S, h);
+            const bool last_is_origin = cur.depth == 0;
+            const f3 ray_dir = w.dir;
+            depth += 1;
+            if (g.emitter) {
+                result += eye_emitter_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
+                break;
+            }
+            EyeVertex mid;
+            eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
+            cur = mid;
+            // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419)
+            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                float pmf1, pmf2;
+                const int l = binary_sample(p.cmf_gamma + (size_t)cur.sub * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, w.seed, pmf1, cn);
+                const DSubspace ss = p.subspace[l];
+                if (ss.size == 0) continue;
+                const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
+                const int slot = p.jump[ss.jump_bias + k];
+                const float4* src = reinterpret_cast<const float4*>(p.lvc + slot);
+                LightVertex b;
+                float4* dst = reinterpret_cast<float4*>(&b);
+#pragma unroll
+                for (int q = 0; q < 6; q++) dst[q] = src[q];
+                cn.add(C_CONN);
+                // visibilityTest (cuProg.h:463-487)
+                const f3 bias = ld3(b.position) - cur.c.pos;
+                const float len = sqrtf(dot(bias, bias));
+                const f3 sdir = bias / len;
+                HitRec sh;
+                cn.add(C_SHADOW);
+                if (!traverse<true, COUNT>(S, st, cur.c.pos, sdir, kEps, len - kEps, sh, cn)) {
+                    const float pmf = (float)path_count * pmf2 * pmf1;
+                    f3 res = connect_vertices(p, cur, b, cn);
+                    if (is_invalid(res)) res = mk3(0.0f);
+                    res = res / pmf;
+                    if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+                }
+            }
+        }
+        film_write(p, x, y, result);
+    }
+    cn.flush(p.counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_pt(const KParams p) {
+    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    uint32_t x, y;
+    const bool active = lane_pixel(p, x, y);
+    Counts<COUNT> cn;
+    cn.clear();
+    if (active) {
+        const DeviceScene& S = p.scene;
+        TravStack<BLOCK, STACK_LDS> st;
+        st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
+        uint32_t seed;
+        f3 dir = camera_ray(p, x, y, seed);
+        f3 origin = ld3(p.eye);
+        f3 throughput = mk3(1.0f), result = mk3(0.0f);
+        float prd_pdf = 0.0f;
+        int depth = 0;
+        bool done = false;
+        cn.add(C_PIX); cn.add(C_EYE);
+        while (true) {
+            HitRec h;
+            cn.add(C_CLOSEST);
+            f3 current = mk3(0.0f), visA = mk3(0.0f), visB = mk3(0.0f);
+            if (!traverse<false, COUNT>(S, st, origin, dir, kEps, 1e16f, h, cn)) {
+                done = true;  // __miss__constant_radiance, no env map
+            } else {
+                const Geom g = local_geometry(S, h);
+                Pbr pbr = load_pbr(S, g.mat);
+                if (g.emitter) {  // __closesthit__lightsource
+                    const DLight& L = S.lights[pbr.light_id];
+                    const LightSampleD ls = light_reverse_sample(S, L, g.u, g.v);
+                    if (dot(dir, ls.normal) <= 0) {
+                        float mis = 1.0f;
+                        if (depth != 0) {
+                            const float pdf_hit = prd_pdf * fabsf(dot(dir, ls.normal)) / (h.t * h.t);
+                            mis = pdf_hit / (ls.pdf + pdf_hit);
+                        }
+                        result += throughput * ls.emission * mis;
+                    }
+                    done = true;
+                } else {  // __closesthit__radiance
+                    color_tex_sample(S, g, pbr, cn);
+                    f3 N = g.N;
+                    if (dot(N, dir) > 0.f) N = -N;
+                    const f3 in_dir = -dir;
+                    const float rr = clampf(max3(pbr.base), SPCBPT_MIN_RR_RATE, 1.0f);
+                    const int lid = pick_light(S, seed);
+                    const DLight& L = S.lights[lid];
+                    {
+                        const float r1 = rnd(seed), r2 = rnd(seed);
+                        const LightSampleD ls = light_reverse_sample(S, L, r1, r2);
+                        const f3 dvec = ls.position - g.P;
+                        const float L_dist = sqrtf(dot(dvec, dvec));
+                        const f3 Ld = dvec / L_dist;
+                        const f3 V = -normalize(dir);
+                        const float L_dot_LN = dot(-Ld, ls.normal);
+                        const float N_dot_L = dot(N, Ld), N_dot_V = dot(N, V);
+                        if (N_dot_L > 0.0f && N_dot_V > 0.0f && L_dot_LN > 0.0f) {
+                            visA = g.P; visB = ls.position;
+                            const f3 eval = bsdf_eval(pbr, N, V, Ld);
+                            const float pdf_hit = bsdf_pdf(pbr, N, V, Ld) * fabsf(L_dot_LN) / (L_dist * L_dist) * rr;
+                            const float mis = ls.pdf / (pdf_hit + ls.pdf);
+                            current = throughput * ls.emission * 1.0f / ls.pdf * N_dot_L * L_dot_LN / L_dist / L_dist * eval * mis;
+                        }
+                    }
+                    origin = g.P;
+                    cn.add(C_VERTEX);
+                    if (rnd(seed) > rr) {
+                        done = true;
+                    } else {
+                        dir = bsdf_sample(pbr, N, in_dir, seed);
+                        const float pdf = bsdf_pdf(pbr, N, in_dir, dir);
+                        if (pdf > 0.0f) {
+                            throughput *= bsdf_eval(pbr, N, in_dir, dir) * fabsf(dot(dir, N)) / pdf / rr;
+                            prd_pdf = pdf * rr;
+                        } else {
+                            done = true;
+                        }
+                    }
+                }
+            }
+            if (sum3(current) > 0.0f) {  // the shadow ray is shot by raygen (raygen.cu:134-143)
+                const f3 bias = visB - visA;
+                const float len = sqrtf(dot(bias, bias));
+                HitRec sh;
+                cn.add(C_SHADOW);
+                if (!traverse<true, COUNT>(S, st, visA, bias / len, kEps, len - kEps, sh, cn)) result += current;
+            }
+            if (done || depth > 30) break;
+            depth += 1;
+        }
+        film_write(p, x, y, result);
+    }
+    cn.flush(p.counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Light pass: one core per lane, each core walks m_per_core light paths and fills its own padded slot range, exactly the
+// launch geometry of LightTraceParams; the MI355X default is num_core = M, m_per_core = 1 (one path per lane).
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_light_trace(const KParams p) {
+    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    const int local_core = blockIdx.x * BLOCK + threadIdx.x;
+    Counts<COUNT> cn;
+    cn.clear();
+    if (local_core < p.core_count) {
+        const DeviceScene& S = p.scene;
+        const int core = p.core_begin + local_core;
+        TravStack<BLOCK, STACK_LDS> st;
+        st.init(s_stack, p.spill, p.spill_entries, (size_t)local_core);
+        uint32_t seed = tea4((uint32_t)core, p.launch_frame);  // light sampling stream
+        uint32_t pseed = seed;                                  // payload.seed: BSDF stream
+        LightVertex* slots = p.lvc_scratch + (size_t)local_core * p.core_padding;
+        int nverts = 0, npaths = 0;
+        auto store = [&](const LightVertex& v) {
+            float4* dst = reinterpret_cast<float4*>(slots + nverts);
+            const float4* src = reinterpret_cast<const float4*>(&v);
+#pragma unroll
+            for (int q = 0; q < 6; q++) dst[q] = src[q];
+            nverts++;
+            cn.add(C_LVCW);
+        };
+        while (true) {
+            const int lid = pick_light(S, seed);
+            const DLight& L = S.lights[lid];
+            const float r1 = rnd(seed), r2 = rnd(seed);
+            const LightSampleD ls = light_reverse_sample(S, L, r1, r2);
+            const float d1 = rnd(seed), d2 = rnd(seed);  // traceMode
+            const Onb onb(ls.normal);
+            f3 dir = onb.to_world(cosine_sample_hemisphere(d1, d2));
+            const float dir_pdf = fabsf(dot(dir, ls.normal)) * kInvPi;
+            f3 origin = ls.position;
+            const uint32_t path_id = (uint32_t)core * (uint32_t)p.m_per_core + (uint32_t)npaths;
+            cn.add(C_LIGHT);
+            // origin vertex (init_vertex_from_lightSample raygen.cu:172-195)
+            LightVertex v;
+            v.position[0] = ls.position.x; v.position[1] = ls.position.y; v.position[2] = ls.position.z; v.pdf = ls.pdf;
+            v.normal[0] = ls.normal.x; v.normal[1] = ls.normal.y; v.normal[2] = ls.normal.z; v.single_pdf = ls.pdf;
+            v.flux[0] = ls.emission.x; v.flux[1] = ls.emission.y; v.flux[2] = ls.emission.z; v.rmis_pointer = 1.0f;
+            v.color[0] = v.color[1] = v.color[2] = 0.0f; v.last_lum = 0.0f;
+            v.last_position[0] = v.last_position[1] = v.last_position[2] = 0.0f; v.last_normal_projection = 0.0f;
+            v.material_id = (int16_t)L.id; v.subspace_id = (int16_t)ls.subspace; v.depth = 0; v.last_zone_id = 0;
+            v.path_id = path_id; v.pad = 0;
+            store(v);
+            if (!(nverts < p.core_padding)) break;
+            // walk (hit_program.cu:341-438)
+            f3 next_flux = mk3(0.0f);
+            float next_single_pdf = dir_pdf;
+            bool done = false, full = false;
+            int depth = 0;
+            LightVertex last = v;
+            while (true) {
+                HitRec h;
+                cn.add(C_CLOSEST);
+                if (!traverse<false, COUNT>(S, st, origin, dir, kEps, 1e16f, h, cn)) { done = true; }
+                else {
+                    const Geom g = local_geometry(S, h);
+                    if (g.emitter) { done = true; }  // __closesthit__lightSource_subpath
+                    else {
+                        Pbr pbr = load_pbr(S, g.mat);
+                        color_tex_sample(S, g, pbr, cn);
+                        f3 N = g.N;
+                        if (dot(N, dir) > 0.f) N = -N;
+                        const f3 inv_dir = -dir;
+                        const f3 new_dir = bsdf_sample(pbr, N, inv_dir, pseed);
+                        const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
+                        if (!(pdf > 0.0f)) done = true;
+                        const f3 last_n = ld3(last.normal), last_flux = ld3(last.flux);
+                        const float pdf_G = fabsf(dot(N, dir) * dot(last_n, dir)) / (h.t * h.t);
+                        const f3 flux = last.depth == 0 ? last_flux * pdf_G : next_flux * last_flux * pdf_G;
+                        LightVertex m;
+                        m.position[0] = g.P.x; m.position[1] = g.P.y; m.position[2] = g.P.z;
+                        m.normal[0] = N.x; m.normal[1] = N.y; m.normal[2] = N.z;
+                        m.flux[0] = flux.x; m.flux[1] = flux.y; m.flux[2] = flux.z;
+                        m.color[0] = pbr.base.x; m.color[1] = pbr.base.y; m.color[2] = pbr.base.z;
+                        m.last_position[0] = last.position[0]; m.last_position[1] = last.position[1]; m.last_position[2] = last.position[2];
+                        m.last_normal_projection = fabsf(dot(last_n, dir));
+                        m.material_id = (int16_t)g.mat;
+                        m.subspace_id = (int16_t)tree_label(p.light_tree, g.P, N, inv_dir, cn);
+                        m.last_zone_id = last.subspace_id;
+                        m.depth = (int16_t)(last.depth + 1);
+                        m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
+                        m.pdf = last.pdf * m.single_pdf;
+                        m.last_lum = sum3(last_flux / last.pdf);
+                        m.path_id = path_id; m.pad = 0;
+                        if (last.depth == 0) {
+                            m.rmis_pointer = last.rmis_pointer / last.single_pdf;  // tracing_init_light
+                        } else {  // tracing_update_light (rmis.h:80-94)
+                            const VCore lc = core_of(last);
+                            const Pbr mat_last = load_pbr_colored(S, lc.mat, lc.color);
+                            const f3 in_dir = normalize(g.P - lc.pos);
+                            const float LL_pdf = rmis_last_pdf(mat_last, lc, in_dir);
+                            const float wgt = rmis_weight_light(p, lc, last.last_zone_id, last.last_lum, g.P, cn);
+                            m.rmis_pointer = (last.rmis_pointer * LL_pdf + wgt) / last.single_pdf;
+                        }
+                        cn.add(C_VERTEX);
+                        next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
+                        next_single_pdf = pdf;
+                        origin = g.P;
+                        dir = new_dir;
+                        const float r = rnd(pseed);
+                        const float rr = rr_of(pbr.base);
+                        if (r > rr) done = true;
+                        else next_single_pdf *= rr;
+                        store(m);
+                        last = m;
+                        if (!(nverts < p.core_padding)) { full = true; break; }
+                    }
+                }
+                if (done || depth > 50) break;
+                depth += 1;
+            }
+            if (full) break;
+            npaths++;
+            if (npaths >= p.m_per_core) break;
+            if (!(nverts < p.core_padding)) break;
+        }
+        p.core_counts[local_core] = nverts;
+    }
+    cn.flush(p.counters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampler build on device (LVC_Process).  Input: padded scratch + per-core counts.  Steps:
+//   1. exclusive scan of core_counts (hipcub)                       -> core_offsets, vertex_count
+//   2. k_lvc_compact: copy to the compact LVC in (core, slot) order, emit key = subspace id, weight, path starts
+//   3. stable radix sort of (subspace id -> compact index) (hipcub)  -> jump_buffer
+//   4. k_subspace_ranges: first/last position of each subspace in the sorted keys -> jump_bias, size
+//   5. inclusive scan (double) of the weights in sorted order (hipcub), k_cmf: per-subspace normalised CMF
+__global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int* __restrict__ core_counts,
+                              const int* __restrict__ core_offsets, int core_count, int core_padding, LightVertex* __restrict__ lvc,
+                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float* __restrict__ weights,
+                              int* __restrict__ sampler_counts) {
+    // one wave per core: 64 lanes copy the core's vertices as 16-B quads
+    const int core = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+    if (core >= core_count) return;
+    const int lane = threadIdx.x & 63;
+    const int n = core_counts[core], off = core_offsets[core];
+    const float4* src = reinterpret_cast<const float4*>(scratch + (size_t)core * core_padding);
+    float4* dst = reinterpret_cast<float4*>(lvc + off);
+    for (int q = lane; q < n * 6; q += 64) dst[q] = src[q];
+    int path_starts = 0;
+    for (int i = lane; i < n; i += 64) {
+        const LightVertex& v = scratch[(size_t)core * core_padding + i];
+        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;  // LVCSubspaceInfoCopy device_thrust.cu:191-212
+        if (isinf(w) || isnan(w)) w = 0.0f;
+        keys[off + i] = (uint32_t)v.subspace_id;
+        vals[off + i] = (uint32_t)(off + i);
+        weights[off + i] = w;
+        path_starts += v.depth == 0 ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) path_starts += __shfl_down(path_starts, o, 64);
+    if (lane == 0 && path_starts) atomicAdd(&sampler_counts[1], path_starts);
+}
+
+__global__ void k_fill_keys_from_lvc(const LightVertex* __restrict__ lvc, int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                     float* __restrict__ weights, int* __restrict__ sampler_counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int start = 0;
+    if (i < n) {
+        const LightVertex& v = lvc[i];
+        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;
+        if (isinf(w) || isnan(w)) w = 0.0f;
+        keys[i] = (uint32_t)v.subspace_id;
+        vals[i] = (uint32_t)i;
+        weights[i] = w;
+        start = v.depth == 0 ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) start += __shfl_down(start, o, 64);
+    if ((threadIdx.x & 63) == 0 && start) atomicAdd(&sampler_counts[1], start);
+}
+
+__global__ void k_subspace_ranges(const uint32_t* __restrict__ sorted_keys, const int* __restrict__ sampler_counts, DSubspace* __restrict__ sub) {
+    const int n = sampler_counts[0];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = sorted_keys[i];
+    if (i == 0 || sorted_keys[i - 1] != k) sub[k].jump_bias = i;
+    if (i == n - 1 || sorted_keys[i + 1] != k) sub[k].size = i + 1;  // temporarily the END position; fixed in k_finish_ranges
+}
+__global__ void k_finish_ranges(DSubspace* __restrict__ sub) {
+    // empty subspaces: size 0, jump_bias = running offset like the reference (device_thrust.cu:301-309)
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int bias = 0;
+        for (int s = 0; s < SPCBPT_NUM_SUBSPACE; s++) {
+            if (sub[s].size > 0) { const int end = sub[s].size; sub[s].size = end - sub[s].jump_bias; bias = end; }
+            else { sub[s].jump_bias = bias; sub[s].size = 0; }
+        }
+    }
+}
+__global__ void k_gather_weights(const float* __restrict__ weights, const uint32_t* __restrict__ sorted_vals, const int* __restrict__ sampler_counts,
+                                 double* __restrict__ out) {
+    const int n = sampler_counts[0];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)weights[sorted_vals[i]];
+}
+__global__ void k_cmf(const double* __restrict__ prefix, const uint32_t* __restrict__ sorted_keys, const int* __restrict__ sampler_counts,
+                      DSubspace* __restrict__ sub, float* __restrict__ cmfs) {
+    const int n = sampler_counts[0];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = sorted_keys[i];
+    const int b = sub[k].jump_bias, e = b + sub[k].size;
+    const double base = b > 0 ? prefix[b - 1] : 0.0;
+    const double total = prefix[e - 1] - base;
+    const bool last = i == e - 1;
+    // sum_pmf == 0 gives NaN CMFs in the reference; guarded here: zero-weight subspaces sample uniformly
+    float c = total > 0.0 ? (float)((prefix[i] - base) / total) : (float)(i - b + 1) / (float)(e - b);
+    if (last) { c = 1.0f; sub[k].sum_pmf = (float)total; }
+    cmfs[i] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Standalone traversal kernels (parity of the software LBVH against the oracle's BVH)
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(const KParams p, const float* __restrict__ rays, int n, float* __restrict__ out_t,
+                                                        int* __restrict__ out_tri, float* __restrict__ out_uv) {
+    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    TravStack<BLOCK, STACK_LDS> st;
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)i);
+    const float* r = rays + (size_t)i * 8;
+    Counts<false> cn;
+    HitRec h;
+    traverse<false, false>(p.scene, st, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], h, cn);
+    out_t[i] = h.t;
+    out_tri[i] = h.tri >= 0 ? p.scene.tri_orig[h.tri] : -1;
+    out_uv[2 * i] = h.u; out_uv[2 * i + 1] = h.v;
+}
+__global__ __launch_bounds__(BLOCK) void k_trace_any(const KParams p, const float* __restrict__ rays, int n, int* __restrict__ out_visible) {
+    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    TravStack<BLOCK, STACK_LDS> st;
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)i);
+    const float* r = rays + (size_t)i * 8;
+    Counts<false> cn;
+    HitRec h;
+    out_visible[i] = traverse<true, false>(p.scene, st, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], h, cn) ? 0 : 1;
+}
+
+// ---- host-callable launchers ---------------------------------------------------------------------
+static inline int render_blocks(const KParams& p) {
+    const int tiles_x = ((int)p.width + 7) / 8;
+    const int band_begin = p.row_begin / 8;
+    const int band_end = (std::min(p.row_end, (int)p.height) + 7) / 8;
+    const int step = p.row_step < 1 ? 1 : p.row_step;
+    const int nb = band_end > band_begin ? (band_end - band_begin + step - 1) / step : 0;
+    const int waves = tiles_x * nb;
+    return (waves + (BLOCK / 64) - 1) / (BLOCK / 64);
+}
+int render_thread_count(const KParams& p) { return render_blocks(p) * BLOCK; }
+
+void launch_spcbpt(const KParams& p, bool count, hipStream_t s) {
+    const int blocks = render_blocks(p);
+    if (blocks <= 0) return;
+    if (count) hipLaunchKernelGGL(k_spcbpt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL(k_spcbpt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
+}
+void launch_pt(const KParams& p, bool count, hipStream_t s) {
+    const int blocks = render_blocks(p);
+    if (blocks <= 0) return;
+    if (count) hipLaunchKernelGGL(k_pt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL(k_pt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
+}
+void launch_light_trace(const KParams& p, bool count, hipStream_t s) {
+    const int blocks = (p.core_count + BLOCK - 1) / BLOCK;
+    if (blocks <= 0) return;
+    if (count) hipLaunchKernelGGL(k_light_trace<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL(k_light_trace<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
+}
+void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
+                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
+    const int waves_per_block = 4;
+    const int blocks = (core_count + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL(k_lvc_compact, dim3(blocks), dim3(64 * waves_per_block), 0, s, scratch, core_counts, core_offsets, core_count,
+                       core_padding, lvc, keys, vals, weights, sampler_counts);
+}
+void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fill_keys_from_lvc, dim3((n + 255) / 256), dim3(256), 0, s, lvc, n, keys, vals, weights, sampler_counts);
+}
+void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s) {
+    hipLaunchKernelGGL(k_subspace_ranges, dim3((capacity + 255) / 256), dim3(256), 0, s, sorted_keys, sampler_counts, sub);
+    hipLaunchKernelGGL(k_finish_ranges, dim3(1), dim3(64), 0, s, sub);
+}
+void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_weights, dim3((capacity + 255) / 256), dim3(256), 0, s, weights, sorted_vals, sampler_counts, out);
+}
+void launch_cmf(const double* prefix, const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, float* cmfs, int capacity, hipStream_t s) {
+    hipLaunchKernelGGL(k_cmf, dim3((capacity + 255) / 256), dim3(256), 0, s, prefix, sorted_keys, sampler_counts, sub, cmfs);
+}
+void launch_trace_closest(const KParams& p, const float* rays, int n, float* t, int* tri, float* uv, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_trace_closest, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p, rays, n, t, tri, uv);
+}
+void launch_trace_any(const KParams& p, const float* rays, int n, int* vis, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_trace_any, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p, rays, n, vis);
+}
+
+}  // namespace spc

@@ -1,0 +1,109 @@
+// Device/host shared data layout of the MI355X SPCBPT hot path (HBM-resident).
+// All records are 16-byte aligned so every lane fetch is a global_load_dwordx4.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/spcbpt.h"
+
+namespace spc {
+
+// ---- software LBVH ---------------------------------------------------------
+// One node = 64 B = 4 x float4, both child boxes inline (a visit is ONE 64-B fetch):
+//   q0 = (lo0.xyz, as_float(child0))   q1 = (hi0.xyz, as_float(child1))
+//   q2 = (lo1.xyz, as_float(count0))   q3 = (hi1.xyz, as_float(count1))
+// child >= 0: internal node index.  child < 0: leaf, first triangle = ~child,
+// count in the matching q2/q3 slot (1..LEAF_MAX).
+static const int LEAF_MAX = 4;
+static const int NODE_QUADS = 4;
+
+// One triangle = 64 B = 4 x float4 in BVH order; the intersection test reads the
+// first three quads (48 B), hit shading reads all four:
+//   t0 = (P0.xyz, uv0.x)  t1 = (P1.xyz, uv0.y)  t2 = (P2.xyz, uv1.x)
+//   t3 = (uv1.y, uv2.x, uv2.y, as_float(material | emitter << 31))
+static const int TRI_QUADS = 4;
+
+struct DMaterial {  // 64 B; MaterialData::Pbr values (cuda/MaterialData.h:82-100)
+    float base_color[3];
+    float metallic;
+    float roughness, specular, specular_tint, subsurface;
+    float sheen, sheen_tint, clearcoat, clearcoat_gloss;
+    int32_t albedo_tex;  // 0 none, else texture index + 1
+    int32_t light_id;    // >= 0 for the emissive pseudo-materials (scene_shift.cpp:92-103)
+    int32_t pad[2];
+};
+static_assert(sizeof(DMaterial) == 64, "DMaterial");
+
+struct DLight {  // 80 B; Light::QUAD (cuda/Light.h:65-84); u, v are absolute corner points
+    float corner[3]; float area;
+    float u[3]; int32_t div_level;
+    float v[3]; int32_t ss_base;
+    float emission[3]; int32_t id;
+    float normal[3]; int32_t pad;
+};
+static_assert(sizeof(DLight) == 80, "DLight");
+
+struct DTexture {
+    const uint32_t* rgba;  // device pointer, RGBA8 packed little-endian
+    int32_t width, height;
+};
+
+// Subspace-tree node, 48 B = 3 x float4:
+//   q0 = (mid.xyz, as_float(type | leaf << 2 | label << 3))  q1 = child[0..3]  q2 = child[4..7]
+static const int TREE_QUADS = 3;
+
+typedef spcbpt_light_vertex LightVertex;  // 96 B = 6 x float4, AoS because it is fetched by random gather
+static_assert(sizeof(LightVertex) == 96, "LightVertex");
+
+struct DSubspace {  // 16 B
+    int32_t jump_bias;
+    int32_t size;
+    float sum_pmf;
+    int32_t pad;
+};
+
+enum CounterSlot {
+    C_CLOSEST = 0, C_SHADOW, C_NODE, C_TRI, C_VERTEX, C_TEX, C_TREE, C_CMF, C_CONN, C_GQ, C_LVCW, C_PIX, C_EYE, C_LIGHT,
+    C_COUNT
+};
+
+struct DeviceScene {
+    const float* nodes;      // float4 x NODE_QUADS per node
+    const float* tris;       // float4 x TRI_QUADS per triangle (BVH order)
+    const int32_t* tri_orig; // BVH order -> caller's triangle index (quad-light triangles follow the scene's)
+    const DMaterial* mats;
+    const DLight* lights;
+    const DTexture* tex;
+    int32_t n_lights;
+    int32_t n_mats;
+};
+
+struct KParams {  // passed by value as the kernel argument block (the MyParams analogue)
+    DeviceScene scene;
+    float eye[3], U[3], V[3], W[3];
+    uint32_t width, height, subframe;
+    int32_t row_begin, row_end, row_step;  // 8-row bands: see spcbpt_launch
+    float* accum;        // float4 per pixel
+    uint32_t* frame;     // RGBA8 per pixel
+    // subspace tuple (subspaceMacroInfo)
+    const float* eye_tree;
+    const float* light_tree;
+    const float* Q;
+    const float* cmf_gamma;
+    // sampler (SubspaceSampler)
+    const LightVertex* lvc;
+    const DSubspace* subspace;
+    const float* cmfs;
+    const int32_t* jump;
+    const int32_t* sampler_counts;  // [0] vertex_count, [1] path_count (device-resident: no host round trip)
+    // light pass (LightTraceParams)
+    int32_t num_core, core_padding, m_per_core, core_begin, core_count;
+    uint32_t launch_frame;
+    LightVertex* lvc_scratch;   // core_count * core_padding padded slots
+    int32_t* core_counts;       // vertices stored per core
+    // instrumentation / traversal scratch
+    unsigned long long* counters;  // C_COUNT slots or null
+    uint32_t* spill;               // per-thread traversal stack overflow area
+    int32_t spill_entries;         // entries per thread in `spill`
+};
+
+}  // namespace spc

@@ -1,0 +1,199 @@
+// Host-side LBVH construction (replaces OptiX's GAS/IAS build, sutil/Scene.cpp:943-1338).
+// Morton-ordered primitives (63-bit codes) -> Karras 2012 radix-tree topology ->
+// collapse of every subtree covering <= LEAF_MAX primitives into one leaf ->
+// depth-first node emission with both child boxes stored in the parent (layout.h).
+#include "lbvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace spc {
+
+static inline uint64_t expand21(uint64_t v) {  // spread the low 21 bits to every third bit
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+struct Builder {
+    const HostMesh& m;
+    int n;
+    std::vector<uint64_t> keys;
+    std::vector<int> order;       // sorted position -> original triangle
+    std::vector<int> left, right; // Karras internal nodes: child ids (>= 0 internal, < 0 -> leaf ~id = sorted position)
+    std::vector<int> rlo, rhi;    // covered range of each internal node
+    std::vector<float> tlo, thi;  // per sorted triangle bounds
+    Lbvh& out;
+    int max_depth = 0;
+
+    Builder(const HostMesh& mesh, Lbvh& o) : m(mesh), n(mesh.n_triangles), out(o) {}
+
+    inline int delta(int i, int j) const {
+        if (j < 0 || j >= n) return -1;
+        uint64_t a = keys[i], b = keys[j];
+        if (a != b) return __builtin_clzll(a ^ b);
+        return 64 + __builtin_clz((unsigned)i ^ (unsigned)j);
+    }
+
+    void topology() {
+        left.assign(n - 1, 0); right.assign(n - 1, 0); rlo.assign(n - 1, 0); rhi.assign(n - 1, 0);
+        for (int i = 0; i < n - 1; i++) {
+            int d = (delta(i, i + 1) - delta(i, i - 1)) >= 0 ? 1 : -1;
+            int dmin = delta(i, i - d);
+            int lmax = 2;
+            while (delta(i, i + lmax * d) > dmin) lmax *= 2;
+            int l = 0;
+            for (int t = lmax / 2; t >= 1; t /= 2)
+                if (delta(i, i + (l + t) * d) > dmin) l += t;
+            int j = i + l * d;
+            int dnode = delta(i, j);
+            int s = 0;
+            for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+                if (delta(i, i + (s + t) * d) > dnode) s += t;
+                if (t == 1) break;
+            }
+            int gamma = i + s * d + std::min(d, 0);
+            int lo = std::min(i, j), hi = std::max(i, j);
+            left[i] = (lo == gamma) ? ~gamma : gamma;
+            right[i] = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+            rlo[i] = lo; rhi[i] = hi;
+        }
+    }
+
+    struct Box { float lo[3], hi[3]; };
+    Box range_box(int a, int b) const {
+        Box r;
+        for (int k = 0; k < 3; k++) { r.lo[k] = 1e30f; r.hi[k] = -1e30f; }
+        for (int i = a; i <= b; i++)
+            for (int k = 0; k < 3; k++) {
+                r.lo[k] = std::min(r.lo[k], tlo[3 * i + k]);
+                r.hi[k] = std::max(r.hi[k], thi[3 * i + k]);
+            }
+        return r;
+    }
+    static Box merge(const Box& a, const Box& b) {
+        Box r;
+        for (int k = 0; k < 3; k++) { r.lo[k] = std::min(a.lo[k], b.lo[k]); r.hi[k] = std::max(a.hi[k], b.hi[k]); }
+        return r;
+    }
+    // child id (Karras) -> covered range
+    void child_range(int c, int& a, int& b) const {
+        if (c < 0) { a = b = ~c; } else { a = rlo[c]; b = rhi[c]; }
+    }
+    // Emits the subtree rooted at Karras node `k` (which covers > LEAF_MAX primitives) as output node; returns its box.
+    Box emit(int k, int out_index, int depth) {
+        max_depth = std::max(max_depth, depth);
+        int cid[2] = {left[k], right[k]};
+        Box cb[2];
+        int cref[2], ccount[2];
+        for (int s = 0; s < 2; s++) {
+            int a, b;
+            child_range(cid[s], a, b);
+            if (b - a + 1 <= LEAF_MAX) {
+                cb[s] = range_box(a, b);
+                cref[s] = ~a;
+                ccount[s] = b - a + 1;
+            } else {
+                int idx = (int)(out.nodes.size() / 16);
+                out.nodes.resize(out.nodes.size() + 16);
+                cb[s] = emit(cid[s], idx, depth + 1);
+                cref[s] = idx;
+                ccount[s] = 0;
+            }
+        }
+        float* q = &out.nodes[(size_t)out_index * 16];
+        auto put_i = [](float* p, int v) { memcpy(p, &v, 4); };
+        q[0] = cb[0].lo[0]; q[1] = cb[0].lo[1]; q[2] = cb[0].lo[2]; put_i(q + 3, cref[0]);
+        q[4] = cb[0].hi[0]; q[5] = cb[0].hi[1]; q[6] = cb[0].hi[2]; put_i(q + 7, cref[1]);
+        q[8] = cb[1].lo[0]; q[9] = cb[1].lo[1]; q[10] = cb[1].lo[2]; put_i(q + 11, ccount[0]);
+        q[12] = cb[1].hi[0]; q[13] = cb[1].hi[1]; q[14] = cb[1].hi[2]; put_i(q + 15, ccount[1]);
+        return merge(cb[0], cb[1]);
+    }
+
+    void run() {
+        const float* P = m.vertices;
+        // centroid bounds
+        float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
+        std::vector<float> cen((size_t)3 * n);
+        for (int t = 0; t < n; t++) {
+            const float* a = P + 3 * (size_t)m.indices[3 * t];
+            const float* b = P + 3 * (size_t)m.indices[3 * t + 1];
+            const float* c = P + 3 * (size_t)m.indices[3 * t + 2];
+            for (int k = 0; k < 3; k++) {
+                float lo = std::min(a[k], std::min(b[k], c[k])), hi = std::max(a[k], std::max(b[k], c[k]));
+                float ce = 0.5f * (lo + hi);
+                cen[3 * (size_t)t + k] = ce;
+                clo[k] = std::min(clo[k], ce); chi[k] = std::max(chi[k], ce);
+            }
+        }
+        keys.resize(n);
+        std::vector<std::pair<uint64_t, int>> kv(n);
+        for (int t = 0; t < n; t++) {
+            uint64_t code = 0;
+            for (int k = 0; k < 3; k++) {
+                double ext = (double)chi[k] - (double)clo[k];
+                double f = ext > 0 ? ((double)cen[3 * (size_t)t + k] - clo[k]) / ext : 0.0;
+                uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, f * 2097152.0));
+                code |= expand21(q) << (2 - k);
+            }
+            kv[t] = {code, t};
+        }
+        std::sort(kv.begin(), kv.end());
+        order.resize(n);
+        for (int i = 0; i < n; i++) { keys[i] = kv[i].first; order[i] = kv[i].second; }
+        tlo.resize((size_t)3 * n); thi.resize((size_t)3 * n);
+        out.tris.resize((size_t)16 * n);
+        out.tri_orig.resize(n);
+        for (int i = 0; i < n; i++) {
+            int t = order[i];
+            out.tri_orig[i] = t;
+            const uint32_t* ix = m.indices + 3 * (size_t)t;
+            float* q = &out.tris[(size_t)16 * i];
+            float uv[3][2];
+            for (int v = 0; v < 3; v++) {
+                const float* p = P + 3 * (size_t)ix[v];
+                q[4 * v + 0] = p[0]; q[4 * v + 1] = p[1]; q[4 * v + 2] = p[2];
+                uv[v][0] = m.texcoords ? m.texcoords[2 * (size_t)ix[v]] : 0.0f;
+                uv[v][1] = m.texcoords ? m.texcoords[2 * (size_t)ix[v] + 1] : 0.0f;
+            }
+            q[3] = uv[0][0]; q[7] = uv[0][1]; q[11] = uv[1][0];
+            q[12] = uv[1][1]; q[13] = uv[2][0]; q[14] = uv[2][1];
+            uint32_t meta = (uint32_t)m.tri_material[t] | (m.tri_emitter[t] ? 0x80000000u : 0u);
+            memcpy(q + 15, &meta, 4);
+            for (int k = 0; k < 3; k++) {
+                tlo[3 * (size_t)i + k] = std::min(q[k], std::min(q[4 + k], q[8 + k]));
+                thi[3 * (size_t)i + k] = std::max(q[k], std::max(q[4 + k], q[8 + k]));
+            }
+        }
+        out.nodes.clear();
+        out.nodes.resize(16);
+        if (n <= LEAF_MAX) {
+            // degenerate tiny scene: root with one real leaf and one empty child
+            Box b = range_box(0, n - 1);
+            float* q = &out.nodes[0];
+            int c0 = ~0, cnt0 = n, c1 = ~0, cnt1 = 0;
+            q[0] = b.lo[0]; q[1] = b.lo[1]; q[2] = b.lo[2]; memcpy(q + 3, &c0, 4);
+            q[4] = b.hi[0]; q[5] = b.hi[1]; q[6] = b.hi[2]; memcpy(q + 7, &c1, 4);
+            q[8] = 1e30f; q[9] = 1e30f; q[10] = 1e30f; memcpy(q + 11, &cnt0, 4);
+            q[12] = -1e30f; q[13] = -1e30f; q[14] = -1e30f; memcpy(q + 15, &cnt1, 4);
+            out.depth = 1;
+            return;
+        }
+        topology();
+        emit(0, 0, 1);
+        out.depth = max_depth;
+    }
+};
+
+void build_lbvh(const HostMesh& mesh, Lbvh& out) {
+    Builder b(mesh, out);
+    b.run();
+}
+
+}  // namespace spc

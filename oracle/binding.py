@@ -113,8 +113,11 @@ class Oracle:
         self.l.orc_set_subspace(self.h, C.c_void_p(et.ctypes.data), et.shape[0], C.c_void_p(lt.ctypes.data), lt.shape[0],
                                 C.c_void_p(q.ctypes.data), C.c_void_p(g.ctypes.data))
 
-    def set_light_trace(self, num_core, core_padding, m_per_core):
+    def set_light_trace(self, num_core, core_padding, m_per_core, decorrelate=None):
+        if decorrelate is None:
+            decorrelate = m_per_core == 1   # same default as the product binding
         self.l.orc_set_light_trace(self.h, num_core, core_padding, m_per_core)
+        self.l.orc_set_light_decorrelate(self.h, int(decorrelate))
         self.lt = (num_core, core_padding, m_per_core)
 
     def set_cmf_double(self, on):

@@ -104,6 +104,7 @@ int orc_set_subspace(orc_ctx* c, const spcbpt_tree_node* eye_tree, int n_eye, co
     } else c->P.CMFGamma = nullptr;
     return 0;
 }
+int orc_set_light_decorrelate(orc_ctx* c, int on) { c->P.lt.decorrelate_bsdf_stream = on != 0; return 0; }
 int orc_set_light_trace(orc_ctx* c, int num_core, int core_padding, int m_per_core) {
     c->P.lt.num_core = num_core; c->P.lt.core_padding = core_padding; c->P.lt.M_per_core = m_per_core;
     c->lvc.assign((size_t)num_core * core_padding, BDPTVertex());
@@ -138,7 +139,9 @@ int orc_launch(orc_ctx* c, const char* name, unsigned frame, int row_begin, int 
         c->P.subframe_index = frame;
         if (row_step < 1) row_step = 1;
         std::vector<int> rows;
-        for (int y = row_begin; y < row_end && y < (int)c->P.height; y += row_step) rows.push_back(y);
+        // 8-row bands, band k of every row_step (same rule as spcbpt_launch)
+        for (int y = row_begin; y < row_end && y < (int)c->P.height; y++)
+            if (((y / 8) - (row_begin / 8)) % row_step == 0) rows.push_back(y);
         bool spc = alg == "SPCBPT_eye";
         make_views();
         parallel_for((int)rows.size(), nthreads, [&](int i, int t) {

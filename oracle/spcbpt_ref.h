@@ -81,6 +81,8 @@ struct Subspace { int jump_bias, id, size; float sum_pmf, Q; };  // optixPathTra
 
 struct LightTraceParams {  // optixPathTracer.h:52-66
     int num_core = 1000, core_padding = 800, M_per_core = 100, launch_frame = 0;
+    // test knob, NOT reference behaviour (see spcbpt_light_trace_params::decorrelate_bsdf_stream); false = reference
+    bool decorrelate_bsdf_stream = false;
     BDPTVertex* ans = nullptr;
     uint8_t* validState = nullptr;
     int get_element_count() const { return num_core * core_padding; }
@@ -826,7 +828,7 @@ inline void raygen_lightTrace(const Params& P, int launch_index) {
     const Scene& S = *P.scene;
     uint32_t seed = tea<4>((uint32_t)launch_index, (uint32_t)lt.launch_frame);
     PayloadBDPTVertex payload;
-    payload.seed = seed;
+    payload.seed = lt.decorrelate_bsdf_stream ? tea<4>((uint32_t)launch_index ^ 0x80000000u, (uint32_t)lt.launch_frame) : seed;
     unsigned bufferBias = (unsigned)lt.core_padding * (unsigned)launch_index;
     unsigned lightVertexCount = 0, lightPathCount = 0;
     auto push = [&](BDPTVertex& v) {  // pushVertexToLVC raygen.cu:613-619

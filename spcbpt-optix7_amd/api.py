@@ -54,7 +54,7 @@ class TreeNode(C.Structure):
 
 class LightTraceParams(C.Structure):
     _fields_ = [("num_core", C.c_int32), ("core_padding", C.c_int32), ("m_per_core", C.c_int32),
-                ("core_begin", C.c_int32), ("core_count", C.c_int32)]
+                ("core_begin", C.c_int32), ("core_count", C.c_int32), ("decorrelate_bsdf_stream", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -198,6 +198,13 @@ def load_library(path: str = LIB_PATH):
         return _lib
     if not os.path.exists(path):
         raise SpcbptError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).
+    # Importing torch first makes this library bind to the runtime torch uses, so torch.distributed (RCCL) buffers
+    # and the context's buffers live in the same HIP context.  Without torch the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, i32, u32, f32p = C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_float)
     sig = {
@@ -324,8 +331,10 @@ class Renderer:
                                                q.ctypes.data, g.ctypes.data), "get_subspace")
         return et[:ne.value].copy(), lt[:nl.value].copy(), q, g.reshape(NUM_SUBSPACE, NUM_SUBSPACE)
 
-    def set_light_trace(self, num_core, core_padding, m_per_core, core_begin=0, core_count=0):
-        p = LightTraceParams(num_core, core_padding, m_per_core, core_begin, core_count)
+    def set_light_trace(self, num_core, core_padding, m_per_core, core_begin=0, core_count=0, decorrelate=None):
+        if decorrelate is None:
+            decorrelate = m_per_core == 1   # one path per lane: see spcbpt_light_trace_params in include/spcbpt.h
+        p = LightTraceParams(num_core, core_padding, m_per_core, core_begin, core_count, int(decorrelate))
         self._chk(self.lib.spcbpt_set_light_trace(self.h, C.byref(p)), "set_light_trace")
         self.lt = p
 

@@ -176,12 +176,13 @@ int Context::ensure_temp(size_t bytes) {
 int Context::launch_light(uint32_t frame) {
     if (!have_subspace) { error = "light trace needs a subspace tuple (spcbpt_set_subspace)"; return SPCBPT_ERR_STATE; }
     if (!d_scratch) {
-        spcbpt_light_trace_params d = {100000, 52, 1, 0, 0};
+        spcbpt_light_trace_params d = {100000, 52, 1, 0, 0, 1};
         int rc = set_light_trace(d);
         if (rc) return rc;
     }
     kp.num_core = lt.num_core; kp.core_padding = lt.core_padding; kp.m_per_core = lt.m_per_core;
     kp.core_begin = lt.core_begin; kp.core_count = lt.core_count; kp.launch_frame = frame;
+    kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
     kp.lvc_scratch = d_scratch; kp.core_counts = d_core_counts;
     int rc = ensure_spill(((size_t)lt.core_count + 255) / 256 * 256);
     if (rc) return rc;

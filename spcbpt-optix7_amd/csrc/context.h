@@ -44,7 +44,7 @@ struct Context {
     std::vector<float> h_Q, h_gamma;
     bool have_subspace = false;
     // light pass + LVC + sampler
-    spcbpt_light_trace_params lt = {100000, 52, 1, 0, 100000};
+    spcbpt_light_trace_params lt = {100000, 52, 1, 0, 100000, 1};
     LightVertex* d_scratch = nullptr;
     size_t scratch_capacity = 0;
     int* d_core_counts = nullptr;

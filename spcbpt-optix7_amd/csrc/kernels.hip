@@ -314,7 +314,8 @@ __global__ __launch_bounds__(BLOCK) void k_light_trace(const KParams p) {
         TravStack<BLOCK, STACK_LDS> st;
         st.init(s_stack, p.spill, p.spill_entries, (size_t)local_core);
         uint32_t seed = tea4((uint32_t)core, p.launch_frame);  // light sampling stream
-        uint32_t pseed = seed;                                  // payload.seed: BSDF stream
+        // payload.seed: BSDF stream; the reference starts it equal to `seed`
+        uint32_t pseed = p.lt_decorrelate ? tea4((uint32_t)core ^ 0x80000000u, p.launch_frame) : seed;
         LightVertex* slots = p.lvc_scratch + (size_t)local_core * p.core_padding;
         int nverts = 0, npaths = 0;
         auto store = [&](const LightVertex& v) {

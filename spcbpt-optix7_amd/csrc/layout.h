@@ -96,7 +96,7 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     const int32_t* jump;
     const int32_t* sampler_counts;  // [0] vertex_count, [1] path_count (device-resident: no host round trip)
     // light pass (LightTraceParams)
-    int32_t num_core, core_padding, m_per_core, core_begin, core_count;
+    int32_t num_core, core_padding, m_per_core, core_begin, core_count, lt_decorrelate;
     uint32_t launch_frame;
     LightVertex* lvc_scratch;   // core_count * core_padding padded slots
     int32_t* core_counts;       // vertices stored per core

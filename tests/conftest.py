@@ -1,0 +1,58 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _make(path, target=None):
+    cmd = ["make", "-C", path] + ([target] if target else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="session")
+def ob(pkg):
+    """oracle binding (test infrastructure)"""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        _make(os.path.join(ROOT, "oracle"))
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def hip_lib(pkg):
+    """the product shared library (cross-compiled by hipcc when missing; needs no GPU to load)"""
+    if not os.path.exists(pkg.api.LIB_PATH):
+        _make(os.path.join(ROOT, "spcbpt-optix7_amd", "csrc"))
+    return pkg.load_library()
+
+
+def gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu(pkg, hip_lib):
+    if not gpu_available():
+        pytest.fail("GPU test selected but no HIP device is visible — the product has no CPU fallback")
+    return 0

@@ -57,3 +57,34 @@ def image_parity(a: np.ndarray, b: np.ndarray, rel: float = 2e-3, abs_: float = 
 
 def rmse(a, b):
     return float(np.sqrt(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).mean()))
+
+
+def grid_tree_tuple(pkg, oracle, scene, frames: int = 2, first_frame: int = 20_000):
+    """A valid multi-leaf tuple for tests: both classifiers are one position octree level (8 leaves) followed by a
+    normal split under octant 0; Q measured with those trees; Gamma rows proportional to Q."""
+    lo, hi = scene.vertices.min(0), scene.vertices.max(0)
+    mid = 0.5 * (lo + hi)
+
+    def tree(base):
+        t = np.zeros(11, dtype=pkg.TREE_NODE_DTYPE)
+        t[0]["mid"] = mid; t[0]["type"] = 0; t[0]["child"] = np.arange(1, 9)
+        for k in range(1, 9):
+            t[k]["leaf"] = 1; t[k]["label"] = base + k
+        t[1]["leaf"] = 0; t[1]["type"] = 1; t[1]["mid"] = (0, 0, 0); t[1]["child"] = [9, 10, 9, 10, 10, 9, 10, 9]
+        t[9]["leaf"] = 1; t[9]["label"] = base + 20
+        t[10]["leaf"] = 1; t[10]["label"] = base + 21
+        return t
+
+    et, lt = tree(100), tree(300)
+    n = pkg.NUM_SUBSPACE
+    uni = np.tile((np.arange(1, n + 1, dtype=np.float32) / n)[None, :], (n, 1))
+    oracle.set_subspace(et, lt, np.ones(n, np.float32), uni)
+    acc = np.zeros(n, np.float64)
+    tot = 0
+    for f in range(frames):
+        oracle.launch("light trace", first_frame + f)
+        q, paths = q_from_lvc(oracle.lvc_read(), n)
+        acc += q * paths
+        tot += paths
+    _, _, q, gamma = tuple_from_q(pkg, acc / max(tot, 1))
+    return et, lt, q, gamma

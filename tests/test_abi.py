@@ -1,0 +1,59 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/spcbpt.h declares,
+and fails loudly (no CPU fallback) when no HIP device exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "spcbpt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(spcbpt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(hip_lib, pkg):
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(hip_lib, n), f"{n} declared in include/spcbpt.h but not exported"
+    assert sorted(pkg.api.EXPORTED_SYMBOLS) == names
+
+
+def test_struct_sizes_match_header(pkg):
+    assert pkg.LIGHT_VERTEX_DTYPE.itemsize == 96
+    assert pkg.SUBSPACE_DTYPE.itemsize == 20
+    assert pkg.TREE_NODE_DTYPE.itemsize == 56      # sizeof(classTree::tree_node) in the reference is 56 too
+    assert C.sizeof(pkg.api.Material) == 52 and C.sizeof(pkg.api.QuadLight) == 52
+    assert C.sizeof(pkg.api.Counters) == 14 * 8
+
+
+def test_create_fails_loudly_without_a_gpu(hip_lib, pkg):
+    from tests.conftest import gpu_available
+    if gpu_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.SpcbptError) as e:
+        pkg.Renderer(pkg.scenes.cornell_box(), 0)
+    assert "no HIP device" in str(e.value) or "-2" in str(e.value)
+
+
+def test_create_rejects_bad_scenes_before_touching_the_gpu(hip_lib, pkg):
+    sc = pkg.scenes.cornell_box()
+    sd, keep = sc.desc()
+    bad = np.array(sc.indices, dtype=np.uint32).copy()
+    bad[0, 0] = 10**6
+    sd.indices = bad.ctypes.data
+    h = C.c_void_p()
+    rc = hip_lib.spcbpt_create(C.byref(sd), 0, C.byref(h))
+    assert rc in (-1, -2)  # invalid argument, or no device when that check comes first
+    assert hip_lib.spcbpt_create(None, 0, C.byref(h)) == -1
+
+
+def test_null_context_is_an_error_not_a_crash(hip_lib):
+    assert hip_lib.spcbpt_sync(None) == -1
+    assert hip_lib.spcbpt_launch(None, b"pt", 0, 0, 8, 1) == -1
+    assert hip_lib.spcbpt_build_sampler(None) == -1

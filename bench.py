@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpaths/s of the SPCBPT hot path on the bedroom-class scene at 1920x1080 (BASELINE.json metric;
+configs[2] at N=1, configs[3] at N>1).
+
+One "step" = one subframe of the reference's render loop (optixPathTracer.cpp:791-822): light trace (M = 100 000 light
+paths) -> device sampler build -> [N>1: RCCL all-gather of the LVC shards] -> SPCBPT eye megakernel over the image
+(N>1: every N-th band of 8 rows per rank); N>1 ends the timed region with the RCCL framebuffer sum.
+value = (eye paths + light paths) of all ranks / wall time.  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_scene(pkg, name, tris):
+    if name == "bedroom":
+        return pkg.scenes.bedroom(target_tris=tris)
+    if name == "cornell":
+        return pkg.scenes.cornell_box()
+    if name == "hallway":
+        return pkg.scenes.hallway(target_tris=tris)
+    raise SystemExit(f"unknown scene {name}")
+
+
+def cpu_baseline(pkg, scene, args, tup):
+    """The oracle (scalar CPU restatement, `kind: port`) timed on this host's cores on a bounded sample of the same
+    workload: the full light pass + sampler build + every `stride`-th band of the eye pass."""
+    from oracle import binding as ob
+    threads = os.cpu_count() or 1
+    o = ob.Oracle(scene, nthreads=threads)
+    cam = scene.camera
+    o.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
+    o.resize(args.width, args.height)
+    o.set_light_trace(args.light_paths, 52, 1)
+    o.set_subspace(*tup)
+    o.enable_counters(False)
+    stride = max(1, args.cpu_band_stride)
+    t0 = time.perf_counter()
+    o.launch("light trace", 1)
+    o.build_sampler()
+    o.launch("SPCBPT_eye", 0, rows=(0, args.height, stride))
+    dt = time.perf_counter() - t0
+    rows = sum(1 for y in range(args.height) if (y // 8) % stride == 0)
+    paths = rows * args.width + args.light_paths
+    return {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "sample": f"1 subframe: {args.light_paths} light paths + sampler build + eye pass on every {stride}-th 8-row band "
+                      f"({rows * args.width} eye paths) in {dt:.1f} s with {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="bedroom")
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--light-paths", type=int, default=100_000)
+    ap.add_argument("--tuple", default="minimal", choices=["minimal", "trained"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-band-stride", type=int, default=6)
+    ap.add_argument("--write-image", default="")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    pkg = entry.load_package()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    scene = make_scene(pkg, args.scene, args.tris)
+    r = pkg.Renderer(scene, local_rank)
+    cam = scene.camera
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
+    r.resize(args.width, args.height)
+    M = args.light_paths
+    # the subspace tuple is computed with the full light pass on every rank (identical result), then the pass is sharded
+    r.set_light_trace(M, 52, 1)
+    if args.tuple == "trained":
+        r.preprocess(target_paths=2_000_000, target_q_paths=2_000_000, train=True)
+    else:
+        r.set_subspace()
+    tup = r.get_subspace()
+    begin, count = pkg.dist.core_range(M, rank, world)
+    r.set_light_trace(M, 52, 1, core_begin=begin, core_count=count)
+    rows = pkg.dist.band_rows(args.height, rank, world)
+    ex = pkg.dist.FrameExchanger(r, rank, world, device) if world > 1 else None
+    info = r.scene_info()
+
+    def step(f):
+        r.launch("light trace", f + 1)
+        if ex is not None:
+            ex.allgather_lvc()
+        r.build_sampler()
+        r.launch("SPCBPT_eye", f, rows)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        r.sync()
+        torch.cuda.synchronize()
+
+    r.clear_accum()
+    for f in range(args.warmup):
+        step(f)
+    # event counts of ONE launch of the dominant kernel -> algorithmic bytes per launch (untimed)
+    r.sync()
+    r.launch("light trace", 999)
+    if ex is not None:
+        ex.allgather_lvc()
+    r.build_sampler()
+    r.enable_counters(True)
+    r.reset_counters()
+    r.launch("SPCBPT_eye", 999, rows)
+    r.sync()
+    c_eye = r.counters()
+    r.enable_counters(False)
+    bytes_per_launch = pkg.algorithmic_bytes(c_eye)
+
+    r.clear_accum()
+    r.enable_kernel_timing(True)
+    r.reset_kernel_time()
+    barrier()
+    t0 = time.perf_counter()
+    for f in range(args.steps):
+        step(f)
+    if ex is not None:
+        ex.reduce_framebuffer()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    k_ms, k_n = r.kernel_time("spcbpt_render")
+    lt_ms, _ = r.kernel_time("light_trace")
+    sb_ms, _ = r.kernel_time("sampler_build")
+    cp_ms, _ = r.kernel_time("lvc_compact")
+    r.enable_kernel_timing(False)
+
+    eye_paths = args.width * args.height
+    total_paths = (eye_paths + M) * args.steps
+    value = total_paths / dt / 1e6
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+
+    if args.write_image and rank == 0:
+        img = r.read_accum()
+        np.save(args.write_image, img)
+
+    if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("spcbpt_render_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpaths/sec (whole node), SPCBPT, 1920x1080",
+            "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} scene ({info['n_triangles']} triangles, LBVH {info['n_bvh_nodes']} nodes depth "
+                                   f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
+                                   f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+            "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel_ms": round(k_ms, 4), "launches": k_n},
+            "kernels_ms": {"spcbpt_render": round(k_ms, 4), "light_trace": round(lt_ms, 4), "lvc_compact": round(cp_ms, 4),
+                           "sampler_build": round(sb_ms, 4)},
+            "events_per_eye_path": {k: round(v / max(c_eye["eye_paths"], 1), 3) for k, v in c_eye.items()
+                                    if k in ("closest_rays", "shadow_rays", "node_visits", "tri_tests", "surface_vertices",
+                                             "connections", "tree_nodes", "cmf_probes")},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, scene, args, tup)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

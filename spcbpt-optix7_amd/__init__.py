@@ -7,7 +7,7 @@ as the module `spcbpt_optix7_amd`.
 from .api import (CONNECTION_N, NUM_SUBSPACE, NUM_SUBSPACE_LIGHTSOURCE, LIGHT_VERTEX_DTYPE, SUBSPACE_DTYPE,
                   TREE_NODE_DTYPE, Renderer, Scene, SpcbptError, algorithmic_bytes, camera_frame, load_library,
                   single_leaf_tree)
-from . import scenes
+from . import api, dist, scenes
 
 __all__ = ["Renderer", "Scene", "SpcbptError", "scenes", "camera_frame", "single_leaf_tree", "load_library",
            "algorithmic_bytes", "NUM_SUBSPACE", "NUM_SUBSPACE_LIGHTSOURCE", "CONNECTION_N", "LIGHT_VERTEX_DTYPE",

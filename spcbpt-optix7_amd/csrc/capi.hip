@@ -264,8 +264,14 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     kp.counters = counting ? d_counters : nullptr;
     int rc = ensure_spill((size_t)render_thread_count(kp));
     if (rc) return rc;
+    if (spcbpt_alg) {
+        kp.n_tiles = (uint32_t)render_tile_count(kp);
+        kp.work_counter = d_work_counter;
+        HIP_TRY(this, hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), stream));
+        if (!blocks_per_cu[counting]) blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
+    }
     time_begin(name);
-    if (spcbpt_alg) launch_spcbpt(kp, counting, stream);
+    if (spcbpt_alg) launch_spcbpt(kp, counting, num_cus * blocks_per_cu[counting], stream);
     else launch_pt(kp, counting, stream);
     time_end();
     HIP_TRY(this, hipGetLastError());
@@ -318,7 +324,7 @@ Context::~Context() {
     dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_lvc); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_vals2); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix); dev_free(d_cmfs);
-    dev_free(d_subspace); dev_free(d_sampler_counts); dev_free(d_counters); dev_free(d_spill); dev_free(d_temp);
+    dev_free(d_subspace); dev_free(d_sampler_counts); dev_free(d_counters); dev_free(d_work_counter); dev_free(d_spill); dev_free(d_temp);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -447,6 +453,12 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     CREATE_TRY(dev_alloc(&c->d_subspace, (size_t)SPCBPT_NUM_SUBSPACE));
     CREATE_TRY(dev_alloc(&c->d_sampler_counts, (size_t)2));
     CREATE_TRY(hipMemset(c->d_sampler_counts, 0, 2 * sizeof(int)));
+    {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, device));
+        c->num_cus = prop.multiProcessorCount;
+    }
+    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)1));
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
     CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
     memset(&c->kp, 0, sizeof(c->kp));

@@ -66,6 +66,8 @@ struct Context {
     uint32_t* d_spill = nullptr;
     size_t spill_capacity = 0;
     // instrumentation
+    uint32_t* d_work_counter = nullptr;
+    int num_cus = 0, blocks_per_cu[2] = {0, 0};
     unsigned long long* d_counters = nullptr;
     bool counting = false, timing = false;
     std::vector<TimedSpan> spans;

@@ -14,6 +14,9 @@ namespace spc {
 
 static constexpr int BLOCK = 256;
 static constexpr int STACK_LDS = 24;  // 24 KB of LDS per block; deeper entries spill (TravStack)
+#ifndef SPC_WAVES
+#define SPC_WAVES 4  // measured on MI355X (bedroom 1080p): 2 -> 38.8 ms, 3 -> 31.6, 4 -> 28.3, 5 -> 29.3; minimum waves per SIMD requested from the register allocator for the megakernel
+#endif
 
 // pixel of this lane: 8x8 tile per wave, 4 tiles (in x) per block, bands of 8 rows selected by (row_begin, row_step)
 SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
@@ -127,84 +130,148 @@ SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pixel of work-slot `slot` (0..63) of tile `tile`: tiles are 8x8 pixels, enumerated x-major inside the selected bands.
+SPC_DEV bool tile_pixel(const KParams& p, uint32_t tile, uint32_t slot, uint32_t& x, uint32_t& y) {
+    const uint32_t tiles_x = (p.width + 7) / 8;
+    const uint32_t tile_x = tile % tiles_x, band_k = tile / tiles_x;
+    const uint32_t band = (uint32_t)(p.row_begin / 8) + band_k * (uint32_t)p.row_step;
+    x = tile_x * 8 + (slot & 7);
+    y = band * 8 + (slot >> 3);
+    return x < p.width && y < p.height && (int)y < p.row_end;
+}
+
+// The SPCBPT megakernel: persistent waves with per-lane path regeneration.  A wave pulls 8x8 pixel tiles from a global
+// queue (one atomicAdd per tile); a lane whose eye path ends writes its pixel and immediately starts the next
+// pixel-sample of the wave's pool, so the 64 lanes stay busy although path lengths differ by an order of magnitude.
+// Every iteration runs the same phases for all live lanes: closest-hit traversal -> vertex -> 3 x (two-stage
+// resampling, shadow traversal, connection).  The queue counter saturates, so every wave reaches the exit.
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_spcbpt(const KParams p) {
+__global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    uint32_t x, y;
-    const bool active = lane_pixel(p, x, y);
+    const DeviceScene& S = p.scene;
+    const uint32_t lane = threadIdx.x & 63;
     Counts<COUNT> cn;
     cn.clear();
-    if (active) {
-        const DeviceScene& S = p.scene;
-        TravStack<BLOCK, STACK_LDS> st;
-        st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
-        WalkState w;
-        w.dir = camera_ray(p, x, y, w.seed);
-        w.origin = ld3(p.eye);
-        w.done = false;
-        w.next_flux = mk3(0.0f);
-        w.next_single_pdf = 1.0f;
-        // init_EyeSubpath (raygen.cu:216-231)
-        EyeVertex cur;
-        cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
-        cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0;
-        f3 result = mk3(0.0f);
-        const int path_count = p.sampler_counts[1];
-        cn.add(C_PIX); cn.add(C_EYE);
-        int depth = 0;
-        while (true) {
-            if (w.done || depth > 50) break;
-            HitRec h;
-            cn.add(C_CLOSEST);
-            if (!traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn)) break;  // __miss__BDPTVertex
-            const Geom g = local_geometry(S, h);
-            const bool last_is_origin = cur.depth == 0;
-            const f3 ray_dir = w.dir;
-            depth += 1;
-            if (g.emitter) {
-                result += eye_emitter_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
-                break;
+    TravStack<BLOCK, STACK_LDS> st;
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
+    const int path_count = p.sampler_counts[1];
+    const uint32_t n_tiles = p.n_tiles;
+
+    bool alive = false, exhausted = false;
+    uint32_t pool_tile = 0;
+    int pool_left = 0;
+    uint32_t x = 0, y = 0;
+    WalkState w;
+    EyeVertex cur;
+    f3 result = mk3(0.0f);
+    int depth = 0;
+    w.done = false; w.seed = 0; w.origin = w.dir = w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
+    cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0;
+    cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0;
+
+    while (true) {
+        // ---- regeneration: hand pixel-samples of the pool to idle lanes
+        unsigned long long idle = __ballot(!alive);
+        while (idle != 0ull && !exhausted) {
+            if (pool_left == 0) {
+                uint32_t t = 0;
+                if (lane == (uint32_t)__ffsll((long long)idle) - 1u) t = atomicAdd(p.work_counter, 1u);
+                t = __shfl(t, __ffsll((long long)idle) - 1, 64);
+                if (t >= n_tiles) { exhausted = true; break; }
+                pool_tile = t;
+                pool_left = 64;
             }
-            EyeVertex mid;
-            eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
-            cur = mid;
-            // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419)
-            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                float pmf1, pmf2;
-                const int l = binary_sample(p.cmf_gamma + (size_t)cur.sub * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, w.seed, pmf1, cn);
-                const DSubspace ss = p.subspace[l];
-                if (ss.size == 0) continue;
-                const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
-                const int slot = p.jump[ss.jump_bias + k];
-                const float4* src = reinterpret_cast<const float4*>(p.lvc + slot);
-                LightVertex b;
-                float4* dst = reinterpret_cast<float4*>(&b);
-#pragma unroll
-                for (int q = 0; q < 6; q++) dst[q] = src[q];
-                cn.add(C_CONN);
-                // visibilityTest (cuProg.h:463-487)
-                const f3 bias = ld3(b.position) - cur.c.pos;
-                const float len = sqrtf(dot(bias, bias));
-                const f3 sdir = bias / len;
-                HitRec sh;
-                cn.add(C_SHADOW);
-                if (!traverse<true, COUNT>(S, st, cur.c.pos, sdir, kEps, len - kEps, sh, cn)) {
-                    const float pmf = (float)path_count * pmf2 * pmf1;
-                    f3 res = connect_vertices(p, cur, b, cn);
-                    if (is_invalid(res)) res = mk3(0.0f);
-                    res = res / pmf;
-                    if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+            const int n_idle = __popcll(idle);
+            const int take = n_idle < pool_left ? n_idle : pool_left;
+            const int my_rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (!alive && my_rank < take) {
+                const uint32_t slot = (uint32_t)(64 - pool_left + my_rank);
+                if (tile_pixel(p, pool_tile, slot, x, y)) {
+                    alive = true;
+                    w.dir = camera_ray(p, x, y, w.seed);
+                    w.origin = ld3(p.eye);
+                    w.done = false;
+                    w.next_flux = mk3(0.0f);
+                    w.next_single_pdf = 1.0f;
+                    // init_EyeSubpath (raygen.cu:216-231)
+                    cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
+                    cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0;
+                    result = mk3(0.0f);
+                    depth = 0;
+                    cn.add(C_PIX); cn.add(C_EYE);
                 }
             }
+            pool_left -= take;
+            // slots that fall outside the image (partial tiles) are consumed; their lanes stay idle for this round
+            const unsigned long long still = __ballot(!alive);
+            if (still == idle && pool_left > 0) break;  // only out-of-image slots were handed out: avoid spinning
+            idle = still;
         }
-        film_write(p, x, y, result);
+        if (!__any(alive)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (alive) {
+            bool finished = false;
+            HitRec h;
+            cn.add(C_CLOSEST);
+            if (!traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn)) {
+                finished = true;  // __miss__BDPTVertex
+            } else {
+                const Geom g = local_geometry(S, h);
+                const bool last_is_origin = cur.depth == 0;
+                const f3 ray_dir = w.dir;
+                depth += 1;
+                if (g.emitter) {
+                    result += eye_emitter_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
+                    finished = true;
+                } else {
+                    EyeVertex mid;
+                    eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
+                    cur = mid;
+                    // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419)
+                    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                        float pmf1, pmf2;
+                        const int l = binary_sample(p.cmf_gamma + (size_t)cur.sub * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, w.seed, pmf1, cn);
+                        const DSubspace ss = p.subspace[l];
+                        if (ss.size == 0) continue;
+                        const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
+                        const int slot = p.jump[ss.jump_bias + k];
+                        const float4* src = reinterpret_cast<const float4*>(p.lvc + slot);
+                        LightVertex b;
+                        float4* dst = reinterpret_cast<float4*>(&b);
+#pragma unroll
+                        for (int q = 0; q < 6; q++) dst[q] = src[q];
+                        cn.add(C_CONN);
+                        // visibilityTest (cuProg.h:463-487)
+                        const f3 bias = ld3(b.position) - cur.c.pos;
+                        const float len = sqrtf(dot(bias, bias));
+                        const f3 sdir = bias / len;
+                        HitRec sh;
+                        cn.add(C_SHADOW);
+                        if (!traverse<true, COUNT>(S, st, cur.c.pos, sdir, kEps, len - kEps, sh, cn)) {
+                            const float pmf = (float)path_count * pmf2 * pmf1;
+                            f3 res = connect_vertices(p, cur, b, cn);
+                            if (is_invalid(res)) res = mk3(0.0f);
+                            res = res / pmf;
+                            if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+                        }
+                    }
+                    if (w.done || depth > 50) finished = true;  // the loop-top test of raygen.cu:361
+                }
+            }
+            if (finished) {
+                film_write(p, x, y, result);
+                alive = false;
+            }
+        }
     }
     cn.flush(p.counters);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_pt(const KParams p) {
+__global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     uint32_t x, y;
     const bool active = lane_pixel(p, x, y);
@@ -303,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_pt(const KParams p) {
 // Light pass: one core per lane, each core walks m_per_core light paths and fills its own padded slot range, exactly the
 // launch geometry of LightTraceParams; the MI355X default is num_core = M, m_per_core = 1 (one path per lane).
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_light_trace(const KParams p) {
+__global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     const int local_core = blockIdx.x * BLOCK + threadIdx.x;
     Counts<COUNT> cn;
@@ -437,26 +504,31 @@ __global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int
                               const int* __restrict__ core_offsets, int core_count, int core_padding, LightVertex* __restrict__ lvc,
                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float* __restrict__ weights,
                               int* __restrict__ sampler_counts) {
-    // one wave per core: 64 lanes copy the core's vertices as 16-B quads
-    const int core = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
-    if (core >= core_count) return;
-    const int lane = threadIdx.x & 63;
-    const int n = core_counts[core], off = core_offsets[core];
-    const float4* src = reinterpret_cast<const float4*>(scratch + (size_t)core * core_padding);
-    float4* dst = reinterpret_cast<float4*>(lvc + off);
-    for (int q = lane; q < n * 6; q += 64) dst[q] = src[q];
-    int path_starts = 0;
-    for (int i = lane; i < n; i += 64) {
-        const LightVertex& v = scratch[(size_t)core * core_padding + i];
-        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;  // LVCSubspaceInfoCopy device_thrust.cu:191-212
-        if (isinf(w) || isnan(w)) w = 0.0f;
-        keys[off + i] = (uint32_t)v.subspace_id;
-        vals[off + i] = (uint32_t)(off + i);
-        weights[off + i] = w;
-        path_starts += v.depth == 0 ? 1 : 0;
+    // one thread per padded slot; only the filled slots (slot < count of its core) copy their 96-B record
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int start = 0;
+    if (t < (long long)core_count * core_padding) {
+        const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
+        if (slot < core_counts[core]) {
+            const int dst_i = core_offsets[core] + slot;
+            const float4* src = reinterpret_cast<const float4*>(scratch + t);
+            float4* dst = reinterpret_cast<float4*>(lvc + dst_i);
+            float4 q[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) q[k] = src[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) dst[k] = q[k];
+            const LightVertex& v = *reinterpret_cast<const LightVertex*>(q);
+            float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;  // LVCSubspaceInfoCopy device_thrust.cu:191-212
+            if (isinf(w) || isnan(w)) w = 0.0f;
+            keys[dst_i] = (uint32_t)v.subspace_id;
+            vals[dst_i] = (uint32_t)dst_i;
+            weights[dst_i] = w;
+            start = v.depth == 0 ? 1 : 0;
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) path_starts += __shfl_down(path_starts, o, 64);
-    if (lane == 0 && path_starts) atomicAdd(&sampler_counts[1], path_starts);
+    for (int o = 32; o > 0; o >>= 1) start += __shfl_down(start, o, 64);
+    if ((threadIdx.x & 63) == 0 && start) atomicAdd(&sampler_counts[1], start);
 }
 
 __global__ void k_fill_keys_from_lvc(const LightVertex* __restrict__ lvc, int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -485,13 +557,22 @@ __global__ void k_subspace_ranges(const uint32_t* __restrict__ sorted_keys, cons
     if (i == n - 1 || sorted_keys[i + 1] != k) sub[k].size = i + 1;  // temporarily the END position; fixed in k_finish_ranges
 }
 __global__ void k_finish_ranges(DSubspace* __restrict__ sub) {
-    // empty subspaces: size 0, jump_bias = running offset like the reference (device_thrust.cu:301-309)
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int bias = 0;
-        for (int s = 0; s < SPCBPT_NUM_SUBSPACE; s++) {
-            if (sub[s].size > 0) { const int end = sub[s].size; sub[s].size = end - sub[s].jump_bias; bias = end; }
-            else { sub[s].jump_bias = bias; sub[s].size = 0; }
-        }
+    // one block of 1024 threads: empty subspaces get jump_bias = end of the last non-empty one before them, like the
+    // running offset of the reference's host loop (device_thrust.cu:301-309) -> inclusive max-scan of the END positions
+    __shared__ int ends[1024];
+    const int s = threadIdx.x;
+    const int end = s < SPCBPT_NUM_SUBSPACE ? sub[s].size : 0;  // END position written by k_subspace_ranges, 0 if empty
+    ends[s] = end;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = s >= off ? ends[s - off] : 0;
+        __syncthreads();
+        ends[s] = max(ends[s], v);
+        __syncthreads();
+    }
+    if (s < SPCBPT_NUM_SUBSPACE) {
+        if (end > 0) sub[s].size = end - sub[s].jump_bias;
+        else { sub[s].jump_bias = s > 0 ? ends[s - 1] : 0; sub[s].size = 0; }
     }
 }
 __global__ void k_gather_weights(const float* __restrict__ weights, const uint32_t* __restrict__ sorted_vals, const int* __restrict__ sampler_counts,
@@ -557,11 +638,28 @@ static inline int render_blocks(const KParams& p) {
 }
 int render_thread_count(const KParams& p) { return render_blocks(p) * BLOCK; }
 
-void launch_spcbpt(const KParams& p, bool count, hipStream_t s) {
-    const int blocks = render_blocks(p);
-    if (blocks <= 0) return;
+void launch_spcbpt(const KParams& p, bool count, int max_blocks, hipStream_t s) {
+    // persistent grid: at most `max_blocks` (resident) blocks, never more than the tile queue can feed
+    const int tiles = (int)p.n_tiles;
+    if (tiles <= 0) return;
+    int blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     if (count) hipLaunchKernelGGL(k_spcbpt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL(k_spcbpt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
+}
+int spcbpt_blocks_per_cu(bool count) {
+    int n = 0;
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true>, BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false>, BLOCK, 0);
+    return e == hipSuccess && n > 0 ? n : 1;
+}
+int render_tile_count(const KParams& p) {
+    const int tiles_x = ((int)p.width + 7) / 8;
+    const int band_begin = p.row_begin / 8;
+    const int band_end = (std::min(p.row_end, (int)p.height) + 7) / 8;
+    const int step = p.row_step < 1 ? 1 : p.row_step;
+    const int nb = band_end > band_begin ? (band_end - band_begin + step - 1) / step : 0;
+    return tiles_x * nb;
 }
 void launch_pt(const KParams& p, bool count, hipStream_t s) {
     const int blocks = render_blocks(p);
@@ -577,9 +675,9 @@ void launch_light_trace(const KParams& p, bool count, hipStream_t s) {
 }
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
                         LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
-    const int waves_per_block = 4;
-    const int blocks = (core_count + waves_per_block - 1) / waves_per_block;
-    hipLaunchKernelGGL(k_lvc_compact, dim3(blocks), dim3(64 * waves_per_block), 0, s, scratch, core_counts, core_offsets, core_count,
+    const long long total = (long long)core_count * core_padding;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(k_lvc_compact, dim3(blocks), dim3(256), 0, s, scratch, core_counts, core_offsets, core_count,
                        core_padding, lvc, keys, vals, weights, sampler_counts);
 }
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
@@ -588,7 +686,7 @@ void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* v
 }
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_subspace_ranges, dim3((capacity + 255) / 256), dim3(256), 0, s, sorted_keys, sampler_counts, sub);
-    hipLaunchKernelGGL(k_finish_ranges, dim3(1), dim3(64), 0, s, sub);
+    hipLaunchKernelGGL(k_finish_ranges, dim3(1), dim3(1024), 0, s, sub);
 }
 void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_weights, dim3((capacity + 255) / 256), dim3(256), 0, s, weights, sorted_vals, sampler_counts, out);

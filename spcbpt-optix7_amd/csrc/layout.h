@@ -101,6 +101,8 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     LightVertex* lvc_scratch;   // core_count * core_padding padded slots
     int32_t* core_counts;       // vertices stored per core
     // instrumentation / traversal scratch
+    uint32_t* work_counter;        // tile queue head of the persistent megakernel (zeroed before each launch)
+    uint32_t n_tiles;              // 8x8 pixel tiles in the selected bands
     unsigned long long* counters;  // C_COUNT slots or null
     uint32_t* spill;               // per-thread traversal stack overflow area
     int32_t spill_entries;         // entries per thread in `spill`

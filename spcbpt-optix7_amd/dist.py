@@ -1,0 +1,125 @@
+"""Multi-GPU decomposition of one SPCBPT frame (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm,
+"gloo" on CPU for tests).  The reference is single-GPU; this is new work:
+
+  light pass   rank r traces cores [r*M/N, (r+1)*M/N)  (seeded by GLOBAL core index -> rank-count invariant)
+  exchange 1   all-gather of the compact LVC shards (+ their counts); shards concatenate in rank order = global
+               (path_id, depth) order, so every rank builds the identical sampler
+  eye pass     rank r renders the 8-row bands b with b % N == r
+  exchange 2   framebuffer sum over RCCL (bands a rank did not render are zero), only when an image is read out
+
+PyTorch is plumbing here (device buffers for the collectives); the kernels run behind the C ABI.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .api import LIGHT_VERTEX_DTYPE
+
+VERTEX_BYTES = LIGHT_VERTEX_DTYPE.itemsize
+
+
+def core_range(num_core: int, rank: int, world: int):
+    """Contiguous core range of a rank (the last rank takes the remainder)."""
+    per = num_core // world
+    begin = rank * per
+    count = per if rank < world - 1 else num_core - begin
+    return begin, count
+
+
+def band_rows(height: int, rank: int, world: int):
+    """(row_begin, row_end, row_step) for spcbpt_launch: every world-th band of 8 rows, starting at band `rank`."""
+    return 8 * rank, height, world
+
+
+def rows_of_rank(height: int, rank: int, world: int):
+    return [y for y in range(height) if (y // 8) % world == rank]
+
+
+class _DevPtr:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can view it without copying."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr: int, nbytes: int, device):
+    import torch
+    return torch.as_tensor(_DevPtr(ptr, nbytes), device=device)
+
+
+def allgather_lvc_host(local: np.ndarray, group=None) -> np.ndarray:
+    """CPU/gloo variant of exchange 1 on host arrays of spcbpt_light_vertex records (tests)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64)
+    cnts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    cap = int(max(int(c) for c in cnts))
+    buf = torch.zeros(cap * VERTEX_BYTES, dtype=torch.uint8)
+    raw = np.frombuffer(local.tobytes(), dtype=np.uint8)
+    buf[: raw.shape[0]] = torch.from_numpy(raw.copy())
+    out = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    parts = [np.frombuffer(out[r][: int(cnts[r]) * VERTEX_BYTES].numpy().tobytes(), dtype=LIGHT_VERTEX_DTYPE) for r in range(world)]
+    return np.concatenate(parts)
+
+
+def allreduce_image_host(img: np.ndarray, group=None) -> np.ndarray:
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(img))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.numpy()
+
+
+class FrameExchanger:
+    """GPU (RCCL) exchanges for one Renderer per rank."""
+
+    def __init__(self, renderer, rank: int, world: int, device):
+        import torch
+        self.r = renderer
+        self.rank, self.world = rank, world
+        self.device = device
+        self.torch = torch
+        self.counts = torch.zeros(world, dtype=torch.int32, device=device)
+        self.gather_buf = None
+        self.cat_buf = None
+
+    def allgather_lvc(self):
+        """After `light trace` on every rank: gathers the shards and installs the global LVC in the context."""
+        torch = self.torch
+        import torch.distributed as dist
+        r = self.r
+        dv, dc, cap = r.lvc_export()
+        r.sync()  # the context's stream -> torch's stream hand-off
+        my_count = device_view(dc, 8, self.device).view(torch.int32)[:1]
+        dist.all_gather_into_tensor(self.counts, my_count.clone())
+        counts = self.counts.cpu().tolist()   # one small D2H per frame (the sampler build needs the total on the host anyway)
+        mx = max(counts)
+        nbytes = mx * VERTEX_BYTES
+        if self.gather_buf is None or self.gather_buf.numel() < self.world * nbytes:
+            self.gather_buf = torch.empty(self.world * max(nbytes, VERTEX_BYTES), dtype=torch.uint8, device=self.device)
+        shard = device_view(dv, cap * VERTEX_BYTES, self.device)[:nbytes]
+        out = self.gather_buf[: self.world * nbytes]
+        dist.all_gather_into_tensor(out, shard)
+        total = sum(counts)
+        if self.cat_buf is None or self.cat_buf.numel() < total * VERTEX_BYTES:
+            self.cat_buf = torch.empty(max(total, 1) * VERTEX_BYTES * 5 // 4, dtype=torch.uint8, device=self.device)
+        off = 0
+        for k, c in enumerate(counts):
+            self.cat_buf[off: off + c * VERTEX_BYTES].copy_(out[k * nbytes: k * nbytes + c * VERTEX_BYTES])
+            off += c * VERTEX_BYTES
+        torch.cuda.synchronize(self.device)
+        r.lvc_import_device(self.cat_buf.data_ptr(), total)
+        return total
+
+    def reduce_framebuffer(self):
+        """Sum of the per-rank accum buffers (disjoint bands, zero elsewhere) in place on every rank."""
+        torch = self.torch
+        import torch.distributed as dist
+        r = self.r
+        r.sync()
+        acc = device_view(r.accum_device_ptr(), r.width * r.height * 16, self.device).view(torch.float32)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(self.device)

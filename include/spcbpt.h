@@ -289,12 +289,62 @@ int spcbpt_trace_closest(spcbpt_ctx* ctx, const float* rays, int n,
                          float* out_t, int32_t* out_tri, float* out_uv);
 int spcbpt_trace_any(spcbpt_ctx* ctx, const float* rays, int n, int32_t* out_visible);
 
+/* Training records of the "pretrace" pass: values of TrainData::pathInfo_sample and TrainData::pathInfo_node
+ * (optixPathTracer.h:325-383).  begin_ind/end_ind index the node array; label_A holds the eye depth until the trees
+ * exist (node_label, device_thrust.cu:554-573); label_B is pre-filled for emitter vertices only. */
+typedef struct spcbpt_pretrace_path {
+    float contri[3];
+    float sample_pdf;
+    float fix_pdf;
+    int32_t begin_ind;
+    int32_t end_ind;
+    int32_t choice_id;
+    int32_t pixel_id[2];
+    int32_t valid;
+    int32_t pad;
+} spcbpt_pretrace_path; /* 48 bytes */
+
+typedef struct spcbpt_pretrace_node {
+    float a_position[3];
+    float b_position[3];
+    float a_dir[3];
+    float b_dir[3];
+    float a_normal[3];
+    float b_normal[3];
+    float peak_pdf;
+    int32_t path_id;
+    int32_t label_a;
+    int32_t label_b;
+    int32_t valid;
+    int32_t light_source;
+} spcbpt_pretrace_node; /* 96 bytes */
+
+/* Replaces preTracer_params_setup (optixPathTracer.cpp:479-490): threads per "pretrace" launch (reference 10000) and
+ * node slots per thread (reference PRETRACE_CONN_PADDING = 10, the maximum). */
+int spcbpt_set_pretrace(spcbpt_ctx* ctx, int num_core, int padding);
+
+/* The training set accumulated by "pretrace" launches (= neat_paths / neat_conns after valid_sample_gather,
+ * device_thrust.cu:457-493): counts, host copies, replacement (tests inject the oracle's records), reset. */
+int spcbpt_train_records_count(spcbpt_ctx* ctx, int* n_paths, int* n_nodes);
+int spcbpt_train_records_read(spcbpt_ctx* ctx, spcbpt_pretrace_path* paths, int cap_paths,
+                              spcbpt_pretrace_node* nodes, int cap_nodes);
+int spcbpt_train_records_import(spcbpt_ctx* ctx, const spcbpt_pretrace_path* paths, int n_paths,
+                                const spcbpt_pretrace_node* nodes, int n_nodes);
+int spcbpt_train_records_clear(spcbpt_ctx* ctx);
+
 /* Host-owned preprocessing = preprocessing() (optixPathTracer.cpp:552-608):
  * pretrace -> reweight -> subspace trees -> Q -> labels -> Gamma_0 -> Adam
  * training -> CMF Gamma.  Installs the result with spcbpt_set_subspace.
  * target_paths / target_q_paths are the reference's 2,000,000 each; smaller
  * values give a coarser but still valid tuple. */
 int spcbpt_preprocess(spcbpt_ctx* ctx, int target_paths, int target_q_paths, int train);
+/* The stages of spcbpt_preprocess one by one, on the records currently held (tests compare each with the oracle):
+ * stage 1 = sample_reweight + both subspace trees, 2 = Q from light passes (needs target_q_paths), 3 = node labels +
+ * outlier clean + Gamma_0, 4 = Adam training, 5 = CMF Gamma + install.  image_width is the 10x10-pixel tile pitch of
+ * sample_reweight (the reference hard-codes 1920). */
+int spcbpt_preprocess_stage(spcbpt_ctx* ctx, int stage, int arg);
+/* Intermediate results for tests / checkpoints: Gamma before the CMF transform (row-major 1000x1000). */
+int spcbpt_get_gamma(spcbpt_ctx* ctx, float* gamma);
 
 /* Read back the installed subspace tuple (checkpoint writer the reference lacks). */
 int spcbpt_get_subspace(spcbpt_ctx* ctx,

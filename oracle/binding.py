@@ -258,3 +258,95 @@ def tree_index(tree: np.ndarray, pnd: np.ndarray):
     out = np.zeros(a.shape[0], np.int32)
     lib().orc_tree_index(C.c_void_p(t.ctypes.data), t.shape[0], C.c_void_p(a.ctypes.data), a.shape[0], C.c_void_p(out.ctypes.data))
     return out
+
+
+# ---- preprocessing (oracle/preprocess_ref.h) --------------------------------------------------------------------
+def _pre_methods():
+    def pretrace(self, iteration, num_core=10000, padding=10, nthreads=None):
+        return self.l.orc_pretrace(self.h, iteration, num_core, padding, nthreads or self.nthreads)
+
+    def train_records(self):
+        p = self.pkg
+        a, b = C.c_int(), C.c_int()
+        self.l.orc_train_records_count(self.h, C.byref(a), C.byref(b))
+        paths = np.zeros(a.value, dtype=p.PRETRACE_PATH_DTYPE)
+        nodes = np.zeros(b.value, dtype=p.PRETRACE_NODE_DTYPE)
+        self.l.orc_train_records_read(self.h, C.c_void_p(paths.ctypes.data), C.c_void_p(nodes.ctypes.data))
+        return paths, nodes
+
+    def train_records_import(self, paths, nodes):
+        p = self.pkg
+        pa = np.ascontiguousarray(paths, dtype=p.PRETRACE_PATH_DTYPE)
+        no = np.ascontiguousarray(nodes, dtype=p.PRETRACE_NODE_DTYPE)
+        self.l.orc_train_records_import(self.h, C.c_void_p(pa.ctypes.data), pa.shape[0], C.c_void_p(no.ctypes.data), no.shape[0])
+
+    def train_records_clear(self):
+        self.l.orc_train_records_clear(self.h)
+
+    def preprocess_stage(self, stage, arg=0, nthreads=None):
+        rc = self.l.orc_preprocess_stage(self.h, stage, arg, nthreads or self.nthreads)
+        if rc != 0:
+            raise RuntimeError(f"orc_preprocess_stage({stage}) -> {rc}")
+
+    def get_gamma(self):
+        n = self.pkg.NUM_SUBSPACE
+        g = np.zeros((n, n), np.float32)
+        self.l.orc_get_gamma(self.h, C.c_void_p(g.ctypes.data))
+        return g
+
+    def get_q(self):
+        q = np.zeros(self.pkg.NUM_SUBSPACE, np.float32)
+        self.l.orc_get_q(self.h, C.c_void_p(q.ctypes.data))
+        return q
+
+    def get_cmf_gamma(self):
+        n = self.pkg.NUM_SUBSPACE
+        g = np.zeros((n, n), np.float32)
+        self.l.orc_get_cmf_gamma(self.h, C.c_void_p(g.ctypes.data))
+        return g
+
+    def get_tree(self, light: bool):
+        n = C.c_int()
+        self.l.orc_get_tree(self.h, int(light), None, 0, C.byref(n))
+        t = np.zeros(n.value, dtype=self.pkg.TREE_NODE_DTYPE)
+        self.l.orc_get_tree(self.h, int(light), C.c_void_p(t.ctypes.data), n.value, C.byref(n))
+        return t
+
+    def preprocess(self, target_paths, target_q_paths, train=True, num_core=10000, batch=20000):
+        self.train_records_clear()
+        it = 0
+        while self.train_records_count() < target_paths:
+            it += 1
+            self.pretrace(it, num_core)
+        n_train = target_paths // batch * batch if (train and target_paths >= batch) else target_paths
+        self.preprocess_stage(1)
+        self.preprocess_stage(2, target_q_paths)
+        self.preprocess_stage(3, n_train)
+        if train:
+            self.preprocess_stage(4, min(batch, n_train))
+        self.preprocess_stage(5)
+
+    def train_records_count(self):
+        a, b = C.c_int(), C.c_int()
+        self.l.orc_train_records_count(self.h, C.byref(a), C.byref(b))
+        return a.value
+
+    for f in (pretrace, train_records, train_records_import, train_records_clear, preprocess_stage, get_gamma, get_q, get_cmf_gamma,
+              get_tree, preprocess, train_records_count):
+        setattr(Oracle, f.__name__, f)
+
+
+_pre_methods()
+
+
+def build_tree(samples: np.ndarray, subspace_size: int, label_bias: int = 0):
+    """samples: (n, 10) float32 rows of position(3), dir(3), normal(3), weight."""
+    p = _pkg()
+    s = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, 10)
+    cap = max(16, 9 * 40 * s.shape[0])
+    out = np.zeros(cap, dtype=p.TREE_NODE_DTYPE)
+    n = C.c_int()
+    rc = lib().orc_build_tree(C.c_void_p(s.ctypes.data), s.shape[0], subspace_size, label_bias, C.c_void_p(out.ctypes.data), cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"orc_build_tree -> {rc}")
+    return out[:n.value].copy()

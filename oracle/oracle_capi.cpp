@@ -10,23 +10,12 @@
 #include <thread>
 #include <vector>
 
+#include "oracle_ctx.h"
 #include "spcbpt_ref.h"
 
 using namespace orc;
 
-struct orc_ctx {
-    Scene scene;
-    Params P;
-    std::vector<tree_node> eye_tree, light_tree;
-    std::vector<float> Q, CMFGamma;
-    std::vector<float4> accum;
-    std::vector<uint32_t> frame;
-    std::vector<BDPTVertex> lvc;
-    std::vector<uint8_t> lvc_valid;
-    SamplerStorage sampler_storage;
-    Counters counters;
-    bool count_events = true;
-};
+
 
 static void copy_tree(const spcbpt_tree_node* in, int n, std::vector<tree_node>& out) {
     out.resize(n);
@@ -66,7 +55,7 @@ orc_ctx* orc_create(const spcbpt_scene_desc* d) {
     c->P.scene = &c->scene;
     return c;
 }
-void orc_destroy(orc_ctx* c) { delete c; }
+void orc_destroy(orc_ctx* c) { orc_free_pre(c); delete c; }
 
 int orc_set_camera(orc_ctx* c, const float* eye, const float* U, const float* V, const float* W) {
     c->P.eye = load3(eye); c->P.U = load3(U); c->P.V = load3(V); c->P.W = load3(W);

@@ -79,6 +79,13 @@ SUBSPACE_DTYPE = np.dtype([("jump_bias", "<i4"), ("id", "<i4"), ("size", "<i4"),
 TREE_NODE_DTYPE = np.dtype([("mid", "<f4", 3), ("child", "<i4", 8), ("label", "<i4"), ("type", "<i4"), ("leaf", "<i4")])
 assert TREE_NODE_DTYPE.itemsize == C.sizeof(TreeNode)
 
+PRETRACE_PATH_DTYPE = np.dtype([("contri", "<f4", 3), ("sample_pdf", "<f4"), ("fix_pdf", "<f4"), ("begin_ind", "<i4"),
+                                ("end_ind", "<i4"), ("choice_id", "<i4"), ("pixel_id", "<i4", 2), ("valid", "<i4"), ("pad", "<i4")])
+PRETRACE_NODE_DTYPE = np.dtype([("a_position", "<f4", 3), ("b_position", "<f4", 3), ("a_dir", "<f4", 3), ("b_dir", "<f4", 3),
+                                ("a_normal", "<f4", 3), ("b_normal", "<f4", 3), ("peak_pdf", "<f4"), ("path_id", "<i4"),
+                                ("label_a", "<i4"), ("label_b", "<i4"), ("valid", "<i4"), ("light_source", "<i4")])
+assert PRETRACE_PATH_DTYPE.itemsize == 48 and PRETRACE_NODE_DTYPE.itemsize == 96
+
 # Algorithmic byte constants of SURVEY.md 8(d) (fixed by the survey, not tuned).
 BYTES = dict(node=64, tri=48, hit=72, mat=144, tex=16, tree=56, cmf=4, sub=20, jump=4, lvc=120, gq=4, lvcw=121, fb=36)
 
@@ -236,6 +243,13 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_trace_closest": [vp, vp, i32, vp, vp, vp],
         "spcbpt_trace_any": [vp, vp, i32, vp],
         "spcbpt_preprocess": [vp, i32, i32, i32],
+        "spcbpt_set_pretrace": [vp, i32, i32],
+        "spcbpt_train_records_count": [vp, C.POINTER(i32), C.POINTER(i32)],
+        "spcbpt_train_records_read": [vp, vp, i32, vp, i32],
+        "spcbpt_train_records_import": [vp, vp, i32, vp, i32],
+        "spcbpt_train_records_clear": [vp],
+        "spcbpt_preprocess_stage": [vp, i32, i32],
+        "spcbpt_get_gamma": [vp, vp],
         "spcbpt_get_subspace": [vp, vp, C.POINTER(i32), i32, vp, C.POINTER(i32), i32, vp, vp],
         "spcbpt_scene_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     }
@@ -256,7 +270,9 @@ EXPORTED_SYMBOLS = [
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
-    "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info",
+    "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
+    "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
+    "spcbpt_get_gamma",
 ]
 
 
@@ -351,6 +367,36 @@ class Renderer:
 
     def preprocess(self, target_paths=2_000_000, target_q_paths=2_000_000, train=True):
         self._chk(self.lib.spcbpt_preprocess(self.h, target_paths, target_q_paths, int(train)), "preprocess")
+
+    def set_pretrace(self, num_core=10000, padding=10):
+        self._chk(self.lib.spcbpt_set_pretrace(self.h, num_core, padding), "set_pretrace")
+
+    def preprocess_stage(self, stage: int, arg: int = 0):
+        self._chk(self.lib.spcbpt_preprocess_stage(self.h, stage, arg), f"preprocess_stage({stage})")
+
+    def train_records(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.lib.spcbpt_train_records_count(self.h, C.byref(a), C.byref(b)), "train_records_count")
+        paths = np.zeros(a.value, dtype=PRETRACE_PATH_DTYPE)
+        nodes = np.zeros(b.value, dtype=PRETRACE_NODE_DTYPE)
+        if a.value:
+            self._chk(self.lib.spcbpt_train_records_read(self.h, paths.ctypes.data, a.value, nodes.ctypes.data, max(b.value, 1)),
+                      "train_records_read")
+        return paths, nodes
+
+    def train_records_import(self, paths, nodes):
+        pa = np.ascontiguousarray(paths, dtype=PRETRACE_PATH_DTYPE)
+        no = np.ascontiguousarray(nodes, dtype=PRETRACE_NODE_DTYPE)
+        self._chk(self.lib.spcbpt_train_records_import(self.h, pa.ctypes.data, pa.shape[0], no.ctypes.data, no.shape[0]),
+                  "train_records_import")
+
+    def train_records_clear(self):
+        self._chk(self.lib.spcbpt_train_records_clear(self.h), "train_records_clear")
+
+    def get_gamma(self):
+        g = np.zeros((NUM_SUBSPACE, NUM_SUBSPACE), dtype=np.float32)
+        self._chk(self.lib.spcbpt_get_gamma(self.h, g.ctypes.data), "get_gamma")
+        return g
 
     # -- readback -----------------------------------------------------------
     def read_accum(self):

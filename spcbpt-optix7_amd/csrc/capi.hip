@@ -319,6 +319,7 @@ int Context::install_minimal_tuple() {
 
 Context::~Context() {
     resolve_spans();
+    free_preprocess();
     dev_free(d_nodes); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
     dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);

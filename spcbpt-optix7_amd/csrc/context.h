@@ -12,6 +12,8 @@
 
 namespace spc {
 
+struct Preprocessor;
+
 struct TimedSpan {
     std::string name;
     hipEvent_t a, b;
@@ -89,8 +91,16 @@ struct Context {
     int build_sampler();
     int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs);
     // preprocess.hip
+    Preprocessor* pre = nullptr;
+    spcbpt_pretrace_path* d_pre_paths = nullptr;
+    spcbpt_pretrace_node* d_pre_nodes = nullptr;
+    size_t pre_capacity = 0;
+    int pre_num_core = 100000, pre_padding = 10, pre_last_added = 0;
+    int set_pretrace(int num_core, int padding);
     int launch_pretrace(uint32_t iteration);
+    int preprocess_stage(int stage, int arg);
     int preprocess(int target_paths, int target_q_paths, bool train);
+    void free_preprocess();
 };
 
 }  // namespace spc

@@ -1,0 +1,121 @@
+"""Parity of the host-owned preprocessing driven through the C ABI against the oracle, stage by stage.
+Tolerances: pretrace records (device FP32 vs host FP32) within 2e-3 relative for >= 98 % of the matched records; stage 1
+(reweight + both trees) is pure host arithmetic on identical records -> bit-exact; Q within 2 % (different light-path FP
+flips); Gamma_0 and the trained Gamma within 2e-3 absolute on >= 99.5 % of the entries; CMF rows valid."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(pkg, ob, scene, w, h, lt=(4000, 64, 1)):
+    r = pkg.Renderer(scene, 0)
+    o = ob.Oracle(scene)
+    cam = scene.camera
+    for x in (r, o):
+        x.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], w / h)
+        x.resize(w, h)
+        x.set_light_trace(*lt)
+    return r, o
+
+
+def test_pretrace_records_match_oracle(gpu, pkg, ob):
+    scene = pkg.scenes.cornell_box()
+    r, o = _pair(pkg, ob, scene, 2048, 2048)   # large pixel grid: (pixel id, node count) identifies a record uniquely
+    r.set_pretrace(6000, 10)
+    r.launch("pretrace", 3)
+    o.pretrace(3, 6000)
+    pg, ng = r.train_records()
+    po, no = o.train_records()
+    assert abs(len(pg) - len(po)) <= 0.01 * len(po) and len(po) > 1500
+    key = lambda p: (int(p["pixel_id"][0]), int(p["pixel_id"][1]), int(p["end_ind"] - p["begin_ind"]))
+    table = {}
+    for i, p in enumerate(po):
+        table.setdefault(key(p), []).append(i)
+    matched = good = 0
+    for p in pg:
+        cands = table.get(key(p), [])
+        if len(cands) != 1:
+            continue
+        q = po[cands[0]]
+        matched += 1
+        a = np.concatenate([p["contri"], [p["sample_pdf"], p["fix_pdf"]]]).astype(np.float64)
+        b = np.concatenate([q["contri"], [q["sample_pdf"], q["fix_pdf"]]]).astype(np.float64)
+        na, nb = ng[p["begin_ind"]:p["end_ind"]], no[q["begin_ind"]:q["end_ind"]]
+        ok = np.allclose(a, b, rtol=2e-3, atol=1e-9) and np.allclose(na["peak_pdf"], nb["peak_pdf"], rtol=2e-3, atol=1e-12) \
+            and np.allclose(na["a_position"], nb["a_position"], atol=1e-4) and np.allclose(na["b_position"], nb["b_position"], atol=1e-4) \
+            and (na["label_a"] == nb["label_a"]).all() and (na["label_b"] == nb["label_b"]).all() and (na["light_source"] == nb["light_source"]).all()
+        good += bool(ok)
+    assert matched >= 0.9 * len(pg) and good >= 0.98 * matched, (len(pg), matched, good)
+
+
+def test_preprocessing_stages_match_oracle(gpu, pkg, ob):
+    scene = pkg.scenes.cornell_box()
+    r, o = _pair(pkg, ob, scene, 64, 64)
+    it = 0
+    while o.train_records_count() < 8000:
+        it += 1
+        o.pretrace(it, 4000)
+    paths, nodes = o.train_records()
+    r.train_records_import(paths, nodes)          # identical records on both sides
+    r.preprocess_stage(1); o.preprocess_stage(1)
+    pg, _ = r.train_records(); po, _ = o.train_records()
+    assert pg["contri"].tobytes() == po["contri"].tobytes()          # sample_reweight, bit exact
+    r.preprocess_stage(2, 40000); o.preprocess_stage(2, 40000)
+    r.preprocess_stage(3, 8000); o.preprocess_stage(3, 8000)
+    g0r, g0o = r.get_gamma(), o.get_gamma()
+    r.preprocess_stage(4, 2000); o.preprocess_stage(4, 2000)
+    g1r, g1o = r.get_gamma(), o.get_gamma()
+    r.preprocess_stage(5); o.preprocess_stage(5)
+    et, lt, q, cmf = r.get_subspace()
+    assert et.tobytes() == o.get_tree(False).tobytes()               # buildTreeBaseOnExistSample, bit exact
+    assert lt.tobytes() == o.get_tree(True).tobytes()
+    qo = o.get_q()
+    both = (q < 1e30) & (qo < 1e30)
+    assert ((q < 1e30) == (qo < 1e30)).mean() > 0.99
+    np.testing.assert_allclose(q[both].sum(), qo[both].sum(), rtol=5e-3)
+    big = both & (qo > 0.01 * qo[both].max())
+    np.testing.assert_allclose(q[big], qo[big], rtol=0.1)
+    assert (np.abs(g0r - g0o) <= 2e-3).mean() > 0.995
+    assert (np.abs(g1r - g1o) <= 2e-3).mean() > 0.995
+    np.testing.assert_allclose(g1r.sum(1), 1.0, rtol=2e-4)
+    assert (np.diff(cmf, axis=1) > 0).all() and (cmf[:, -1] == 1.0).all()
+    assert (np.abs(cmf - o.get_cmf_gamma()) <= 5e-3).mean() > 0.995
+
+
+def test_full_preprocess_gives_an_unbiased_trained_tuple(gpu, pkg, ob):
+    scene = pkg.scenes.cornell_box()
+    r, o = _pair(pkg, ob, scene, 128, 128, lt=(20000, 52, 1))
+    r.set_pretrace(20000, 10)
+    r.preprocess(target_paths=40000, target_q_paths=40000, train=True)
+    et, lt, q, cmf = r.get_subspace()
+    assert len(et) > 1 and len(lt) > 1 and len(set(et["label"][et["leaf"] == 1].tolist())) > 300
+    n = 48
+    for f in range(n):
+        r.launch("pt", f)
+    pt = r.read_accum()[..., :3].astype(np.float64)
+    r.clear_accum()
+    for f in range(n):
+        r.render_frame("SPCBPT_eye", f, launch_frame=100 + f)
+    sp = r.read_accum()[..., :3].astype(np.float64)
+    assert abs(sp.mean() - pt.mean()) / pt.mean() < 0.01
+    # the same tuple on the oracle renders the same image (classification + stage-1 sampling over 1000 subspaces)
+    o.set_light_trace(20000, 52, 1)
+    o.set_subspace(et, lt, q, cmf)
+    o.set_cmf_double(True)
+    r.clear_accum()
+    for f in range(2):
+        r.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
+    from tests.parity_util import image_parity
+    s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
+    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s
+
+
+def test_pretrace_needs_state(gpu, pkg):
+    r = pkg.Renderer(pkg.scenes.cornell_box(), 0)
+    with pytest.raises(pkg.SpcbptError):
+        r.launch("pretrace", 1)            # no camera / image size yet
+    with pytest.raises(pkg.SpcbptError):
+        r.preprocess_stage(1)              # no records
+    with pytest.raises(pkg.SpcbptError):
+        r.set_pretrace(100, 11)            # PRETRACE_CONN_PADDING is 10

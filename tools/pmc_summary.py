@@ -1,0 +1,53 @@
+"""Condenses the rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof_<tag>/) into profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (per-kernel calls / average ns)
+  profiles/<tag>_pmc_summary.json   per-kernel averages of the PMC passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss, SQ_*)
+  profiles/traffic_latest.json      HBM-side bytes per k_spcbpt launch, read by bench.py for roofline.traffic
+Usage: python tools/pmc_summary.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+summary = {}
+for f in sorted(glob.glob(os.path.join(src, "pmc_*_ours.csv"))):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in agg.items():
+        summary.setdefault(k, {})[c] = {"avg_per_launch": sum(v) / len(v), "launches": len(v)}
+for k, d in summary.items():
+    if "TCC_HIT_sum" in d and "TCC_MISS_sum" in d:
+        h, m = d["TCC_HIT_sum"]["avg_per_launch"], d["TCC_MISS_sum"]["avg_per_launch"]
+        d["l2_hit_rate"] = h / (h + m)
+    if "SQ_WAVE_CYCLES" in d and "SQ_WAIT_ANY" in d:
+        d["wait_any_frac"] = d["SQ_WAIT_ANY"]["avg_per_launch"] / d["SQ_WAVE_CYCLES"]["avg_per_launch"]
+notes = ("FETCH_SIZE / WRITE_SIZE are in KB per launch, collected in separate --pmc passes (TCC slot limits). "
+         "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a wide coalesced 16-B/lane stream and is "
+         "uncalibrated for other patterns; this kernel issues scattered 16-B/lane gathers, so hbm bytes are reported as a "
+         "range [FETCH_SIZE, 2*FETCH_SIZE] + WRITE_SIZE; Infinity-Cache hits are included in these memory-side counters.")
+out = {"tag": tag, "notes": notes, "kernels": summary}
+key = "spc::k_spcbpt<false>"
+if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[key]:
+    f = summary[key]["FETCH_SIZE"]["avg_per_launch"] * 1024.0
+    w = summary[key]["WRITE_SIZE"]["avg_per_launch"] * 1024.0
+    out["spcbpt_render_hbm_bytes_per_launch_low"] = f + w
+    out["spcbpt_render_hbm_bytes_per_launch_high"] = 2 * f + w
+    json.dump({"tag": tag, "spcbpt_render_hbm_bytes_per_launch": 2 * f + w,
+               "definition": "2*FETCH_SIZE + WRITE_SIZE (KB*1024) per k_spcbpt<false> launch, gfx950 FETCH_SIZE half-count correction applied; "
+                             "uncorrected lower bound = FETCH_SIZE + WRITE_SIZE = %.4g" % (f + w)},
+              open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+print("wrote", os.path.join(dst, f"{tag}_pmc_summary.json"))

@@ -188,6 +188,8 @@ int Context::launch_light(uint32_t frame) {
     if (rc) return rc;
     kp.counters = counting ? d_counters : nullptr;
     HIP_TRY(this, hipMemsetAsync(d_core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), stream));
+    HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), stream));
+    kp.path_counter = d_sampler_counts + 1;
     time_begin("light_trace");
     launch_light_trace(kp, counting, stream);
     time_end();
@@ -199,7 +201,6 @@ int Context::launch_light(uint32_t frame) {
     rc = ensure_temp(tb);
     if (rc) return rc;
     HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(d_temp, tb, d_core_counts, d_core_offsets, lt.core_count + 1, stream));
-    HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), stream));
     HIP_TRY(this, hipMemcpyAsync(d_sampler_counts, d_core_offsets + lt.core_count, sizeof(int), hipMemcpyDeviceToDevice, stream));
     launch_lvc_compact(d_scratch, d_core_counts, d_core_offsets, lt.core_count, lt.core_padding, d_lvc, d_keys, d_vals, d_weights,
                        d_sampler_counts, stream);

@@ -154,29 +154,34 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 // "while-while" traversal: all lanes first descend through internal nodes (lanes that already sit on a leaf wait), then
 // the wave processes leaves together, so the two code paths are not interleaved per iteration inside a divergent wave.
 static constexpr int kTravDone = 0x7fffffff;
+// pop the next stack entry into (node, leaf_count); leaf refs carry their count: 1<<31 | first<<3 | count (count <= 4).
+// A macro, not a lambda: a by-reference capture keeps node / leaf_count in scratch memory inside the loop.
+#define SPC_TRAV_POP()                                                                              \
+    do {                                                                                            \
+        if (st.sp == 0) { node = kTravDone; }                                                       \
+        else {                                                                                      \
+            const uint32_t w__ = st.pop();                                                          \
+            if (w__ & 0x80000000u) { node = ~(int)((w__ & 0x7fffffffu) >> 3); leaf_count = (int)(w__ & 7u); } \
+            else node = (int)w__;                                                                   \
+        }                                                                                           \
+    } while (0)
 template <bool ANY, bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 o, f3 d, float tmin, float tmax, HitRec& hit,
                       Counts<COUNT>& cn) {
     const f3 inv = safe_inv(d);
-    hit.t = tmax; hit.tri = -1; hit.u = hit.v = 0.0f;
+    float best_t = tmax, best_u = 0.0f, best_v = 0.0f;
+    int best_tri = -1;
     st.sp = 0;
     int node = 0;        // >= 0 internal node, < 0 leaf (~first triangle), kTravDone = finished
     int leaf_count = 0;
-    auto pop = [&]() {
-        if (st.sp == 0) { node = kTravDone; return; }
-        const uint32_t w = st.pop();
-        // leaf refs carry their count in the low bits of the pushed word: 1<<31 | first<<3 | count (count <= 4)
-        if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
-        else node = (int)w;
-    };
     while (node != kTravDone) {
         while (node >= 0 && node != kTravDone) {
             const float4 q0 = ldq(S.nodes, (size_t)node * 4 + 0), q1 = ldq(S.nodes, (size_t)node * 4 + 1);
             const float4 q2 = ldq(S.nodes, (size_t)node * 4 + 2), q3 = ldq(S.nodes, (size_t)node * 4 + 3);
             cn.add(C_NODE);
             float t0, t1;
-            const bool h0 = slab(q0, q1, o, inv, tmin, hit.t, t0);
-            const bool h1 = slab(q2, q3, o, inv, tmin, hit.t, t1);
+            const bool h0 = slab(q0, q1, o, inv, tmin, best_t, t0);
+            const bool h1 = slab(q2, q3, o, inv, tmin, best_t, t1);
             const int c0 = __float_as_int(q0.w), c1 = __float_as_int(q1.w);
             const int n0 = __float_as_int(q2.w), n1 = __float_as_int(q3.w);
             if (h0 && h1) {
@@ -190,31 +195,30 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
             } else if (h1) {
                 node = c1; leaf_count = n1;
             } else {
-                pop();
+                SPC_TRAV_POP();
             }
         }
         if (node == kTravDone) break;
-        {
-            const int first = ~node;
-            for (int i = 0; i < leaf_count; i++) {
-                const size_t base = (size_t)(first + i) * 4;
-                const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
-                cn.add(C_TRI);
-                bool cull = false;
-                if (!ANY) {
-                    // emitter flag lives in quad 3; only fetched for closest-hit rays
-                    cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
-                }
-                float t, u, v;
-                if (tri_test(a, b, c, o, d, tmin, hit.t, cull, t, u, v)) {
-                    hit.t = t; hit.tri = first + i; hit.u = u; hit.v = v;
-                    if (ANY) return true;
-                }
+        const int first = ~node;
+        for (int i = 0; i < leaf_count; i++) {
+            const size_t base = (size_t)(first + i) * 4;
+            const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
+            cn.add(C_TRI);
+            bool cull = false;
+            if (!ANY) {
+                // emitter flag lives in quad 3; only fetched for closest-hit rays
+                cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
             }
-            pop();
+            float t, u, v;
+            if (tri_test(a, b, c, o, d, tmin, best_t, cull, t, u, v)) {
+                best_t = t; best_tri = first + i; best_u = u; best_v = v;
+                if (ANY) { node = kTravDone; break; }
+            }
         }
+        if (node != kTravDone) SPC_TRAV_POP();
     }
-    return hit.tri >= 0;
+    hit.t = best_t; hit.tri = best_tri; hit.u = best_u; hit.v = best_v;
+    return best_tri >= 0;
 }
 
 // ---- materials / textures / hit geometry -------------------------------------

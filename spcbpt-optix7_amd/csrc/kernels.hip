@@ -238,18 +238,21 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                         const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
                         const int slot = p.jump[ss.jump_bias + k];
                         const float4* src = reinterpret_cast<const float4*>(p.lvc + slot);
-                        LightVertex b;
-                        float4* dst = reinterpret_cast<float4*>(&b);
-#pragma unroll
-                        for (int q = 0; q < 6; q++) dst[q] = src[q];
                         cn.add(C_CONN);
-                        // visibilityTest (cuProg.h:463-487)
-                        const f3 bias = ld3(b.position) - cur.c.pos;
+                        // visibilityTest (cuProg.h:463-487): only the position quad is fetched before the shadow ray, the other
+                        // 80 bytes of the light vertex after it (and only for unoccluded connections) — 21 fewer live registers
+                        // across the traversal
+                        const float4 bq0 = src[0];
+                        const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
                         const float len = sqrtf(dot(bias, bias));
                         const f3 sdir = bias / len;
                         HitRec sh;
                         cn.add(C_SHADOW);
                         if (!traverse<true, COUNT>(S, st, cur.c.pos, sdir, kEps, len - kEps, sh, cn)) {
+                            LightVertex b;
+                            float4* dst = reinterpret_cast<float4*>(&b);
+#pragma unroll
+                            for (int q = 0; q < 6; q++) dst[q] = src[q];
                             const float pmf = (float)path_count * pmf2 * pmf1;
                             f3 res = connect_vertices(p, cur, b, cn);
                             if (is_invalid(res)) res = mk3(0.0f);
@@ -375,9 +378,11 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
     const int local_core = blockIdx.x * BLOCK + threadIdx.x;
     Counts<COUNT> cn;
     cn.clear();
+    int paths_started = 0;
     if (local_core < p.core_count) {
         const DeviceScene& S = p.scene;
         const int core = p.core_begin + local_core;
+        int origins = 0;
         TravStack<BLOCK, STACK_LDS> st;
         st.init(s_stack, p.spill, p.spill_entries, (size_t)local_core);
         uint32_t seed = tea4((uint32_t)core, p.launch_frame);  // light sampling stream
@@ -415,6 +420,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
             v.material_id = (int16_t)L.id; v.subspace_id = (int16_t)ls.subspace; v.depth = 0; v.last_zone_id = 0;
             v.path_id = path_id; v.pad = 0;
             store(v);
+            origins++;
             if (!(nverts < p.core_padding)) break;
             // walk (hit_program.cu:341-438)
             f3 next_flux = mk3(0.0f);
@@ -489,7 +495,12 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
             if (!(nverts < p.core_padding)) break;
         }
         p.core_counts[local_core] = nverts;
+        paths_started = origins;
     }
+    // path_count of the sampler (#depth-0 vertices, device_thrust.cu:324-326): one atomic per wave, spread over the
+    // kernel's run time (a same-address atomic costs ~11 ns; per-wave atomics in the compaction kernel cost 0.9 ms)
+    for (int o = 32; o > 0; o >>= 1) paths_started += __shfl_down(paths_started, o, 64);
+    if ((threadIdx.x & 63) == 0 && paths_started) atomicAdd(p.path_counter, paths_started);
     cn.flush(p.counters);
 }
 
@@ -506,7 +517,6 @@ __global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int
                               int* __restrict__ sampler_counts) {
     // one thread per padded slot; only the filled slots (slot < count of its core) copy their 96-B record
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int start = 0;
     if (t < (long long)core_count * core_padding) {
         const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
         if (slot < core_counts[core]) {
@@ -524,11 +534,9 @@ __global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int
             keys[dst_i] = (uint32_t)v.subspace_id;
             vals[dst_i] = (uint32_t)dst_i;
             weights[dst_i] = w;
-            start = v.depth == 0 ? 1 : 0;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) start += __shfl_down(start, o, 64);
-    if ((threadIdx.x & 63) == 0 && start) atomicAdd(&sampler_counts[1], start);
+    (void)sampler_counts;
 }
 
 __global__ void k_fill_keys_from_lvc(const LightVertex* __restrict__ lvc, int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,

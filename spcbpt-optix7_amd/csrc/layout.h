@@ -100,6 +100,7 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     uint32_t launch_frame;
     LightVertex* lvc_scratch;   // core_count * core_padding padded slots
     int32_t* core_counts;       // vertices stored per core
+    int32_t* path_counter;      // number of light paths started (= depth-0 vertices) by this launch
     // instrumentation / traversal scratch
     uint32_t* work_counter;        // tile queue head of the persistent megakernel (zeroed before each launch)
     uint32_t n_tiles;              // 8x8 pixel tiles in the selected bands

@@ -73,7 +73,7 @@ void Context::resolve_spans() {
 }
 
 int Context::ensure_spill(size_t threads) {
-    const int entries = std::max(0, bvh_depth - kStackLds);
+    const int entries = std::max(0, 3 * bvh_depth - kStackLds);  // a 4-wide node pushes up to 3 children
     kp.spill_entries = entries;
     if (entries == 0) { kp.spill = nullptr; return 0; }
     const size_t need = threads * (size_t)entries;
@@ -427,7 +427,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     mesh.n_vertices = (int)(V.size() / 3); mesh.n_triangles = (int)(I.size() / 3);
     Lbvh bvh;
     build_lbvh(mesh, bvh);
-    c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 16); c->bvh_depth = bvh.depth;
+    c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 32); c->bvh_depth = bvh.depth;
     c->n_lights = (int)lights.size(); c->n_mats = (int)mats.size();
 
     CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size()));

@@ -165,6 +165,30 @@ static constexpr int kTravDone = 0x7fffffff;
             else node = (int)w__;                                                                   \
         }                                                                                           \
     } while (0)
+// slab test of the 4 child boxes of a node at once (SoA quads); misses get key 0xffffffff, hits the entry distance with
+// the slot index in the two low mantissa bits (t >= 0, so unsigned order = float order)
+SPC_DEV void slab4(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, f3 o, f3 inv,
+                   float tmin, float tmax, uint32_t key[4]) {
+    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
+    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float tx0 = (lox[i] - o.x) * inv.x, tx1 = (hix[i] - o.x) * inv.x;
+        const float ty0 = (loy[i] - o.y) * inv.y, ty1 = (hiy[i] - o.y) * inv.y;
+        const float tz0 = (loz[i] - o.z) * inv.z, tz1 = (hiz[i] - o.z) * inv.z;
+        const float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+        const float t1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+        key[i] = (t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
+    }
+}
+SPC_DEV int sel4i(const float4 q, uint32_t i) {
+    const float v = i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w));
+    return __float_as_int(v);
+}
+SPC_DEV uint32_t stack_word(int ref, int count) {
+    return ref >= 0 ? (uint32_t)ref : (0x80000000u | ((uint32_t)(~ref) << 3) | (uint32_t)count);
+}
+
 template <bool ANY, bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 o, f3 d, float tmin, float tmax, HitRec& hit,
                       Counts<COUNT>& cn) {
@@ -176,26 +200,31 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     int leaf_count = 0;
     while (node != kTravDone) {
         while (node >= 0 && node != kTravDone) {
-            const float4 q0 = ldq(S.nodes, (size_t)node * 4 + 0), q1 = ldq(S.nodes, (size_t)node * 4 + 1);
-            const float4 q2 = ldq(S.nodes, (size_t)node * 4 + 2), q3 = ldq(S.nodes, (size_t)node * 4 + 3);
-            cn.add(C_NODE);
-            float t0, t1;
-            const bool h0 = slab(q0, q1, o, inv, tmin, best_t, t0);
-            const bool h1 = slab(q2, q3, o, inv, tmin, best_t, t1);
-            const int c0 = __float_as_int(q0.w), c1 = __float_as_int(q1.w);
-            const int n0 = __float_as_int(q2.w), n1 = __float_as_int(q3.w);
-            if (h0 && h1) {
-                const bool first0 = ANY ? true : (t0 <= t1);
-                const int near_c = first0 ? c0 : c1, far_c = first0 ? c1 : c0;
-                const int near_n = first0 ? n0 : n1, far_n = first0 ? n1 : n0;
-                st.push(far_c >= 0 ? (uint32_t)far_c : (0x80000000u | ((uint32_t)(~far_c) << 3) | (uint32_t)far_n));
-                node = near_c; leaf_count = near_n;
-            } else if (h0) {
-                node = c0; leaf_count = n0;
-            } else if (h1) {
-                node = c1; leaf_count = n1;
-            } else {
+            const size_t nb = (size_t)node * NODE_QUADS;
+            const float4 lx = ldq(S.nodes, nb + 0), ly = ldq(S.nodes, nb + 1), lz = ldq(S.nodes, nb + 2);
+            const float4 hx = ldq(S.nodes, nb + 3), hy = ldq(S.nodes, nb + 4), hz = ldq(S.nodes, nb + 5);
+            const float4 refs = ldq(S.nodes, nb + 6), cnts = ldq(S.nodes, nb + 7);
+            cn.add(C_NODE, 2);  // one 128-B visit = two 64-B units of the algorithmic-bytes table
+            uint32_t k[4];
+            slab4(lx, ly, lz, hx, hy, hz, o, inv, tmin, best_t, k);
+            if (!ANY) {  // sort the four keys ascending: nearest child first (5 compare-exchanges)
+#define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
+                SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
+#undef SPC_CSWAP
+            } else {     // any-hit: order is irrelevant, only compact the hits to the front
+#define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
+                SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
+#undef SPC_CSWAP
+            }
+            if (k[0] == 0xffffffffu) {
                 SPC_TRAV_POP();
+            } else {
+                // push the farther hits, farthest first, so the nearest pops first
+                if (k[3] != 0xffffffffu) st.push(stack_word(sel4i(refs, k[3] & 3u), sel4i(cnts, k[3] & 3u)));
+                if (k[2] != 0xffffffffu) st.push(stack_word(sel4i(refs, k[2] & 3u), sel4i(cnts, k[2] & 3u)));
+                if (k[1] != 0xffffffffu) st.push(stack_word(sel4i(refs, k[1] & 3u), sel4i(cnts, k[1] & 3u)));
+                node = sel4i(refs, k[0] & 3u);
+                leaf_count = sel4i(cnts, k[0] & 3u);
             }
         }
         if (node == kTravDone) break;

@@ -8,13 +8,13 @@
 namespace spc {
 
 // ---- software LBVH ---------------------------------------------------------
-// One node = 64 B = 4 x float4, both child boxes inline (a visit is ONE 64-B fetch):
-//   q0 = (lo0.xyz, as_float(child0))   q1 = (hi0.xyz, as_float(child1))
-//   q2 = (lo1.xyz, as_float(count0))   q3 = (hi1.xyz, as_float(count1))
-// child >= 0: internal node index.  child < 0: leaf, first triangle = ~child,
-// count in the matching q2/q3 slot (1..LEAF_MAX).
+// One node = 128 B = 8 x float4: a 4-wide node folded from the binary radix tree (lbvh.cpp), SoA per axis so a visit is
+// ONE round trip of eight independent 16-B loads:
+//   q0 = lo.x[4] q1 = lo.y[4] q2 = lo.z[4] q3 = hi.x[4] q4 = hi.y[4] q5 = hi.z[4] q6 = as_float(child ref[4]) q7 = as_float(count[4])
+// ref >= 0: internal node index.  ref < 0: leaf, first triangle = ~ref, count 1..LEAF_MAX.  Empty slot: ref = 0x7fffffff and
+// a point box at 1e30 (never hit; an inverted box WOULD be hit by the min/max slab test).
 static const int LEAF_MAX = 4;
-static const int NODE_QUADS = 4;
+static const int NODE_QUADS = 8;
 
 // One triangle = 64 B = 4 x float4 in BVH order; the intersection test reads the
 // first three quads (48 B), hit shading reads all four:
@@ -67,7 +67,7 @@ enum CounterSlot {
 };
 
 struct DeviceScene {
-    const float* nodes;      // float4 x NODE_QUADS per node
+    const float* nodes;      // float4 x NODE_QUADS per 4-wide node
     const float* tris;       // float4 x TRI_QUADS per triangle (BVH order)
     const int32_t* tri_orig; // BVH order -> caller's triangle index (quad-light triangles follow the scene's)
     const DMaterial* mats;

@@ -259,9 +259,81 @@ struct Builder {
     }
 };
 
+// ---- 2-wide -> 4-wide collapse ---------------------------------------------------------------------------------------
+// A traversal step is one dependent memory round trip whatever the node holds, and the megakernel is bound by that latency
+// (69 % of wave-cycles in SQ_WAIT_ANY with 2-wide nodes), so the binary radix tree is folded into 4-wide nodes: the child with
+// the largest surface area is replaced by its own two children until four slots are used.  128-B node, SoA per axis:
+//   q0 = lo.x[4] q1 = lo.y[4] q2 = lo.z[4] q3 = hi.x[4] q4 = hi.y[4] q5 = hi.z[4] q6 = child ref[4] q7 = leaf count[4]
+// ref >= 0 internal node, ref < 0 leaf (~first triangle), empty slot: ref = 0x7fffffff with a point box at 1e30.
+namespace {
+struct Slot { float lo[3], hi[3]; int ref, count; };
+struct Collapser {
+    const std::vector<float>& bin;
+    std::vector<float>& out;
+    int max_depth = 0;
+    Collapser(const std::vector<float>& b, std::vector<float>& o) : bin(b), out(o) {}
+    static int geti(const float* p) { int v; memcpy(&v, p, 4); return v; }
+    void children_of(int bnode, Slot& a, Slot& b) const {
+        const float* q = &bin[(size_t)bnode * 16];
+        for (int k = 0; k < 3; k++) { a.lo[k] = q[k]; a.hi[k] = q[4 + k]; b.lo[k] = q[8 + k]; b.hi[k] = q[12 + k]; }
+        a.ref = geti(q + 3); b.ref = geti(q + 7); a.count = geti(q + 11); b.count = geti(q + 15);
+    }
+    static float area(const Slot& s) {
+        float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    void emit(int bnode, int out_index, int depth) {
+        max_depth = std::max(max_depth, depth);
+        Slot s[4];
+        int n = 2;
+        children_of(bnode, s[0], s[1]);
+        if (s[1].count == 0 && s[1].ref < 0) n = 1;  // degenerate root of a tiny scene: second child is an empty leaf
+        while (n < 4) {
+            int best = -1;
+            float best_a = -1.0f;
+            for (int i = 0; i < n; i++)
+                if (s[i].ref >= 0 && area(s[i]) > best_a) { best_a = area(s[i]); best = i; }
+            if (best < 0) break;
+            Slot a, b;
+            children_of(s[best].ref, a, b);
+            s[best] = a;
+            s[n++] = b;
+        }
+        for (int i = 0; i < n; i++)
+            if (s[i].ref >= 0) {
+                const int idx = (int)(out.size() / 32);
+                out.resize(out.size() + 32);
+                emit(s[i].ref, idx, depth + 1);
+                s[i].ref = idx;
+                s[i].count = 0;
+            }
+        float* q = &out[(size_t)out_index * 32];
+        for (int i = 0; i < 4; i++) {
+            const bool used = i < n;
+            for (int k = 0; k < 3; k++) {
+                // empty slot: a point box at 1e30 (|t| >= 1e30 > any tmax).  NOT an inverted box: the min/max slab test is
+                // symmetric in lo/hi, an inverted box would be hit by every ray
+                q[4 * k + i] = used ? s[i].lo[k] : 1e30f;
+                q[12 + 4 * k + i] = used ? s[i].hi[k] : 1e30f;
+            }
+            int ref = used ? s[i].ref : 0x7fffffff, cnt = used ? s[i].count : 0;
+            memcpy(q + 24 + i, &ref, 4);
+            memcpy(q + 28 + i, &cnt, 4);
+        }
+    }
+};
+}  // namespace
+
 void build_lbvh(const HostMesh& mesh, Lbvh& out) {
     Builder b(mesh, out);
     b.run();
+    std::vector<float> binary;
+    binary.swap(out.nodes);
+    out.nodes.assign(32, 0.0f);
+    Collapser c(binary, out.nodes);
+    c.emit(0, 0, 1);
+    out.binary_depth = out.depth;
+    out.depth = c.max_depth;
 }
 
 }  // namespace spc

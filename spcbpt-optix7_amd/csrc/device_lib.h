@@ -167,15 +167,16 @@ static constexpr int kTravDone = 0x7fffffff;
     } while (0)
 // slab test of the 4 child boxes of a node at once (SoA quads); misses get key 0xffffffff, hits the entry distance with
 // the slot index in the two low mantissa bits (t >= 0, so unsigned order = float order)
-SPC_DEV void slab4(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, f3 o, f3 inv,
+SPC_DEV void slab4(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, f3 ood, f3 inv,
                    float tmin, float tmax, uint32_t key[4]) {
     const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
     const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float tx0 = (lox[i] - o.x) * inv.x, tx1 = (hix[i] - o.x) * inv.x;
-        const float ty0 = (loy[i] - o.y) * inv.y, ty1 = (hiy[i] - o.y) * inv.y;
-        const float tz0 = (loz[i] - o.z) * inv.z, tz1 = (hiz[i] - o.z) * inv.z;
+        // plane distance as one FMA: b * inv - o * inv (ood = o * inv is per-ray)
+        const float tx0 = fmaf(lox[i], inv.x, -ood.x), tx1 = fmaf(hix[i], inv.x, -ood.x);
+        const float ty0 = fmaf(loy[i], inv.y, -ood.y), ty1 = fmaf(hiy[i], inv.y, -ood.y);
+        const float tz0 = fmaf(loz[i], inv.z, -ood.z), tz1 = fmaf(hiz[i], inv.z, -ood.z);
         const float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
         const float t1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
         key[i] = (t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
@@ -193,6 +194,7 @@ template <bool ANY, bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 o, f3 d, float tmin, float tmax, HitRec& hit,
                       Counts<COUNT>& cn) {
     const f3 inv = safe_inv(d);
+    const f3 ood = o * inv;
     float best_t = tmax, best_u = 0.0f, best_v = 0.0f;
     int best_tri = -1;
     st.sp = 0;
@@ -206,7 +208,7 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
             const float4 refs = ldq(S.nodes, nb + 6), cnts = ldq(S.nodes, nb + 7);
             cn.add(C_NODE, 2);  // one 128-B visit = two 64-B units of the algorithmic-bytes table
             uint32_t k[4];
-            slab4(lx, ly, lz, hx, hy, hz, o, inv, tmin, best_t, k);
+            slab4(lx, ly, lz, hx, hy, hz, ood, inv, tmin, best_t, k);
             if (!ANY) {  // sort the four keys ascending: nearest child first (5 compare-exchanges)
 #define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
                 SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)

@@ -352,6 +352,18 @@ int spcbpt_get_subspace(spcbpt_ctx* ctx,
                         spcbpt_tree_node* light_tree, int* n_light, int cap_light,
                         float* q, float* cmf_gamma);
 
+/* `.scene` + OBJ ingestion: replaces LoadScene (OptiXPathTracer/sceneLoader.cpp:47-308) and the
+ * flattening Scene_shift does (OptiXPathTracer/scene_shift.cpp:32-328).  data_root plays SAMPLES_DIR "/data": mesh and
+ * texture paths of the file are relative to it (back-slashes accepted).  The desc points into the handle's storage
+ * and stays valid until spcbpt_scene_file_free.  Needs no GPU. */
+typedef struct spcbpt_scene_file spcbpt_scene_file;
+int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt_scene_file** out);
+int spcbpt_scene_file_desc(spcbpt_scene_file* s, spcbpt_scene_desc* desc);
+int spcbpt_scene_file_camera(spcbpt_scene_file* s, float eye[3], float lookat[3], float up[3], float* fov_y_deg,
+                             int* width, int* height);
+const char* spcbpt_scene_file_warnings(spcbpt_scene_file* s);
+int spcbpt_scene_file_free(spcbpt_scene_file* s);
+
 /* Scene statistics after create. */
 int spcbpt_scene_info(spcbpt_ctx* ctx, int* n_triangles, int* n_bvh_nodes, int* bvh_depth);
 

@@ -168,6 +168,46 @@ class Scene:
         return sd, (v, i, m, t, mats, texs, tex_keep, ls)
 
 
+def load_scene_file(scene_path: str, data_root: str):
+    """Parses a reference-format `.scene` file with the library's C++ loader (spcbpt_scene_file_load) and copies the
+    result into a Scene.  Returns (scene, warnings)."""
+    lib = load_library()
+    h = C.c_void_p()
+    rc = lib.spcbpt_scene_file_load(scene_path.encode(), data_root.encode(), C.byref(h))
+    if rc != 0:
+        raise SpcbptError(f"spcbpt_scene_file_load({scene_path}) failed ({rc})")
+    try:
+        d = SceneDesc()
+        lib.spcbpt_scene_file_desc(h, C.byref(d))
+        nv, nt = d.n_vertices, d.n_triangles
+        as_np = lambda ptr, ct, n: np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,)).copy() if n else np.zeros(0, ct)
+        V = as_np(d.vertices, C.c_float, 3 * nv).reshape(-1, 3)
+        UV = as_np(d.texcoords, C.c_float, 2 * nv).reshape(-1, 2)
+        I = as_np(d.indices, C.c_uint32, 3 * nt).reshape(-1, 3)
+        M = as_np(d.tri_material, C.c_int32, nt)
+        mats = []
+        for k in range(d.n_materials):
+            m = d.materials[k]
+            mats.append(dict(color=tuple(m.base_color), metallic=m.metallic, roughness=m.roughness, albedo_tex=m.albedo_tex))
+        lights = []
+        for k in range(d.n_lights):
+            l = d.lights[k]
+            lights.append(dict(position=tuple(l.position), u=tuple(l.u), v=tuple(l.v), emission=tuple(l.emission), div_level=l.div_level))
+        texs = []
+        for k in range(d.n_textures):
+            t = d.textures[k]
+            texs.append(np.ctypeslib.as_array(C.cast(t.rgba, C.POINTER(C.c_uint8)), shape=(t.height, t.width, 4)).copy())
+        eye, look, up = (np.zeros(3, np.float32) for _ in range(3))
+        fov, w, hh = C.c_float(), C.c_int(), C.c_int()
+        lib.spcbpt_scene_file_camera(h, _fp(eye), _fp(look), _fp(up), C.byref(fov), C.byref(w), C.byref(hh))
+        cam = dict(eye=tuple(eye), lookat=tuple(look), up=tuple(up), fov=fov.value, width=w.value, height=hh.value)
+        warn = lib.spcbpt_scene_file_warnings(h).decode()
+        return Scene(vertices=V, indices=I, tri_material=M, materials=mats, lights=lights, texcoords=UV, textures=texs,
+                     camera=cam, name=os.path.basename(scene_path)), warn
+    finally:
+        lib.spcbpt_scene_file_free(h)
+
+
 def camera_frame(eye, lookat, up, fov_y_deg, aspect):
     """sutil::Camera::UVWFrame (sutil/Camera.cpp:34-45) in float32."""
     f = np.float32
@@ -250,6 +290,10 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_train_records_clear": [vp],
         "spcbpt_preprocess_stage": [vp, i32, i32],
         "spcbpt_get_gamma": [vp, vp],
+        "spcbpt_scene_file_load": [C.c_char_p, C.c_char_p, C.POINTER(vp)],
+        "spcbpt_scene_file_desc": [vp, C.POINTER(SceneDesc)],
+        "spcbpt_scene_file_camera": [vp, f32p, f32p, f32p, f32p, C.POINTER(i32), C.POINTER(i32)],
+        "spcbpt_scene_file_free": [vp],
         "spcbpt_get_subspace": [vp, vp, C.POINTER(i32), i32, vp, C.POINTER(i32), i32, vp, vp],
         "spcbpt_scene_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     }
@@ -259,6 +303,8 @@ def load_library(path: str = LIB_PATH):
         fn.restype = C.c_int
     lib.spcbpt_last_error.argtypes = [vp]
     lib.spcbpt_last_error.restype = C.c_char_p
+    lib.spcbpt_scene_file_warnings.argtypes = [vp]
+    lib.spcbpt_scene_file_warnings.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -272,7 +318,8 @@ EXPORTED_SYMBOLS = [
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
-    "spcbpt_get_gamma",
+    "spcbpt_get_gamma", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
+    "spcbpt_scene_file_warnings", "spcbpt_scene_file_free",
 ]
 
 

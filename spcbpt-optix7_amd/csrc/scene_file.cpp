@@ -1,0 +1,293 @@
+// `.scene` + OBJ ingestion: the input format of the reference app.
+//   grammar      OptiXPathTracer/sceneLoader.cpp:47-308 (LoadScene): line oriented, '#' in column 0 = comment, a block starts at
+//                a line that sscanf's as `material <name>` or merely CONTAINS `light`, `properties`, `cameraSetting` or `mesh`, and
+//                runs to the first line containing '}'
+//   hand-off     OptiXPathTracer/scene_shift.cpp:32-328: only color / metallic / roughness / albedo texture reach the renderer
+//                (q17), the k-th mesh block uses the k-th pushed material, OBJ normals are discarded, missing UVs are zero
+// OBJ reading follows what the old tinyobj API gives scene_shift.cpp (triangulated fans, one vertex per distinct v/vt pair).
+// Textures: binary PPM (P6) only — the reference decodes JPEG/PNG through stb_image, which is not part of this build; other
+// formats are reported in the warnings string and the material renders with its flat colour.
+// PARITY UNPINNED: the reference's loader cannot be compiled here (sutil.h needs the CMake-generated sampleConfig.h).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spcbpt.h"
+
+struct spcbpt_scene_file {
+    std::vector<float> V, UV;
+    std::vector<uint32_t> I;
+    std::vector<int32_t> M;
+    std::vector<spcbpt_material> materials;
+    std::vector<spcbpt_quad_light> lights;
+    std::vector<std::vector<uint8_t>> tex_pixels;
+    std::vector<spcbpt_texture> textures;
+    float eye[3] = {0, 0, 0}, lookat[3] = {0, 0, -1}, up[3] = {0, 1, 0};
+    float fov = 35.0f;
+    int width = 1920, height = 1001;  // sceneLoader.cpp:201-203 defaults (parsed, ignored by the app)
+    int n_mesh_blocks = 0;
+    std::string warnings;
+};
+
+namespace {
+
+const int kMaxLine = 2048;
+
+struct MatParam {  // MaterialParameter defaults (material_parameters.h:16-32)
+    float color[3] = {1, 1, 1};
+    float metallic = 0.0f, roughness = 0.5f;
+    std::string tex = "None";
+};
+
+std::string fix_slashes(std::string p) {
+    for (auto& ch : p) if (ch == '\\') ch = '/';
+    return p;
+}
+
+bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0};
+    int maxv = 0;
+    bool ok = fscanf(f, "%2s", magic) == 1 && strcmp(magic, "P6") == 0;
+    auto next_int = [&](int& v) {
+        int c;
+        while ((c = fgetc(f)) != EOF) {
+            if (c == '#') { while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }
+            if (c > ' ') { ungetc(c, f); break; }
+        }
+        return fscanf(f, "%d", &v) == 1;
+    };
+    ok = ok && next_int(w) && next_int(h) && next_int(maxv) && maxv == 255 && w > 0 && h > 0 && (long long)w * h < (1ll << 28);
+    if (ok) {
+        fgetc(f);
+        std::vector<uint8_t> rgb((size_t)3 * w * h);
+        ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
+        if (ok) {
+            rgba.resize((size_t)4 * w * h);
+            for (size_t i = 0; i < (size_t)w * h; i++) { rgba[4 * i] = rgb[3 * i]; rgba[4 * i + 1] = rgb[3 * i + 1]; rgba[4 * i + 2] = rgb[3 * i + 2]; rgba[4 * i + 3] = 255; }
+        }
+    }
+    fclose(f);
+    return ok;
+}
+
+// Minimal OBJ reader: v, vt, f (fan triangulation, negative indices, v / v/vt / v//vn / v/vt/vn).
+bool load_obj(const std::string& path, spcbpt_scene_file& s, int material) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    std::vector<float> pos, tc;
+    std::map<std::pair<int, int>, uint32_t> cache;
+    char line[kMaxLine];
+    auto vertex = [&](int vi, int ti) -> uint32_t {
+        auto key = std::make_pair(vi, ti);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+        uint32_t id = (uint32_t)(s.V.size() / 3);
+        s.V.push_back(pos[3 * (size_t)vi]); s.V.push_back(pos[3 * (size_t)vi + 1]); s.V.push_back(pos[3 * (size_t)vi + 2]);
+        if (ti >= 0) { s.UV.push_back(tc[2 * (size_t)ti]); s.UV.push_back(tc[2 * (size_t)ti + 1]); }
+        else { s.UV.push_back(0.0f); s.UV.push_back(0.0f); }  // scene_shift.cpp:204-207
+        cache[key] = id;
+        return id;
+    };
+    while (fgets(line, kMaxLine, f)) {
+        if (line[0] == 'v' && line[1] == ' ') {
+            float x, y, z;
+            if (sscanf(line + 2, "%f %f %f", &x, &y, &z) == 3) { pos.push_back(x); pos.push_back(y); pos.push_back(z); }
+        } else if (line[0] == 'v' && line[1] == 't') {
+            float u = 0, v = 0;
+            if (sscanf(line + 2, "%f %f", &u, &v) >= 1) { tc.push_back(u); tc.push_back(v); }
+        } else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t')) {
+            std::vector<uint32_t> poly;
+            char* p = line + 1;
+            while (*p) {
+                while (*p == ' ' || *p == '\t') p++;
+                if (!*p || *p == '\n' || *p == '\r') break;
+                int vi = 0, ti = 0;
+                bool has_t = false;
+                char* end;
+                vi = (int)strtol(p, &end, 10);
+                if (end == p) break;
+                p = end;
+                if (*p == '/') {
+                    p++;
+                    if (*p != '/') { ti = (int)strtol(p, &end, 10); has_t = end != p; p = end; }
+                    if (*p == '/') { p++; strtol(p, &end, 10); p = end; }
+                }
+                const int nv = (int)(pos.size() / 3), nt = (int)(tc.size() / 2);
+                vi = vi < 0 ? nv + vi : vi - 1;
+                ti = has_t ? (ti < 0 ? nt + ti : ti - 1) : -1;
+                if (vi < 0 || vi >= nv) { fclose(f); return false; }
+                if (ti >= nt) ti = -1;
+                poly.push_back(vertex(vi, ti));
+            }
+            for (size_t k = 2; k < poly.size(); k++) {
+                s.I.push_back(poly[0]); s.I.push_back(poly[k - 1]); s.I.push_back(poly[k]);
+                s.M.push_back(material);
+            }
+        }
+    }
+    fclose(f);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt_scene_file** out) {
+    if (!scene_path || !out) return SPCBPT_ERR_INVALID_ARG;
+    *out = nullptr;
+    FILE* file = fopen(scene_path, "r");
+    if (!file) return SPCBPT_ERR_INVALID_ARG;
+    const std::string root = data_root ? std::string(data_root) : std::string();
+    spcbpt_scene_file* s = new spcbpt_scene_file();
+    std::map<std::string, MatParam> materials_map;
+    std::map<std::string, int> texture_ids;
+    std::vector<std::string> texture_paths;
+    std::vector<MatParam> mesh_materials;
+    std::vector<std::string> mesh_files;
+    char line[kMaxLine];
+    while (fgets(line, kMaxLine, file)) {
+        if (line[0] == '#') continue;
+        char name[kMaxLine] = {0};
+        if (sscanf(line, " material %2047s", name) == 1) {  // sceneLoader.cpp:77-126
+            MatParam m;
+            char tex_name[kMaxLine] = "None";
+            float dummy[3];
+            while (fgets(line, kMaxLine, file)) {
+                if (strchr(line, '}')) break;
+                sscanf(line, " name %2047s", name);
+                sscanf(line, " color %f %f %f", &m.color[0], &m.color[1], &m.color[2]);
+                sscanf(line, " albedoTex %2047s", tex_name);
+                sscanf(line, " metallic %f", &m.metallic);
+                sscanf(line, " roughness %f", &m.roughness);
+                (void)dummy;  // emission / subsurface / specular / ... are parsed by the reference but never reach the renderer (q17)
+            }
+            m.tex = tex_name;
+            materials_map[name] = m;
+        }
+        if (strstr(line, "light")) {  // sceneLoader.cpp:130-193
+            float position[3] = {0, 0, 0}, emission[3] = {0, 0, 0}, v1[3] = {0, 0, 0}, v2[3] = {0, 0, 0};
+            char light_type[64] = "None";
+            int div = 1;
+            while (fgets(line, kMaxLine, file)) {
+                if (strchr(line, '}')) break;
+                sscanf(line, " position %f %f %f", &position[0], &position[1], &position[2]);
+                sscanf(line, " emission %f %f %f", &emission[0], &emission[1], &emission[2]);
+                sscanf(line, " v1 %f %f %f", &v1[0], &v1[1], &v1[2]);
+                sscanf(line, " v2 %f %f %f", &v2[0], &v2[1], &v2[2]);
+                sscanf(line, " type %63s", light_type);
+                sscanf(line, " divLevel %d", &div);
+            }
+            if (strcmp(light_type, "Quad") == 0) {
+                spcbpt_quad_light L;
+                for (int k = 0; k < 3; k++) { L.position[k] = position[k]; L.u[k] = v1[k] - position[k]; L.v[k] = v2[k] - position[k]; L.emission[k] = emission[k]; }
+                L.div_level = div;
+                s->lights.push_back(L);
+            } else {
+                s->warnings += std::string("light of type '") + light_type + "' skipped (only Quad is functional, SURVEY A9); ";
+            }
+        }
+        if (strstr(line, "properties")) {  // sceneLoader.cpp:205-217
+            while (fgets(line, kMaxLine, file)) {
+                if (strchr(line, '}')) break;
+                sscanf(line, " width %i", &s->width);
+                sscanf(line, " height %i", &s->height);
+            }
+        }
+        if (strstr(line, "cameraSetting")) {  // sceneLoader.cpp:221-254
+            while (fgets(line, kMaxLine, file)) {
+                if (strchr(line, '}')) break;
+                sscanf(line, " eye %f %f %f", &s->eye[0], &s->eye[1], &s->eye[2]);
+                sscanf(line, " lookat %f %f %f", &s->lookat[0], &s->lookat[1], &s->lookat[2]);
+                sscanf(line, " up %f %f %f", &s->up[0], &s->up[1], &s->up[2]);
+                sscanf(line, " fov %f", &s->fov);
+            }
+        }
+        if (strstr(line, "mesh")) {  // sceneLoader.cpp:258-300
+            while (fgets(line, kMaxLine, file)) {
+                if (strchr(line, '}')) break;
+                char path[kMaxLine];
+                if (sscanf(line, " file %2047s", path) == 1) mesh_files.push_back(fix_slashes(path));
+                if (sscanf(line, " material %2047s", path) == 1) {
+                    auto it = materials_map.find(path);
+                    if (it != materials_map.end()) mesh_materials.push_back(it->second);
+                    else s->warnings += std::string("could not find material ") + path + "; ";
+                }
+            }
+            s->n_mesh_blocks++;
+        }
+    }
+    fclose(file);
+    // materials: the k-th mesh uses the k-th pushed material (scene_shift.cpp:235)
+    for (size_t k = 0; k < mesh_materials.size(); k++) {
+        const MatParam& p = mesh_materials[k];
+        spcbpt_material m;
+        memset(&m, 0, sizeof(m));
+        memcpy(m.base_color, p.color, 12);
+        m.metallic = p.metallic; m.roughness = p.roughness;
+        m.specular = 0.5f; m.sheen_tint = 0.5f; m.clearcoat_gloss = 1.0f;  // MaterialData() defaults (q17)
+        if (p.tex != "None") {
+            auto it = texture_ids.find(p.tex);
+            if (it != texture_ids.end()) m.albedo_tex = it->second;
+            else {
+                std::vector<uint8_t> px;
+                int w = 0, h = 0;
+                const std::string tp = root + "/" + fix_slashes(p.tex);
+                if (load_ppm(tp, px, w, h)) {
+                    s->tex_pixels.push_back(std::move(px));
+                    spcbpt_texture t;
+                    t.rgba = nullptr; t.width = w; t.height = h;
+                    s->textures.push_back(t);
+                    texture_ids[p.tex] = (int)s->textures.size();
+                    m.albedo_tex = (int)s->textures.size();
+                } else {
+                    texture_ids[p.tex] = 0;
+                    s->warnings += "texture " + p.tex + " not loaded (only binary PPM is decoded here); ";
+                }
+            }
+        }
+        s->materials.push_back(m);
+    }
+    for (size_t k = 0; k < s->textures.size(); k++) s->textures[k].rgba = s->tex_pixels[k].data();
+    for (size_t k = 0; k < mesh_files.size(); k++) {
+        if (k >= s->materials.size()) { s->warnings += "mesh " + mesh_files[k] + " has no material; skipped; "; continue; }
+        if (!load_obj(root + "/" + mesh_files[k], *s, (int)k)) s->warnings += "mesh " + mesh_files[k] + " could not be read; ";
+    }
+    *out = s;
+    return SPCBPT_OK;
+}
+
+int spcbpt_scene_file_desc(spcbpt_scene_file* s, spcbpt_scene_desc* d) {
+    if (!s || !d) return SPCBPT_ERR_INVALID_ARG;
+    d->vertices = s->V.data(); d->texcoords = s->UV.data(); d->n_vertices = (int32_t)(s->V.size() / 3);
+    d->indices = s->I.data(); d->tri_material = s->M.data(); d->n_triangles = (int32_t)(s->I.size() / 3);
+    d->materials = s->materials.data(); d->n_materials = (int32_t)s->materials.size();
+    d->textures = s->textures.data(); d->n_textures = (int32_t)s->textures.size();
+    d->lights = s->lights.data(); d->n_lights = (int32_t)s->lights.size();
+    return SPCBPT_OK;
+}
+
+int spcbpt_scene_file_camera(spcbpt_scene_file* s, float eye[3], float lookat[3], float up[3], float* fov, int* width, int* height) {
+    if (!s) return SPCBPT_ERR_INVALID_ARG;
+    if (eye) memcpy(eye, s->eye, 12);
+    if (lookat) memcpy(lookat, s->lookat, 12);
+    if (up) memcpy(up, s->up, 12);
+    if (fov) *fov = s->fov;
+    if (width) *width = s->width;
+    if (height) *height = s->height;
+    return SPCBPT_OK;
+}
+
+const char* spcbpt_scene_file_warnings(spcbpt_scene_file* s) { return s ? s->warnings.c_str() : ""; }
+
+int spcbpt_scene_file_free(spcbpt_scene_file* s) {
+    delete s;
+    return SPCBPT_OK;
+}
+
+}  // extern "C"

@@ -242,3 +242,50 @@ def simple_room(n: int = 4) -> Scene:
     lights = [dict(position=(-0.4, 1.997, -0.4), u=(0.8, 0, 0), v=(0, 0, 0.8), emission=(10, 10, 10), div_level=4)]
     cam = dict(eye=(0.0, 1.0, 0.95), lookat=(0.0, 0.8, -1.0), up=(0, 1, 0), fov=60.0)
     return b.finish(mats, lights, camera=cam, name="simple_room")
+
+
+def write_scene(scene: Scene, data_root: str, rel_dir: str) -> str:
+    """Writes `scene` in the reference's `.scene` + OBJ format (sceneLoader.cpp grammar) under
+    data_root/rel_dir: one OBJ per material (the k-th mesh block uses the k-th material), binary PPM textures,
+    Quad lights with absolute corner points v1/v2.  Returns the path of the .scene file."""
+    import os
+    out_dir = os.path.join(data_root, rel_dir)
+    os.makedirs(out_dir, exist_ok=True)
+    lines = ["# written by spcbpt-optix7_amd/scenes.py in the .scene syntax of ssufujia/SPCBPT-OptiX7", ""]
+    for k, m in enumerate(scene.materials):
+        lines += [f"material mat{k}", "{", "   color %.9g %.9g %.9g" % tuple(m.get("color", (1, 1, 1))),
+                  "   roughness %.9g" % m.get("roughness", 0.5), "   metallic %.9g" % m.get("metallic", 0.0), "   specular 0.5"]
+        if m.get("albedo_tex", 0) > 0:
+            t = m["albedo_tex"] - 1
+            name = f"{rel_dir}/tex{t}.ppm"
+            img = scene.textures[t]
+            with open(os.path.join(data_root, name), "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]))
+                f.write(np.ascontiguousarray(img[..., :3]).tobytes())
+            lines.append(f"   albedoTex {name}")
+        lines += ["}", ""]
+    c = scene.camera
+    lines += ["cameraSetting", "{", "    eye %.9g %.9g %.9g" % tuple(c["eye"]), "    lookat %.9g %.9g %.9g" % tuple(c["lookat"]),
+              "    up %.9g %.9g %.9g" % tuple(c.get("up", (0, 1, 0))), "    fov %.9g" % c.get("fov", 35.0), "}", ""]
+    uv = scene.texcoords if scene.texcoords is not None else np.zeros((scene.vertices.shape[0], 2), np.float32)
+    for k in range(len(scene.materials)):
+        tris = scene.indices[scene.tri_material == k]
+        used, inv = np.unique(tris.reshape(-1), return_inverse=True)
+        name = f"{rel_dir}/mesh{k}.obj"
+        with open(os.path.join(data_root, name), "w") as f:
+            for v in scene.vertices[used]:
+                f.write("v %.9g %.9g %.9g\n" % tuple(v))
+            for t in uv[used]:
+                f.write("vt %.9g %.9g\n" % tuple(t))
+            for a, b, cc in inv.reshape(-1, 3) + 1:
+                f.write(f"f {a}/{a} {b}/{b} {cc}/{cc}\n")
+        lines += ["mesh", "{", f"    file {name}", f"    material mat{k}", "}", ""]
+    for l in scene.lights:
+        p, u, v = (np.asarray(l[x], np.float64) for x in ("position", "u", "v"))
+        lines += ["light", "{", "    position %.9g %.9g %.9g" % tuple(p), "    v1 %.9g %.9g %.9g" % tuple(p + u),
+                  "    v2 %.9g %.9g %.9g" % tuple(p + v), "    emission %.9g %.9g %.9g" % tuple(l["emission"]), "    type Quad",
+                  "    divLevel %d" % l.get("div_level", 1), "}", ""]
+    path = os.path.join(out_dir, scene.name + ".scene")
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+    return path

@@ -1,0 +1,88 @@
+"""`.scene` + OBJ ingestion: write a scene in the reference's syntax, read it back with the C++ loader,
+and parse the reference's shipped house scene where it lies (skipped when /root/reference is absent)."""
+import os
+
+import numpy as np
+import pytest
+
+HOUSE = "/root/reference/src/data/house/house_uvrefine2.scene"
+
+
+def _tri_set(scene):
+    t = scene.vertices[scene.indices.reshape(-1)].reshape(-1, 9)
+    return t[np.lexsort(t.T[::-1])]
+
+
+@pytest.mark.parametrize("name,kw", [("cornell_box", {}), ("bedroom", {"target_tris": 3000, "tex_size": 16})])
+def test_scene_round_trip(hip_lib, pkg, tmp_path, name, kw):
+    scene = getattr(pkg.scenes, name)(**kw)
+    path = pkg.scenes.write_scene(scene, str(tmp_path), name)
+    loaded, warn = pkg.load_scene_file(path, str(tmp_path))
+    assert warn == "", warn
+    assert loaded.indices.shape == scene.indices.shape
+    assert len(loaded.materials) == len(scene.materials) and len(loaded.lights) == len(scene.lights)
+    np.testing.assert_allclose(_tri_set(loaded), _tri_set(scene), rtol=0, atol=1e-6)
+    for a, b in zip(loaded.materials, scene.materials):
+        np.testing.assert_allclose(a["color"], b["color"], rtol=1e-6)
+        assert abs(a["roughness"] - b["roughness"]) < 1e-6 and abs(a["metallic"] - b["metallic"]) < 1e-6
+        assert (a["albedo_tex"] > 0) == (b.get("albedo_tex", 0) > 0)
+    for a, b in zip(loaded.lights, scene.lights):
+        for k in ("position", "u", "v", "emission"):
+            np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-6)
+        assert a["div_level"] == b["div_level"]
+    np.testing.assert_allclose(loaded.camera["eye"], scene.camera["eye"], rtol=1e-6)
+    assert abs(loaded.camera["fov"] - scene.camera["fov"]) < 1e-5
+    for ta, tb in zip(loaded.textures, scene.textures):
+        assert np.array_equal(ta[..., :3], tb[..., :3]) and (ta[..., 3] == 255).all()
+    # per-triangle material follows the k-th mesh / k-th material rule
+    cen = lambda s: s.vertices[s.indices].mean(axis=1)
+    key = lambda s: np.round(np.concatenate([cen(s), s.tri_material[:, None]], 1), 4)
+    assert set(map(tuple, key(loaded))) == set(map(tuple, key(scene)))
+
+
+def test_loaded_scene_renders_like_the_generated_one(hip_lib, ob, pkg, tmp_path):
+    scene = pkg.scenes.cornell_box()
+    path = pkg.scenes.write_scene(scene, str(tmp_path), "cornell")
+    loaded, _ = pkg.load_scene_file(path, str(tmp_path))
+    imgs = []
+    for s in (scene, loaded):
+        o = ob.Oracle(s)
+        c = s.camera
+        o.set_camera_lookat(c["eye"], c["lookat"], c["up"], c["fov"], 1.0)
+        o.resize(32, 32)
+        for f in range(4):
+            o.launch("pt", f)
+        imgs.append(o.read_accum()[..., :3])
+    assert np.abs(imgs[0] - imgs[1]).max() < 1e-4
+
+
+def test_grammar_quirks(hip_lib, pkg, tmp_path):
+    """Comment lines, back-slash paths, a block without closing brace at EOF, a non-Quad light, an unknown texture format."""
+    d = tmp_path / "q"
+    d.mkdir()
+    (d / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nf 1/1 2/1 3/1 4/1\nf -4//1 -3//1 -2//1\n")
+    (tmp_path / "q.scene").write_text(
+        "#material Commented\n#{\n# color 9 9 9\n#}\nmaterial A\n{\n   color 0.1 0.2 0.3\n   roughness 0.25\n   albedoTex q/none.jpg\n}\n"
+        "mesh\n{\n    file q\\m.obj\n    material A\n}\n"
+        "light\n{\n  position 0 0 0\n  type Sphere\n  radius 1\n}\n"
+        "light\n{\n  position 0 2 0\n  v1 1 2 0\n  v2 0 2 1\n  emission 5 5 5\n divLevel 3\n  type Quad\n")
+    s, warn = pkg.load_scene_file(str(tmp_path / "q.scene"), str(tmp_path))
+    # quad fan (2 triangles, 4 v/vt vertices) + a triangle with negative indices and no vt (3 more distinct v/vt pairs)
+    assert s.indices.shape[0] == 3 and s.vertices.shape[0] == 7
+    assert len(s.materials) == 1 and abs(s.materials[0]["roughness"] - 0.25) < 1e-7 and s.materials[0]["albedo_tex"] == 0
+    assert len(s.lights) == 1 and s.lights[0]["div_level"] == 3 and tuple(s.lights[0]["u"]) == (1.0, 0.0, 0.0)
+    assert "Sphere" in warn and "none.jpg" in warn
+
+
+@pytest.mark.skipif(not os.path.exists(HOUSE), reason="reference data not present")
+def test_reference_house_scene_parses(hip_lib, pkg):
+    s, warn = pkg.load_scene_file(HOUSE, "/root/reference/src/data")
+    assert len(s.lights) == 2 and all(l["div_level"] == 10 for l in s.lights)
+    np.testing.assert_allclose(s.lights[0]["position"], (5.5, -1, 7))
+    np.testing.assert_allclose(s.lights[0]["u"], (-30, 0, 0))
+    np.testing.assert_allclose(s.lights[0]["emission"], (70, 55, 45))
+    np.testing.assert_allclose(s.camera["eye"], (-0.813158, 5.627658, -7.363544), rtol=1e-6)
+    assert abs(s.camera["fov"] - 60) < 1e-6
+    assert len(s.materials) >= 25 and s.indices.shape[0] > 50000     # 30 meshes, ~67 k faces present
+    assert "could not be read" in warn                                 # three referenced OBJs were stripped from the checkout
+    assert ".jpg" in warn or ".png" in warn                           # stb_image formats are not decoded here

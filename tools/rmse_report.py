@@ -1,0 +1,55 @@
+"""Equal-spp RMSE (second half of the BASELINE metric).  RMSE on the linear accum buffer of "pt", "SPCBPT_eye" with the
+minimal tuple and "SPCBPT_eye" with the trained tuple at N spp, against a reference of 32 N spp (16 N of "pt" + 16 N of
+"SPCBPT_eye", trained) whose subframe indices are disjoint from the images under test, so no samples are shared.
+Each frame is launched on a cleared accum buffer at subframe index s (the kernel then leaves new/(s+1) in it) and summed
+on the device in fp32 chunks / fp64 totals, which gives a plain mean for any set of indices.
+  python tools/rmse_report.py <tag> [cornell|bedroom|hallway] [W H spp]   ->  profiles/<tag>_rmse_<scene>.json"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import __graft_entry__ as g
+p = g.load_package()
+tag = sys.argv[1]
+name = sys.argv[2] if len(sys.argv) > 2 else "cornell"
+W, H, N = (int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (1024, 1024, 64)
+scene = {"cornell": p.scenes.cornell_box, "bedroom": p.scenes.bedroom, "hallway": p.scenes.hallway}[name]()
+r = p.Renderer(scene, 0)
+c = scene.camera
+r.set_camera_lookat(c["eye"], c["lookat"], c["up"], c["fov"], W / H)
+r.resize(W, H)
+r.set_light_trace(100000, 52, 1)
+view = p.dist.device_view(r.accum_device_ptr(), W * H * 16, torch.device("cuda:0")).view(torch.float32).view(H, W, 4)
+
+def mean_image(alg, first, n):
+    tot = torch.zeros(H, W, 3, dtype=torch.float64, device="cuda:0")
+    for s in range(first, first + n):
+        r.clear_accum()
+        r.render_frame(alg, s, launch_frame=s + 1)
+        r.sync()
+        tot += view[..., :3].double() * (s + 1)
+        torch.cuda.synchronize()
+    return (tot / n).cpu().numpy()
+
+out = {"tag": tag, "scene": name, "width": W, "height": H, "spp": N, "ref_spp": 32 * N}
+t0 = time.time()
+r.set_subspace()                                   # minimal tuple
+pt = mean_image("pt", 0, N)
+sp_min = mean_image("SPCBPT_eye", 0, N)
+pt_ref = mean_image("pt", 4 * N, 16 * N)
+tp = 400_000 if name == "cornell" else 2_000_000
+t1 = time.time(); r.preprocess(tp, tp, True); out["preprocess_seconds"] = time.time() - t1
+sp_tr = mean_image("SPCBPT_eye", 0, N)
+sp_ref = mean_image("SPCBPT_eye", 32 * N, 16 * N)
+ref = 0.5 * (pt_ref + sp_ref)
+rm = lambda a: float(np.sqrt(((a - ref) ** 2).mean()))
+rel = lambda a: float((((a - ref) ** 2) / (ref ** 2 + 1e-2)).mean())
+out.update(rmse_pt=rm(pt), rmse_spcbpt_minimal=rm(sp_min), rmse_spcbpt_trained=rm(sp_tr),
+           relmse_pt=rel(pt), relmse_spcbpt_minimal=rel(sp_min), relmse_spcbpt_trained=rel(sp_tr),
+           mean_pt_ref=float(pt_ref.mean()), mean_spcbpt_ref=float(sp_ref.mean()),
+           ref_disagreement_rmse=float(np.sqrt(((pt_ref - sp_ref) ** 2).mean())), seconds=time.time() - t0)
+out["variance_ratio_pt_over_trained"] = (out["rmse_pt"] / out["rmse_spcbpt_trained"]) ** 2
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rmse_{name}.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -263,6 +263,15 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }
     kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
     kp.counters = counting ? d_counters : nullptr;
+    if (spcbpt_alg && !eye_megakernel) {
+        kp.n_tiles = (uint32_t)render_tile_count(kp);
+        time_begin(name);
+        int rcw = launch_wavefront();
+        time_end();
+        if (rcw) return rcw;
+        HIP_TRY(this, hipGetLastError());
+        return 0;
+    }
     int rc = ensure_spill((size_t)render_thread_count(kp));
     if (rc) return rc;
     if (spcbpt_alg) {
@@ -276,6 +285,59 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     else launch_pt(kp, counting, stream);
     time_end();
     HIP_TRY(this, hipGetLastError());
+    return 0;
+}
+
+// Wavefront eye pass: state arrays for `slots` path slots (a multiple of 64) in one allocation.
+int Context::ensure_wf(size_t slots) {
+    if (slots > wf_slots_capacity) {
+        HIP_TRY(this, hipStreamSynchronize(stream));
+        dev_free(d_wf_block);
+        d_wf_block = nullptr;
+        // float4 per slot: WF_ARRAYS state arrays + 3 x (conn_ray, conn_rec, contrib); dwords per slot: 2 queues + 3 vis
+        const size_t words = slots * (4 * (size_t)(WF_ARRAYS + 9) + 5) + (size_t)WF_MAX_BOUNCES * WFC_ROW;
+        HIP_TRY(this, dev_alloc(&d_wf_block, words));
+        wf_slots_capacity = slots;
+        float* q = d_wf_block;
+        for (int a = 0; a < WF_ARRAYS; a++) { wf.a[a] = q; q += 4 * slots; }
+        wf.conn_ray = q; q += 12 * slots;
+        wf.conn_rec = reinterpret_cast<uint32_t*>(q); q += 12 * slots;
+        wf.contrib = q; q += 12 * slots;
+        wf.queue[0] = reinterpret_cast<uint32_t*>(q); q += slots;
+        wf.queue[1] = reinterpret_cast<uint32_t*>(q); q += slots;
+        wf.vis = reinterpret_cast<uint32_t*>(q); q += 3 * slots;
+        wf.counts = reinterpret_cast<uint32_t*>(q);
+    }
+    if (!h_wf_counts) HIP_TRY(this, hipHostMalloc(reinterpret_cast<void**>(&h_wf_counts), (size_t)WF_MAX_BOUNCES * WFC_ROW * sizeof(uint32_t)));
+    wf.n_slots = (uint32_t)slots;
+    return 0;
+}
+
+// One frame of "SPCBPT_eye" as a stream of per-phase kernels.  Launch sizes never depend on a host read-back: every kernel
+// is a fixed persistent grid that pulls from device-side cursors.  The host only probes the queue length every 8 bounces
+// to stop issuing (empty) launches once every path has ended.
+int Context::launch_wavefront() {
+    const size_t slots = (size_t)kp.n_tiles * 64;
+    if (slots == 0) return 0;
+    int rc = ensure_wf(slots);
+    if (rc) return rc;
+    rc = ensure_spill(slots * SPCBPT_CONNECTION_N);  // one traversal stack per shadow-ray record
+    if (rc) return rc;
+    HIP_TRY(this, hipMemsetAsync(wf.counts, 0, (size_t)WF_MAX_BOUNCES * WFC_ROW * sizeof(uint32_t), stream));
+    launch_wf_gen(kp, wf, counting, stream);
+    size_t bound = slots;
+    int b = 0;
+    for (; b < WF_MAX_BOUNCES - 1; b++) {
+        launch_wf_bounce(kp, wf, b, counting, bound, stream);
+        if ((b & 7) == 7) {
+            HIP_TRY(this, hipMemcpyAsync(h_wf_counts, wf.counts + (size_t)(b + 1) * WFC_ROW, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(this, hipStreamSynchronize(stream));
+            bound = h_wf_counts[0];
+            if (bound == 0) { b++; break; }
+        }
+    }
+    wf_bounces_last = b;
+    launch_wf_film(kp, wf, stream);
     return 0;
 }
 
@@ -326,7 +388,7 @@ Context::~Context() {
     dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_lvc); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_vals2); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix); dev_free(d_cmfs);
-    dev_free(d_subspace); dev_free(d_sampler_counts); dev_free(d_counters); dev_free(d_work_counter); dev_free(d_spill); dev_free(d_temp);
+    dev_free(d_subspace); dev_free(d_sampler_counts); dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -427,7 +489,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     mesh.n_vertices = (int)(V.size() / 3); mesh.n_triangles = (int)(I.size() / 3);
     Lbvh bvh;
     build_lbvh(mesh, bvh);
-    c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 32); c->bvh_depth = bvh.depth;
+    c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 16); c->bvh_depth = bvh.depth;
     c->n_lights = (int)lights.size(); c->n_mats = (int)mats.size();
 
     CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size()));
@@ -459,6 +521,10 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
         c->num_cus = prop.multiProcessorCount;
+    }
+    {
+        const char* mode = getenv("SPCBPT_EYE_PASS");
+        c->eye_megakernel = !(mode && std::string(mode) == "wavefront");
     }
     CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)1));
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));

@@ -165,23 +165,28 @@ static constexpr int kTravDone = 0x7fffffff;
             else node = (int)w__;                                                                   \
         }                                                                                           \
     } while (0)
-// slab test of the 4 child boxes of a node at once (SoA quads); misses get key 0xffffffff, hits the entry distance with
-// the slot index in the two low mantissa bits (t >= 0, so unsigned order = float order)
-SPC_DEV void slab4(const float4 lx, const float4 ly, const float4 lz, const float4 hx, const float4 hy, const float4 hz, f3 ood, f3 inv,
-                   float tmin, float tmax, uint32_t key[4]) {
-    const float lox[4] = {lx.x, lx.y, lx.z, lx.w}, loy[4] = {ly.x, ly.y, ly.z, ly.w}, loz[4] = {lz.x, lz.y, lz.z, lz.w};
-    const float hix[4] = {hx.x, hx.y, hx.z, hx.w}, hiy[4] = {hy.x, hy.y, hy.z, hy.w}, hiz[4] = {hz.x, hz.y, hz.z, hz.w};
+// slab test of the 4 quantised child boxes of a node; misses get key 0xffffffff, hits the entry distance with the slot index
+// in the two low mantissa bits (t >= 0, so unsigned order = float order).  plane distance = (org + q s - o) / d
+// = q (s inv) + (org inv - o inv): two per-axis constants per node, then one byte->float convert and one FMA per plane.
+SPC_DEV void slab4q(const float4 q0, const float4 q1, const float4 q2, const uint32_t ref[4], f3 ood, f3 inv, float tmin, float tmax,
+                    uint32_t key[4]) {
+    const uint32_t e = __float_as_uint(q0.w);
+    const float ax = __uint_as_float((e & 0xffu) << 23) * inv.x, ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * inv.y,
+                az = __uint_as_float(((e >> 16) & 0xffu) << 23) * inv.z;
+    const float bx = fmaf(q0.x, inv.x, -ood.x), by = fmaf(q0.y, inv.y, -ood.y), bz = fmaf(q0.z, inv.z, -ood.z);
+    const uint32_t lxb = __float_as_uint(q1.x), lyb = __float_as_uint(q1.y), lzb = __float_as_uint(q1.z);
+    const uint32_t hxb = __float_as_uint(q1.w), hyb = __float_as_uint(q2.x), hzb = __float_as_uint(q2.y);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        // plane distance as one FMA: b * inv - o * inv (ood = o * inv is per-ray)
-        const float tx0 = fmaf(lox[i], inv.x, -ood.x), tx1 = fmaf(hix[i], inv.x, -ood.x);
-        const float ty0 = fmaf(loy[i], inv.y, -ood.y), ty1 = fmaf(hiy[i], inv.y, -ood.y);
-        const float tz0 = fmaf(loz[i], inv.z, -ood.z), tz1 = fmaf(hiz[i], inv.z, -ood.z);
+        const float tx0 = fmaf((float)((lxb >> (8 * i)) & 0xffu), ax, bx), tx1 = fmaf((float)((hxb >> (8 * i)) & 0xffu), ax, bx);
+        const float ty0 = fmaf((float)((lyb >> (8 * i)) & 0xffu), ay, by), ty1 = fmaf((float)((hyb >> (8 * i)) & 0xffu), ay, by);
+        const float tz0 = fmaf((float)((lzb >> (8 * i)) & 0xffu), az, bz), tz1 = fmaf((float)((hzb >> (8 * i)) & 0xffu), az, bz);
         const float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
         const float t1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
-        key[i] = (t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
+        key[i] = (ref[i] != NODE_EMPTY && t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
     }
 }
+SPC_DEV uint32_t sel4u(const uint32_t r[4], uint32_t i) { return i == 0 ? r[0] : (i == 1 ? r[1] : (i == 2 ? r[2] : r[3])); }
 SPC_DEV int sel4i(const float4 q, uint32_t i) {
     const float v = i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w));
     return __float_as_int(v);
@@ -203,30 +208,26 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     while (node != kTravDone) {
         while (node >= 0 && node != kTravDone) {
             const size_t nb = (size_t)node * NODE_QUADS;
-            const float4 lx = ldq(S.nodes, nb + 0), ly = ldq(S.nodes, nb + 1), lz = ldq(S.nodes, nb + 2);
-            const float4 hx = ldq(S.nodes, nb + 3), hy = ldq(S.nodes, nb + 4), hz = ldq(S.nodes, nb + 5);
-            const float4 refs = ldq(S.nodes, nb + 6), cnts = ldq(S.nodes, nb + 7);
-            cn.add(C_NODE, 2);  // one 128-B visit = two 64-B units of the algorithmic-bytes table
+            const float4 q0 = ldq(S.nodes, nb + 0), q1 = ldq(S.nodes, nb + 1), q2 = ldq(S.nodes, nb + 2), q3 = ldq(S.nodes, nb + 3);
+            cn.add(C_NODE);  // one 64-B visit
+            const uint32_t ref[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
             uint32_t k[4];
-            slab4(lx, ly, lz, hx, hy, hz, ood, inv, tmin, best_t, k);
-            if (!ANY) {  // sort the four keys ascending: nearest child first (5 compare-exchanges)
+            slab4q(q0, q1, q2, ref, ood, inv, tmin, best_t, k);
+            // sort the four keys ascending: nearest child first (5 compare-exchanges); for any-hit rays the order is irrelevant
+            // but the same network compacts the hits to the front
 #define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
-                SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
+            SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
 #undef SPC_CSWAP
-            } else {     // any-hit: order is irrelevant, only compact the hits to the front
-#define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
-                SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
-#undef SPC_CSWAP
-            }
             if (k[0] == 0xffffffffu) {
                 SPC_TRAV_POP();
             } else {
                 // push the farther hits, farthest first, so the nearest pops first
-                if (k[3] != 0xffffffffu) st.push(stack_word(sel4i(refs, k[3] & 3u), sel4i(cnts, k[3] & 3u)));
-                if (k[2] != 0xffffffffu) st.push(stack_word(sel4i(refs, k[2] & 3u), sel4i(cnts, k[2] & 3u)));
-                if (k[1] != 0xffffffffu) st.push(stack_word(sel4i(refs, k[1] & 3u), sel4i(cnts, k[1] & 3u)));
-                node = sel4i(refs, k[0] & 3u);
-                leaf_count = sel4i(cnts, k[0] & 3u);
+                if (k[3] != 0xffffffffu) st.push(sel4u(ref, k[3] & 3u));
+                if (k[2] != 0xffffffffu) st.push(sel4u(ref, k[2] & 3u));
+                if (k[1] != 0xffffffffu) st.push(sel4u(ref, k[1] & 3u));
+                const uint32_t w__ = sel4u(ref, k[0] & 3u);
+                if (w__ & 0x80000000u) { node = ~(int)((w__ & 0x7fffffffu) >> 3); leaf_count = (int)(w__ & 7u); }
+                else node = (int)w__;
             }
         }
         if (node == kTravDone) break;
@@ -250,6 +251,82 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     }
     hit.t = best_t; hit.tri = best_tri; hit.u = best_u; hit.v = best_v;
     return best_tri >= 0;
+}
+
+// ---- wave-cooperative any-hit traversal ------------------------------------------------------------------------------
+// The CONNECTION_N shadow rays of the 64 eye vertices of a wave (192 rays) are pooled in LDS and every lane of the wave --
+// including lanes whose own path has ended -- pulls rays from the pool until it is empty.  Shadow rays differ wildly in
+// length (45 % are occluded after a few nodes, the rest cross the whole scene): with one ray per lane the wave waits for its
+// longest ray and the measured VALU lane utilisation of any-hit traversal is 21 %; pulling keeps the lanes busy.
+//   s_org[64]   origin of the rays owned by lane l (its eye vertex)
+//   s_ray[192]  ray it * 64 + l: direction.xyz, length (< 0: no ray in this slot)
+//   s_vis[192]  out: 1 = unoccluded
+//   s_next      pool cursor, must be 64 on entry (rays 0..63 are claimed statically by lane id)
+// Wave-scope fences order the LDS traffic; all 64 lanes must call this together.
+static constexpr int POOL_RAYS = 64 * SPCBPT_CONNECTION_N;
+template <bool COUNT, int BLOCK, int STACK_LDS>
+SPC_DEV void shadow_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, const float4* s_org, const float4* s_ray, uint8_t* s_vis,
+                         uint32_t* s_next, Counts<COUNT>& cn) {
+    uint32_t r = threadIdx.x & 63;
+    bool have = false, done = false;
+    f3 o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), ood = mk3(0.0f);
+    float tmax = 0.0f;
+    int node = kTravDone, leaf_count = 0;
+    while (true) {
+        while (!have && !done) {  // acquire the next ray of the pool
+            if (r >= (uint32_t)POOL_RAYS) { done = true; break; }
+            const float4 rq = s_ray[r];
+            if (rq.w < 0.0f) { r = atomicAdd(s_next, 1u); continue; }
+            const float4 oq = s_org[r & 63u];
+            o = mk3(oq.x, oq.y, oq.z); d = mk3(rq.x, rq.y, rq.z);
+            inv = safe_inv(d); ood = o * inv;
+            tmax = rq.w - kEps;
+            node = 0; st.sp = 0; have = true;
+            cn.add(C_SHADOW);
+        }
+        if (!__any(have)) break;
+        if (have) {
+            bool occluded = false;
+            while (node >= 0 && node != kTravDone) {
+                const size_t nb = (size_t)node * NODE_QUADS;
+                const float4 q0 = ldq(S.nodes, nb + 0), q1 = ldq(S.nodes, nb + 1), q2 = ldq(S.nodes, nb + 2), q3 = ldq(S.nodes, nb + 3);
+                cn.add(C_NODE);
+                const uint32_t ref[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
+                uint32_t k[4];
+                slab4q(q0, q1, q2, ref, ood, inv, kEps, tmax, k);
+#define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
+                SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
+#undef SPC_CSWAP
+                if (k[0] == 0xffffffffu) {
+                    SPC_TRAV_POP();
+                } else {
+                    if (k[3] != 0xffffffffu) st.push(sel4u(ref, k[3] & 3u));
+                    if (k[2] != 0xffffffffu) st.push(sel4u(ref, k[2] & 3u));
+                    if (k[1] != 0xffffffffu) st.push(sel4u(ref, k[1] & 3u));
+                    const uint32_t w__ = sel4u(ref, k[0] & 3u);
+                    if (w__ & 0x80000000u) { node = ~(int)((w__ & 0x7fffffffu) >> 3); leaf_count = (int)(w__ & 7u); }
+                    else node = (int)w__;
+                }
+            }
+            if (node != kTravDone) {
+                const int first = ~node;
+                for (int i = 0; i < leaf_count; i++) {
+                    const size_t base = (size_t)(first + i) * 4;
+                    const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
+                    cn.add(C_TRI);
+                    float t, u, v;
+                    if (tri_test(a, b, c, o, d, kEps, tmax, false, t, u, v)) { occluded = true; break; }
+                }
+                if (occluded) node = kTravDone;
+                else SPC_TRAV_POP();
+            }
+            if (node == kTravDone) {
+                s_vis[r] = occluded ? (uint8_t)0 : (uint8_t)1;
+                have = false;
+                r = atomicAdd(s_next, 1u);
+            }
+        }
+    }
 }
 
 // ---- materials / textures / hit geometry -------------------------------------

@@ -24,6 +24,11 @@ void launch_pretrace(const KParams& p, uint32_t iteration, int num_core, int pad
                      spcbpt_pretrace_node* nodes, hipStream_t s);
 void launch_trace_any(const KParams& p, const float* rays, int n, int* vis, hipStream_t s);
 
-static const int kStackLds = 24;  // must match STACK_LDS in kernels.hip
+// wavefront eye pass (wavefront.hip)
+void launch_wf_gen(const KParams& p, const WfState& wf, bool count, hipStream_t s);
+void launch_wf_bounce(const KParams& p, const WfState& wf, int bounce, bool count, size_t bound, hipStream_t s);
+void launch_wf_film(const KParams& p, const WfState& wf, hipStream_t s);
+
+static const int kStackLds = 20;  // LDS traversal-stack entries per lane (20 KB per block); with the 16.4 KB shadow-ray pool of k_spcbpt four blocks fit a CU
 
 }  // namespace spc

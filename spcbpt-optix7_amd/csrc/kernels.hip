@@ -8,12 +8,13 @@
 #include <hip/hip_runtime.h>
 
 #include "device_lib.h"
+#include "eye_walk.h"
 #include "kernels.h"
 
 namespace spc {
 
 static constexpr int BLOCK = 256;
-static constexpr int STACK_LDS = 24;  // 24 KB of LDS per block; deeper entries spill (TravStack)
+static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
 #ifndef SPC_WAVES
 #define SPC_WAVES 4  // measured on MI355X (bedroom 1080p): 2 -> 38.8 ms, 3 -> 31.6, 4 -> 28.3, 5 -> 29.3; minimum waves per SIMD requested from the register allocator for the megakernel
 #endif
@@ -30,116 +31,6 @@ SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
     return x < p.width && y < p.height && (int)y < p.row_end && (int)y >= p.row_begin;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Eye-walk step shared by k_spcbpt and the pretrace kernel: build the vertex at a surface hit
-// (hit_program.cu:246-340).  `last` is the previous vertex (camera when last.depth == 0).
-struct WalkState {
-    f3 origin, dir;        // next ray
-    f3 next_flux;          // NextVertex.flux  = BSDF value of the sampled direction
-    float next_single_pdf; // NextVertex.singlePdf = solid-angle pdf (x RR once survived)
-    uint32_t seed;
-    bool done;
-};
-
-template <bool COUNT>
-SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
-                             WalkState& w, EyeVertex& mid, Counts<COUNT>& cn) {
-    const DeviceScene& S = p.scene;
-    Pbr pbr = load_pbr(S, g.mat);
-    color_tex_sample(S, g, pbr, cn);
-    f3 N = g.N;
-    if (dot(N, ray_dir) > 0.f) N = -N;
-    const f3 inv_dir = -ray_dir;
-    const f3 new_dir = bsdf_sample(pbr, N, inv_dir, w.seed);
-    const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
-    if (!(pdf > 0.0f)) w.done = true;
-
-    mid.c.pos = g.P;
-    mid.c.n = N;
-    const float pdf_G = fabsf(dot(N, ray_dir) * dot(last.c.n, ray_dir)) / (t_hit * t_hit);
-    mid.flux = last_is_origin ? last.flux * pdf_G : w.next_flux * last.flux * pdf_G;
-    mid.c.lastPos = last.c.pos;
-    mid.c.color = pbr.base;
-    mid.c.lnp = fabsf(dot(last.c.n, ray_dir));
-    mid.c.mat = g.mat;
-    mid.sub = tree_label(p.eye_tree, g.P, N, inv_dir, cn);
-    mid.lastZone = last.sub;
-    mid.depth = last.depth + 1;
-    mid.singlePdf = w.next_single_pdf * pdf_G / fabsf(dot(last.c.n, ray_dir));
-    mid.pdf = last.pdf * mid.singlePdf;
-    // recursive MIS (rmis.h:189-207)
-    if (mid.depth == 1) {
-        mid.R3 = mk3(0.0f);
-    } else {
-        const Pbr mat_last = load_pbr_colored(S, last.c.mat, last.c.color);
-        const f3 in_dir = normalize(mid.c.pos - last.c.pos);
-        const float LL_pdf = rmis_last_pdf(mat_last, last.c, in_dir);
-        const float wgt = rmis_weight_eye(p, last.c, last.depth, last.lastZone, mid.c.pos, cn);
-        const f3 fm = rmis_flux_multiplier(mat_last, last.c, in_dir, normalize(last.c.lastPos - last.c.pos));
-        mid.R3 = (last.R3 * LL_pdf * fm + mk3(wgt)) / last.singlePdf;
-    }
-    cn.add(C_VERTEX);
-    // next segment + Russian roulette (the vertex itself is kept; hit_program.cu:324-337)
-    w.next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
-    w.next_single_pdf = pdf;
-    w.origin = g.P;
-    w.dir = new_dir;
-    const float r = rnd(w.seed);
-    const float rr = rr_of(mid.c.color);
-    if (r > rr) w.done = true;
-    else w.next_single_pdf *= rr;
-}
-
-// __closesthit__eyeSubpath_LightSource + rmis::light_hit + lightStraghtHit (hit_program.cu:62-147, rmis.h:359-389,
-// raygen.cu:305-317): contribution of an eye path that runs into an emitter.
-template <bool COUNT>
-SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
-                           const WalkState& w, Counts<COUNT>& cn) {
-    const DeviceScene& S = p.scene;
-    const int light_id = load_pbr(S, g.mat).light_id;
-    const DLight& L = S.lights[light_id];
-    const f3 ln = ld3(L.normal);
-    if (dot(ray_dir, ln) > 0) return mk3(0.0f);
-    const LightSampleD ls = light_reverse_sample(S, L, g.u, g.v);
-    const float pdf_G = fabsf(dot(ln, ray_dir) * dot(last.c.n, ray_dir)) / (t_hit * t_hit);
-    const f3 flux = last_is_origin ? last.flux * pdf_G * ls.emission : w.next_flux * last.flux * pdf_G * ls.emission;
-    const float singlePdf = w.next_single_pdf * pdf_G / fabsf(dot(last.c.n, ray_dir));
-    const float pdf = last.pdf * singlePdf;
-    float rmis_pointer = 1.0f;
-    if (last.depth + 1 != 1) {
-        // light_hit(eye = last, light = virtual vertex at the hit point)
-        const f3 lpos = g.P;
-        const f3 connect_dir = normalize(last.c.pos - lpos);
-        const f3 lflux = ls.emission / ls.pdf;
-        const Pbr mat_e = load_pbr_colored(S, last.c.mat, last.c.color);
-        const f3 LB = normalize(last.c.lastPos - last.c.pos);
-        const float LL_pdf_A = rmis_last_pdf(mat_e, last.c, -connect_dir);
-        const f3 fm0 = rmis_flux_multiplier(mat_e, last.c, -connect_dir, LB);
-        const float wA = rmis_weight_eye(p, last.c, last.depth, last.lastZone, lpos, cn);
-        const f3 D_A_0 = last.R3 * LL_pdf_A * fm0 + mk3(wA);
-        const float pdf_A = rmis_pdf_from_light(lpos, ln, last.c.pos, last.c.n);
-        const float D_A = sum3(D_A_0 * pdf_A * kPi * lflux / last.singlePdf);
-        const float weight = sum3(gamma_ss(p, last.sub, ls.subspace, cn) * lflux * (float)SPCBPT_CONNECTION_N);
-        const float D_B = 1.0f;
-        const float pdf_B = rmis_get_pdf(mat_e, last.c, lpos, ln, LB);
-        const float lh = D_B / ((weight + D_A) / pdf_B * ls.pdf + D_B);
-        rmis_pointer = 1.0f / lh;
-    }
-    const f3 ans = flux / pdf / rmis_pointer;
-    return is_invalid(ans) ? mk3(0.0f) : ans;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pixel of work-slot `slot` (0..63) of tile `tile`: tiles are 8x8 pixels, enumerated x-major inside the selected bands.
-SPC_DEV bool tile_pixel(const KParams& p, uint32_t tile, uint32_t slot, uint32_t& x, uint32_t& y) {
-    const uint32_t tiles_x = (p.width + 7) / 8;
-    const uint32_t tile_x = tile % tiles_x, band_k = tile / tiles_x;
-    const uint32_t band = (uint32_t)(p.row_begin / 8) + band_k * (uint32_t)p.row_step;
-    x = tile_x * 8 + (slot & 7);
-    y = band * 8 + (slot >> 3);
-    return x < p.width && y < p.height && (int)y < p.row_end;
-}
-
 // The SPCBPT megakernel: persistent waves with per-lane path regeneration.  A wave pulls 8x8 pixel tiles from a global
 // queue (one atomicAdd per tile); a lane whose eye path ends writes its pixel and immediately starts the next
 // pixel-sample of the wave's pool, so the 64 lanes stay busy although path lengths differ by an order of magnitude.
@@ -148,8 +39,16 @@ SPC_DEV bool tile_pixel(const KParams& p, uint32_t tile, uint32_t slot, uint32_t
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    __shared__ float4 s_ray[(BLOCK / 64) * POOL_RAYS];
+    __shared__ float4 s_org[BLOCK];
+    __shared__ uint8_t s_vis[(BLOCK / 64) * POOL_RAYS];
+    __shared__ uint32_t s_next[BLOCK / 64];
     const DeviceScene& S = p.scene;
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    float4* w_ray = s_ray + wave_in_block * POOL_RAYS;
+    float4* w_org = s_org + wave_in_block * 64;
+    uint8_t* w_vis = s_vis + wave_in_block * POOL_RAYS;
+    uint32_t* w_next = s_next + wave_in_block;
     Counts<COUNT> cn;
     cn.clear();
     TravStack<BLOCK, STACK_LDS> st;
@@ -211,8 +110,13 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             if (exhausted) break;
             continue;
         }
+        // ---- phase A (live lanes): extend the path, build the vertex, draw the CONNECTION_N light vertices
+        bool finished = false, has_vertex = false;
+        int lslot[SPCBPT_CONNECTION_N];
+        float conn_pmf[SPCBPT_CONNECTION_N];
+#pragma unroll
+        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lslot[it] = 0; conn_pmf[it] = 1.0f; }
         if (alive) {
-            bool finished = false;
             HitRec h;
             cn.add(C_CLOSEST);
             if (!traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn)) {
@@ -229,44 +133,65 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     EyeVertex mid;
                     eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
                     cur = mid;
-                    // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419)
+                    has_vertex = true;
+                    // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419).  Only the
+                    // position quad of the light vertex is fetched here (visibilityTest, cuProg.h:463-487); the connection
+                    // itself does not consume random numbers, so drawing all three first leaves the RNG stream unchanged.
+#pragma unroll
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                         float pmf1, pmf2;
+                        float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
                         const int l = binary_sample(p.cmf_gamma + (size_t)cur.sub * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, w.seed, pmf1, cn);
                         const DSubspace ss = p.subspace[l];
-                        if (ss.size == 0) continue;
-                        const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
-                        const int slot = p.jump[ss.jump_bias + k];
-                        const float4* src = reinterpret_cast<const float4*>(p.lvc + slot);
-                        cn.add(C_CONN);
-                        // visibilityTest (cuProg.h:463-487): only the position quad is fetched before the shadow ray, the other
-                        // 80 bytes of the light vertex after it (and only for unoccluded connections) — 21 fewer live registers
-                        // across the traversal
-                        const float4 bq0 = src[0];
-                        const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
-                        const float len = sqrtf(dot(bias, bias));
-                        const f3 sdir = bias / len;
-                        HitRec sh;
-                        cn.add(C_SHADOW);
-                        if (!traverse<true, COUNT>(S, st, cur.c.pos, sdir, kEps, len - kEps, sh, cn)) {
-                            LightVertex b;
-                            float4* dst = reinterpret_cast<float4*>(&b);
-#pragma unroll
-                            for (int q = 0; q < 6; q++) dst[q] = src[q];
-                            const float pmf = (float)path_count * pmf2 * pmf1;
-                            f3 res = connect_vertices(p, cur, b, cn);
-                            if (is_invalid(res)) res = mk3(0.0f);
-                            res = res / pmf;
-                            if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+                        if (ss.size != 0) {
+                            const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
+                            lslot[it] = p.jump[ss.jump_bias + k];
+                            cn.add(C_CONN);
+                            const float4 bq0 = reinterpret_cast<const float4*>(p.lvc + lslot[it])[0];
+                            const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
+                            const float len = sqrtf(dot(bias, bias));
+                            const f3 sdir = bias / len;
+                            rq = make_float4(sdir.x, sdir.y, sdir.z, len);
+                            conn_pmf[it] = (float)path_count * pmf2 * pmf1;
                         }
+                        w_ray[it * 64 + lane] = rq;
                     }
-                    if (w.done || depth > 50) finished = true;  // the loop-top test of raygen.cu:361
+                    w_org[lane] = make_float4(cur.c.pos.x, cur.c.pos.y, cur.c.pos.z, 0.0f);
+                    if (w.done || depth > 50) finished = true;  // the loop-top test of raygen.cu:361 (after this vertex's connections)
                 }
             }
-            if (finished) {
-                film_write(p, x, y, result);
-                alive = false;
+        }
+        if (!has_vertex) {
+#pragma unroll
+            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f);
+        }
+        if (lane == 0) *w_next = 64u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase B (all 64 lanes, dead ones included): the wave's shadow rays, pulled from the LDS pool
+        if (__any(has_vertex)) shadow_pool(S, st, w_org, w_ray, w_vis, w_next, cn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase C: connect the unoccluded pairs, in connection order
+        if (has_vertex) {
+#pragma unroll
+            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                if (w_ray[it * 64 + lane].w >= 0.0f && w_vis[it * 64 + lane]) {
+                    LightVertex b;
+                    const float4* src = reinterpret_cast<const float4*>(p.lvc + lslot[it]);
+                    float4* dst = reinterpret_cast<float4*>(&b);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) dst[q] = src[q];
+                    f3 res = connect_vertices(p, cur, b, cn);
+                    if (is_invalid(res)) res = mk3(0.0f);
+                    res = res / conn_pmf[it];
+                    if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+                }
             }
+        }
+        if (alive && finished) {
+            film_write(p, x, y, result);
+            alive = false;
         }
     }
     cn.flush(p.counters);

@@ -8,13 +8,20 @@
 namespace spc {
 
 // ---- software LBVH ---------------------------------------------------------
-// One node = 128 B = 8 x float4: a 4-wide node folded from the binary radix tree (lbvh.cpp), SoA per axis so a visit is
-// ONE round trip of eight independent 16-B loads:
-//   q0 = lo.x[4] q1 = lo.y[4] q2 = lo.z[4] q3 = hi.x[4] q4 = hi.y[4] q5 = hi.z[4] q6 = as_float(child ref[4]) q7 = as_float(count[4])
-// ref >= 0: internal node index.  ref < 0: leaf, first triangle = ~ref, count 1..LEAF_MAX.  Empty slot: ref = 0x7fffffff and
-// a point box at 1e30 (never hit; an inverted box WOULD be hit by the min/max slab test).
+// One node = 64 B = 4 x float4: a 4-wide node folded from the binary tree (lbvh.cpp) with its child boxes quantised to
+// 8 bits per plane relative to the node's own box (Ylitie et al. 2017 style).  A node visit is a divergent gather and the
+// L1/TA path delivers ~16 B per clock per CU for those (tools/micro/gather_bench.hip: 74 G visits/s with 128-B nodes,
+// 126 G visits/s with 64-B nodes), so halving the node is worth far more than the ~30 extra VALU ops of decoding it.
+//   q0 = origin.xyz (f32), w = biased scale exponents ex | ey << 8 | ez << 16   (plane = origin + q * 2^(e - 127))
+//   q1 = qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4]      (one byte per child, child i in byte i)
+//   q2 = qhi.y[4], qhi.z[4], ref[0], ref[1]
+//   q3 = ref[2], ref[3], 0, 0
+// ref is the traversal-stack word of the child: internal node index, or 0x80000000 | first triangle << 3 | count for a leaf
+// (count 1..LEAF_MAX), or 0xffffffff for an empty slot.  Quantisation rounds lo down and hi up, so a child box only grows:
+// the nearest hit found is unchanged.
 static const int LEAF_MAX = 4;
-static const int NODE_QUADS = 8;
+static const int NODE_QUADS = 4;
+static const uint32_t NODE_EMPTY = 0xffffffffu;
 
 // One triangle = 64 B = 4 x float4 in BVH order; the intersection test reads the
 // first three quads (48 B), hit shading reads all four:
@@ -107,6 +114,39 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     unsigned long long* counters;  // C_COUNT slots or null
     uint32_t* spill;               // per-thread traversal stack overflow area
     int32_t spill_entries;         // entries per thread in `spill`
+};
+
+// Wavefront ("streaming") eye pass: path state lives in HBM as SoA float4 arrays indexed by path slot
+// (slot = tile * 64 + pixel-in-tile), stages exchange queues of slots.  288 GB of HBM at 8 TB/s make the
+// state traffic (~0.4 KB per path per bounce) negligible next to the gathers of the stages themselves.
+enum WfArray {
+    WF_DIR = 0,   // next ray direction.xyz, RNG seed
+    WF_NEXT,      // NextVertex.flux.xyz, NextVertex.singlePdf
+    WF_POS,       // vertex position.xyz (= next ray origin), lastNormalProjection
+    WF_NRM,       // vertex normal.xyz, material id
+    WF_COL,       // vertex colour.xyz, pdf
+    WF_LASTPOS,   // previous vertex position.xyz, singlePdf
+    WF_FLUX,      // flux.xyz, subspace | lastZone << 16
+    WF_R3,        // RMIS_pointer_3.xyz, depth
+    WF_RESULT,    // radiance accumulated by the path.xyz, pixel x | y << 16 (0xffffffff = slot outside the image)
+    WF_HIT,       // closest hit: t, triangle (-1 = miss), u, v
+    WF_ARRAYS
+};
+enum WfCounter {  // one row of counters per bounce, zeroed at frame start
+    WFC_EXT_COUNT = 0,  // paths to extend at this bounce
+    WFC_VIS_COUNT,      // unoccluded connections of this bounce
+    WFC_ROW = 4
+};
+static constexpr int WF_MAX_BOUNCES = 52;  // depth > 50 ends a path (raygen.cu:361): at most 51 extensions
+struct WfState {
+    float* a[WF_ARRAYS];    // n_slots float4 each
+    float* conn_ray;        // [3 n_slots] float4: shadow-ray direction.xyz, length
+    uint32_t* conn_rec;     // [3 n_slots] uint4: LVC slot, pmf (bits), path slot, connection index
+    float* contrib;         // [3 n_slots] float4: contribution of connection (path slot * 3 + index), folded by the next stage
+    uint32_t* queue[2];     // extension queues (path slots), ping-pong per bounce
+    uint32_t* vis;          // [3 n_slots] indices of unoccluded connection records (compacted)
+    uint32_t* counts;       // [WF_MAX_BOUNCES][WFC_ROW]
+    uint32_t n_slots;
 };
 
 }  // namespace spc

@@ -176,11 +176,129 @@ struct Builder {
         return merge(cb[0], cb[1]);
     }
 
+    // ---- full binned-SAH top-down build ------------------------------------------------------------------------------
+    // OptiX builds its acceleration structure with a surface-area heuristic; a Morton-order LBVH costs 1.5-2x the node
+    // visits for the incoherent shadow rays of the connection stage.  The build runs once per scene on the host (outside
+    // any timed region): 32 bins per axis, all three axes evaluated, median split as the fallback for degenerate ranges.
+    struct SNode { int a, b, left, right; };
+    std::vector<SNode> snodes;
+    std::vector<float> blo, bhi;  // per original triangle
+    std::vector<int> idx;         // permutation being partitioned
+    static constexpr int NB = 32;
+    int sah_build(const std::vector<float>& cen, int a, int b, int depth) {
+        const int id = (int)snodes.size();
+        snodes.push_back({a, b, -1, -1});
+        const int cnt = b - a + 1;
+        if (cnt <= LEAF_MAX) return id;
+        float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = a; i <= b; i++) {
+            const float* c = &cen[3 * (size_t)idx[i]];
+            for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]); }
+        }
+        struct Bin { float lo[3], hi[3]; int n; };
+        Bin bins[3][NB];
+        float scale[3];
+        for (int k = 0; k < 3; k++) {
+            scale[k] = chi[k] > clo[k] ? (float)NB / (chi[k] - clo[k]) : 0.0f;
+            for (int j = 0; j < NB; j++) {
+                bins[k][j].n = 0;
+                for (int d = 0; d < 3; d++) { bins[k][j].lo[d] = 1e30f; bins[k][j].hi[d] = -1e30f; }
+            }
+        }
+        for (int i = a; i <= b; i++) {
+            const int t = idx[i];
+            const float* c = &cen[3 * (size_t)t];
+            for (int k = 0; k < 3; k++) {
+                if (scale[k] == 0.0f) continue;
+                const int j = std::min(NB - 1, std::max(0, (int)((c[k] - clo[k]) * scale[k])));
+                Bin& B = bins[k][j];
+                B.n++;
+                for (int d = 0; d < 3; d++) { B.lo[d] = std::min(B.lo[d], blo[3 * (size_t)t + d]); B.hi[d] = std::max(B.hi[d], bhi[3 * (size_t)t + d]); }
+            }
+        }
+        float best = 3.4e38f;
+        int best_axis = -1, best_bin = -1;
+        for (int k = 0; k < 3; k++) {
+            if (scale[k] == 0.0f) continue;
+            float rarea[NB];
+            int rn[NB];
+            Box acc; for (int d = 0; d < 3; d++) { acc.lo[d] = 1e30f; acc.hi[d] = -1e30f; }
+            int n_acc = 0;
+            for (int j = NB - 1; j > 0; j--) {
+                if (bins[k][j].n) { for (int d = 0; d < 3; d++) { acc.lo[d] = std::min(acc.lo[d], bins[k][j].lo[d]); acc.hi[d] = std::max(acc.hi[d], bins[k][j].hi[d]); } }
+                n_acc += bins[k][j].n;
+                rarea[j] = n_acc ? half_area(acc) : 0.0f;
+                rn[j] = n_acc;
+            }
+            for (int d = 0; d < 3; d++) { acc.lo[d] = 1e30f; acc.hi[d] = -1e30f; }
+            n_acc = 0;
+            for (int j = 0; j < NB - 1; j++) {  // left = bins [0, j], right = bins [j + 1, NB)
+                if (bins[k][j].n) { for (int d = 0; d < 3; d++) { acc.lo[d] = std::min(acc.lo[d], bins[k][j].lo[d]); acc.hi[d] = std::max(acc.hi[d], bins[k][j].hi[d]); } }
+                n_acc += bins[k][j].n;
+                if (n_acc == 0 || rn[j + 1] == 0) continue;
+                const float cost = half_area(acc) * (float)n_acc + rarea[j + 1] * (float)rn[j + 1];
+                if (cost < best) { best = cost; best_axis = k; best_bin = j; }
+            }
+        }
+        int mid;
+        if (best_axis >= 0) {
+            const int k = best_axis;
+            const float lo = clo[k], sc = scale[k];
+            int* first = idx.data() + a;
+            int* last = idx.data() + b + 1;
+            int* m2 = std::partition(first, last, [&](int t) {
+                return std::min(NB - 1, std::max(0, (int)((cen[3 * (size_t)t + k] - lo) * sc))) <= best_bin;
+            });
+            mid = (int)(m2 - idx.data());
+        } else {
+            mid = a + cnt / 2;  // all centroids coincide: any balanced cut
+        }
+        if (mid <= a || mid > b) {  // cannot happen with consistent binning; keep the tree valid regardless
+            int k = 0;
+            for (int d = 1; d < 3; d++) if (chi[d] - clo[d] > chi[k] - clo[k]) k = d;
+            mid = a + cnt / 2;
+            std::nth_element(idx.begin() + a, idx.begin() + mid, idx.begin() + b + 1,
+                             [&](int x, int y) { return cen[3 * (size_t)x + k] < cen[3 * (size_t)y + k]; });
+        }
+        const int l = sah_build(cen, a, mid - 1, depth + 1);
+        const int r = sah_build(cen, mid, b, depth + 1);
+        snodes[id].left = l; snodes[id].right = r;
+        return id;
+    }
+    Box emit_tree(int sn, int out_index, int depth) {
+        max_depth = std::max(max_depth, depth);
+        const int cid[2] = {snodes[sn].left, snodes[sn].right};
+        Box cb[2];
+        int cref[2], ccount[2];
+        for (int k = 0; k < 2; k++) {
+            const SNode c = snodes[cid[k]];
+            if (c.left < 0) {
+                cb[k] = range_box(c.a, c.b);
+                cref[k] = ~c.a;
+                ccount[k] = c.b - c.a + 1;
+            } else {
+                int idx2 = (int)(out.nodes.size() / 16);
+                out.nodes.resize(out.nodes.size() + 16);
+                cb[k] = emit_tree(cid[k], idx2, depth + 1);
+                cref[k] = idx2;
+                ccount[k] = 0;
+            }
+        }
+        float* q = &out.nodes[(size_t)out_index * 16];
+        auto put_i = [](float* p, int v) { memcpy(p, &v, 4); };
+        q[0] = cb[0].lo[0]; q[1] = cb[0].lo[1]; q[2] = cb[0].lo[2]; put_i(q + 3, cref[0]);
+        q[4] = cb[0].hi[0]; q[5] = cb[0].hi[1]; q[6] = cb[0].hi[2]; put_i(q + 7, cref[1]);
+        q[8] = cb[1].lo[0]; q[9] = cb[1].lo[1]; q[10] = cb[1].lo[2]; put_i(q + 11, ccount[0]);
+        q[12] = cb[1].hi[0]; q[13] = cb[1].hi[1]; q[14] = cb[1].hi[2]; put_i(q + 15, ccount[1]);
+        return merge(cb[0], cb[1]);
+    }
+
     void run() {
         const float* P = m.vertices;
         // centroid bounds
         float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
         std::vector<float> cen((size_t)3 * n);
+        blo.resize((size_t)3 * n); bhi.resize((size_t)3 * n);
         for (int t = 0; t < n; t++) {
             const float* a = P + 3 * (size_t)m.indices[3 * t];
             const float* b = P + 3 * (size_t)m.indices[3 * t + 1];
@@ -188,6 +306,7 @@ struct Builder {
             for (int k = 0; k < 3; k++) {
                 float lo = std::min(a[k], std::min(b[k], c[k])), hi = std::max(a[k], std::max(b[k], c[k]));
                 float ce = 0.5f * (lo + hi);
+                blo[3 * (size_t)t + k] = lo; bhi[3 * (size_t)t + k] = hi;
                 cen[3 * (size_t)t + k] = ce;
                 clo[k] = std::min(clo[k], ce); chi[k] = std::max(chi[k], ce);
             }
@@ -207,6 +326,16 @@ struct Builder {
         std::sort(kv.begin(), kv.end());
         order.resize(n);
         for (int i = 0; i < n; i++) { keys[i] = kv[i].first; order[i] = kv[i].second; }
+        // SPCBPT_BVH selects the builder: "sah" = binned SAH top-down, "lbvh" = Karras radix tree over the Morton order,
+        // "lbvh-sah" = SAH cuts along the Morton order (experiment)
+        const char* mode_env = getenv("SPCBPT_BVH");
+        const std::string mode = mode_env ? mode_env : "sah";
+        if (mode == "sah" && n > LEAF_MAX) {
+            idx = order;  // start from the Morton order: equal-cost ties keep spatial locality
+            snodes.reserve((size_t)n);
+            sah_build(cen, 0, n - 1, 1);
+            order = idx;
+        }
         tlo.resize((size_t)3 * n); thi.resize((size_t)3 * n);
         out.tris.resize((size_t)16 * n);
         out.tri_orig.resize(n);
@@ -245,11 +374,11 @@ struct Builder {
             out.depth = 1;
             return;
         }
-        const char* mode = getenv("SPCBPT_LBVH_SPLIT");
-        // default: Karras radix-tree topology (split at the highest differing Morton bit).  SPCBPT_LBVH_SPLIT=sah cuts each
-        // Morton range at the lowest surface-area cost instead; measured on the bedroom scene it visits 4 % MORE nodes
-        // (358 vs 344 per eye path), so it stays an experiment switch.
-        if (mode && std::string(mode) == "sah") {
+        // "lbvh-sah" cuts each Morton range at the lowest surface-area cost; measured on the bedroom scene it visits 4 % MORE
+        // nodes than the radix tree (358 vs 344 per eye path), so it stays an experiment switch.
+        if (mode == "sah") {
+            emit_tree(0, 0, 1);
+        } else if (mode == "lbvh-sah") {
             emit_sah(0, n - 1, 0, 1);
         } else {
             topology();
@@ -259,12 +388,10 @@ struct Builder {
     }
 };
 
-// ---- 2-wide -> 4-wide collapse ---------------------------------------------------------------------------------------
-// A traversal step is one dependent memory round trip whatever the node holds, and the megakernel is bound by that latency
-// (69 % of wave-cycles in SQ_WAIT_ANY with 2-wide nodes), so the binary radix tree is folded into 4-wide nodes: the child with
-// the largest surface area is replaced by its own two children until four slots are used.  128-B node, SoA per axis:
-//   q0 = lo.x[4] q1 = lo.y[4] q2 = lo.z[4] q3 = hi.x[4] q4 = hi.y[4] q5 = hi.z[4] q6 = child ref[4] q7 = leaf count[4]
-// ref >= 0 internal node, ref < 0 leaf (~first triangle), empty slot: ref = 0x7fffffff with a point box at 1e30.
+// ---- 2-wide -> 4-wide collapse + quantisation -------------------------------------------------------------------------
+// A traversal step is one dependent memory round trip whatever the node holds, so the binary tree is folded into 4-wide
+// nodes: the child with the largest surface area is replaced by its own two children until four slots are used.  The node is
+// then written in the 64-B quantised form described in layout.h.
 namespace {
 struct Slot { float lo[3], hi[3]; int ref, count; };
 struct Collapser {
@@ -301,25 +428,54 @@ struct Collapser {
         }
         for (int i = 0; i < n; i++)
             if (s[i].ref >= 0) {
-                const int idx = (int)(out.size() / 32);
-                out.resize(out.size() + 32);
+                const int idx = (int)(out.size() / 16);
+                out.resize(out.size() + 16);
                 emit(s[i].ref, idx, depth + 1);
                 s[i].ref = idx;
                 s[i].count = 0;
             }
-        float* q = &out[(size_t)out_index * 32];
-        for (int i = 0; i < 4; i++) {
-            const bool used = i < n;
-            for (int k = 0; k < 3; k++) {
-                // empty slot: a point box at 1e30 (|t| >= 1e30 > any tmax).  NOT an inverted box: the min/max slab test is
-                // symmetric in lo/hi, an inverted box would be hit by every ray
-                q[4 * k + i] = used ? s[i].lo[k] : 1e30f;
-                q[12 + 4 * k + i] = used ? s[i].hi[k] : 1e30f;
+        // quantise the child boxes against the node's own box: plane = org + q * 2^e, lo rounded down, hi rounded up
+        float org[3], ext[3];
+        uint32_t eb[3];
+        for (int k = 0; k < 3; k++) {
+            float lo = 1e30f, hi = -1e30f;
+            for (int i = 0; i < n; i++) { lo = std::min(lo, s[i].lo[k]); hi = std::max(hi, s[i].hi[k]); }
+            org[k] = lo; ext[k] = hi - lo;
+            int e = -100;  // 2^-100: any exponent works for a flat box (all q = 0)
+            if (ext[k] > 0.0f) { int fe; std::frexp((double)ext[k] / 255.0, &fe); e = fe; }  // 2^fe > ext / 255
+            e = std::max(-120, std::min(120, e));
+            for (;; e++) {  // make sure the largest hi is reachable in float arithmetic
+                const float sc = std::ldexp(1.0f, e);
+                if (org[k] + 255.0f * sc >= hi || e >= 120) break;
             }
-            int ref = used ? s[i].ref : 0x7fffffff, cnt = used ? s[i].count : 0;
-            memcpy(q + 24 + i, &ref, 4);
-            memcpy(q + 28 + i, &cnt, 4);
+            eb[k] = (uint32_t)(e + 127);
         }
+        uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const double sc = std::ldexp(1.0, (int)eb[k] - 127);
+                int a = (int)std::floor(((double)s[i].lo[k] - (double)org[k]) / sc);
+                int b2 = (int)std::ceil(((double)s[i].hi[k] - (double)org[k]) / sc);
+                a = std::max(0, std::min(255, a)); b2 = std::max(0, std::min(255, b2));
+                // the device evaluates org + q * scale in fp32: step outwards if rounding landed inside the true box
+                while (a > 0 && org[k] + (float)a * (float)sc > s[i].lo[k]) a--;
+                while (b2 < 255 && org[k] + (float)b2 * (float)sc < s[i].hi[k]) b2++;
+                qlo[k] |= (uint32_t)a << (8 * i);
+                qhi[k] |= (uint32_t)b2 << (8 * i);
+            }
+        uint32_t w[16];
+        memcpy(&w[0], &org[0], 4); memcpy(&w[1], &org[1], 4); memcpy(&w[2], &org[2], 4);
+        w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16);
+        w[4] = qlo[0]; w[5] = qlo[1]; w[6] = qlo[2]; w[7] = qhi[0];
+        w[8] = qhi[1]; w[9] = qhi[2];
+        uint32_t refs[4];
+        for (int i = 0; i < 4; i++) {
+            if (i >= n) refs[i] = NODE_EMPTY;
+            else if (s[i].ref >= 0) refs[i] = (uint32_t)s[i].ref;
+            else refs[i] = 0x80000000u | ((uint32_t)(~s[i].ref) << 3) | (uint32_t)s[i].count;
+        }
+        w[10] = refs[0]; w[11] = refs[1]; w[12] = refs[2]; w[13] = refs[3]; w[14] = 0; w[15] = 0;
+        memcpy(&out[(size_t)out_index * 16], w, sizeof(w));
     }
 };
 }  // namespace
@@ -329,7 +485,7 @@ void build_lbvh(const HostMesh& mesh, Lbvh& out) {
     b.run();
     std::vector<float> binary;
     binary.swap(out.nodes);
-    out.nodes.assign(32, 0.0f);
+    out.nodes.assign(16, 0.0f);
     Collapser c(binary, out.nodes);
     c.emit(0, 0, 1);
     out.binary_depth = out.depth;

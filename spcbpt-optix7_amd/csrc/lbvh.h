@@ -16,7 +16,7 @@ struct HostMesh {  // triangle soup after the quad-light triangles were appended
 };
 
 struct Lbvh {
-    std::vector<float> nodes;      // 32 floats per 4-wide node (layout.h)
+    std::vector<float> nodes;      // 16 dwords per quantised 4-wide node (layout.h)
     std::vector<float> tris;       // 16 floats per triangle, BVH order
     std::vector<int32_t> tri_orig; // BVH order -> input triangle index
     int depth = 0;         // depth of the 4-wide tree

@@ -274,6 +274,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_clear_accum": [vp],
         "spcbpt_get_counters": [vp, C.POINTER(Counters)],
         "spcbpt_reset_counters": [vp],
+        "spcbpt_debug_phase_clocks": [vp, C.POINTER(C.c_uint64)],
         "spcbpt_enable_counters": [vp, i32],
         "spcbpt_stream": [vp, C.POINTER(vp)],
         "spcbpt_sync": [vp],
@@ -314,7 +315,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
-    "spcbpt_reset_counters", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_kernel_time",
+    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -505,6 +506,11 @@ class Renderer:
         c = Counters()
         self._chk(self.lib.spcbpt_get_counters(self.h, C.byref(c)), "get_counters")
         return c.as_dict()
+
+    def phase_clocks(self):
+        out = (C.c_uint64 * 5)()
+        self._chk(self.lib.spcbpt_debug_phase_clocks(self.h, out), "debug_phase_clocks")
+        return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect"), [int(v) for v in out]))
 
     def reset_counters(self):
         self._chk(self.lib.spcbpt_reset_counters(self.h), "reset_counters")

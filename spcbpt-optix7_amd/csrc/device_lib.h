@@ -168,22 +168,27 @@ static constexpr int kTravDone = 0x7fffffff;
 // slab test of the 4 quantised child boxes of a node; misses get key 0xffffffff, hits the entry distance with the slot index
 // in the two low mantissa bits (t >= 0, so unsigned order = float order).  plane distance = (org + q s - o) / d
 // = q (s inv) + (org inv - o inv): two per-axis constants per node, then one byte->float convert and one FMA per plane.
-SPC_DEV void slab4q(const float4 q0, const float4 q1, const float4 q2, const uint32_t ref[4], f3 ood, f3 inv, float tmin, float tmax,
-                    uint32_t key[4]) {
+// The near/far plane of each axis is picked once per node from the sign of the ray direction (swap of the lo/hi byte
+// quads), so no per-child min/max is needed, and an empty slot (qlo = 255, qhi = 0: an inverted box) misses by itself.
+SPC_DEV void slab4q(const float4 q0, const float4 q1, const float4 q2, f3 ood, f3 inv, float tmin, float tmax, uint32_t key[4]) {
     const uint32_t e = __float_as_uint(q0.w);
     const float ax = __uint_as_float((e & 0xffu) << 23) * inv.x, ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * inv.y,
                 az = __uint_as_float(((e >> 16) & 0xffu) << 23) * inv.z;
     const float bx = fmaf(q0.x, inv.x, -ood.x), by = fmaf(q0.y, inv.y, -ood.y), bz = fmaf(q0.z, inv.z, -ood.z);
     const uint32_t lxb = __float_as_uint(q1.x), lyb = __float_as_uint(q1.y), lzb = __float_as_uint(q1.z);
     const uint32_t hxb = __float_as_uint(q1.w), hyb = __float_as_uint(q2.x), hzb = __float_as_uint(q2.y);
+    const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+    const uint32_t nxb = sx ? hxb : lxb, fxb = sx ? lxb : hxb;
+    const uint32_t nyb = sy ? hyb : lyb, fyb = sy ? lyb : hyb;
+    const uint32_t nzb = sz ? hzb : lzb, fzb = sz ? lzb : hzb;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float tx0 = fmaf((float)((lxb >> (8 * i)) & 0xffu), ax, bx), tx1 = fmaf((float)((hxb >> (8 * i)) & 0xffu), ax, bx);
-        const float ty0 = fmaf((float)((lyb >> (8 * i)) & 0xffu), ay, by), ty1 = fmaf((float)((hyb >> (8 * i)) & 0xffu), ay, by);
-        const float tz0 = fmaf((float)((lzb >> (8 * i)) & 0xffu), az, bz), tz1 = fmaf((float)((hzb >> (8 * i)) & 0xffu), az, bz);
-        const float t0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
-        const float t1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
-        key[i] = (ref[i] != NODE_EMPTY && t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
+        const float txn = fmaf((float)((nxb >> (8 * i)) & 0xffu), ax, bx), txf = fmaf((float)((fxb >> (8 * i)) & 0xffu), ax, bx);
+        const float tyn = fmaf((float)((nyb >> (8 * i)) & 0xffu), ay, by), tyf = fmaf((float)((fyb >> (8 * i)) & 0xffu), ay, by);
+        const float tzn = fmaf((float)((nzb >> (8 * i)) & 0xffu), az, bz), tzf = fmaf((float)((fzb >> (8 * i)) & 0xffu), az, bz);
+        const float t0 = fmaxf(fmaxf(txn, tyn), fmaxf(tzn, tmin));
+        const float t1 = fminf(fminf(txf, tyf), fminf(tzf, tmax));
+        key[i] = (t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
     }
 }
 SPC_DEV uint32_t sel4u(const uint32_t r[4], uint32_t i) { return i == 0 ? r[0] : (i == 1 ? r[1] : (i == 2 ? r[2] : r[3])); }
@@ -212,7 +217,7 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
             cn.add(C_NODE);  // one 64-B visit
             const uint32_t ref[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
             uint32_t k[4];
-            slab4q(q0, q1, q2, ref, ood, inv, tmin, best_t, k);
+            slab4q(q0, q1, q2, ood, inv, tmin, best_t, k);
             // sort the four keys ascending: nearest child first (5 compare-exchanges); for any-hit rays the order is irrelevant
             // but the same network compacts the hits to the front
 #define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
@@ -293,7 +298,7 @@ SPC_DEV void shadow_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, 
                 cn.add(C_NODE);
                 const uint32_t ref[4] = {__float_as_uint(q2.z), __float_as_uint(q2.w), __float_as_uint(q3.x), __float_as_uint(q3.y)};
                 uint32_t k[4];
-                slab4q(q0, q1, q2, ref, ood, inv, kEps, tmax, k);
+                slab4q(q0, q1, q2, ood, inv, kEps, tmax, k);
 #define SPC_CSWAP(a, b) { const uint32_t lo__ = min(k[a], k[b]), hi__ = max(k[a], k[b]); k[a] = lo__; k[b] = hi__; }
                 SPC_CSWAP(0, 1) SPC_CSWAP(2, 3) SPC_CSWAP(0, 2) SPC_CSWAP(1, 3) SPC_CSWAP(1, 2)
 #undef SPC_CSWAP

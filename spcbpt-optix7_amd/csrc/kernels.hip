@@ -68,6 +68,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0;
     cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0;
 
+    long long t_ph = COUNT ? clock64() : 0;
+#define SPC_PHASE(slot) do { if (COUNT) { const long long t1__ = clock64(); if (lane == 0) cn.add(slot, (unsigned)((t1__ - t_ph) >> 4)); t_ph = t1__; } } while (0)
     while (true) {
         // ---- regeneration: hand pixel-samples of the pool to idle lanes
         unsigned long long idle = __ballot(!alive);
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             if (exhausted) break;
             continue;
         }
+        SPC_PHASE(C_T_REGEN);
         // ---- phase A (live lanes): extend the path, build the vertex, draw the CONNECTION_N light vertices
         bool finished = false, has_vertex = false;
         int lslot[SPCBPT_CONNECTION_N];
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
         if (alive) {
             HitRec h;
             cn.add(C_CLOSEST);
-            if (!traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn)) {
+            const bool hit_any = traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn);
+            SPC_PHASE(C_T_CLOSEST);
+            if (!hit_any) {
                 finished = true;  // __miss__BDPTVertex
             } else {
                 const Geom g = local_geometry(S, h);
@@ -166,12 +171,14 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             for (int it = 0; it < SPCBPT_CONNECTION_N; it++) w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f);
         }
         if (lane == 0) *w_next = 64u;
+        SPC_PHASE(C_T_SHADE);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- phase B (all 64 lanes, dead ones included): the wave's shadow rays, pulled from the LDS pool
         if (__any(has_vertex)) shadow_pool(S, st, w_org, w_ray, w_vis, w_next, cn);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        SPC_PHASE(C_T_POOL);
         // ---- phase C: connect the unoccluded pairs, in connection order
         if (has_vertex) {
 #pragma unroll
@@ -193,7 +200,9 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             film_write(p, x, y, result);
             alive = false;
         }
+        SPC_PHASE(C_T_CONNECT);
     }
+#undef SPC_PHASE
     cn.flush(p.counters);
 }
 

@@ -17,11 +17,12 @@ namespace spc {
 //   q2 = qhi.y[4], qhi.z[4], ref[0], ref[1]
 //   q3 = ref[2], ref[3], 0, 0
 // ref is the traversal-stack word of the child: internal node index, or 0x80000000 | first triangle << 3 | count for a leaf
-// (count 1..LEAF_MAX), or 0xffffffff for an empty slot.  Quantisation rounds lo down and hi up, so a child box only grows:
-// the nearest hit found is unchanged.
+// (count 1..LEAF_MAX).  An empty slot has ref 0x80000000 (a leaf of zero triangles) and the inverted box qlo = 255, qhi = 0,
+// which the sign-aware slab test of device_lib.h cannot hit.  Quantisation rounds lo down and hi up, so a child box only
+// grows: the nearest hit found is unchanged.
 static const int LEAF_MAX = 4;
 static const int NODE_QUADS = 4;
-static const uint32_t NODE_EMPTY = 0xffffffffu;
+static const uint32_t NODE_EMPTY = 0x80000000u;  // decodes to a leaf of zero triangles: harmless even if a ray "hits" the slot
 
 // One triangle = 64 B = 4 x float4 in BVH order; the intersection test reads the
 // first three quads (48 B), hit shading reads all four:
@@ -70,6 +71,8 @@ struct DSubspace {  // 16 B
 
 enum CounterSlot {
     C_CLOSEST = 0, C_SHADOW, C_NODE, C_TRI, C_VERTEX, C_TEX, C_TREE, C_CMF, C_CONN, C_GQ, C_LVCW, C_PIX, C_EYE, C_LIGHT,
+    C_PUBLIC,  // slots above are spcbpt_counters; the rest are wave-clock totals of the megakernel phases (>> 4), developer only
+    C_T_REGEN = C_PUBLIC, C_T_CLOSEST, C_T_SHADE, C_T_POOL, C_T_CONNECT,
     C_COUNT
 };
 

@@ -185,15 +185,21 @@ struct Builder {
     std::vector<float> blo, bhi;  // per original triangle
     std::vector<int> idx;         // permutation being partitioned
     static constexpr int NB = 32;
+    float node_cost = 1.0f;  // SPCBPT_BVH_NODE_COST (0 = always make the largest leaf that fits); measured on the bench scene: 0.3 -> 13.57 ms, 1 -> 13.04, 2 -> 13.22, leaf-always -> 13.42
     int sah_build(const std::vector<float>& cen, int a, int b, int depth) {
         const int id = (int)snodes.size();
         snodes.push_back({a, b, -1, -1});
         const int cnt = b - a + 1;
-        if (cnt <= LEAF_MAX) return id;
+        if (cnt <= 1 || (cnt <= LEAF_MAX && node_cost <= 0.0f)) return id;
         float clo[3] = {1e30f, 1e30f, 1e30f}, chi[3] = {-1e30f, -1e30f, -1e30f};
+        Box whole; for (int d = 0; d < 3; d++) { whole.lo[d] = 1e30f; whole.hi[d] = -1e30f; }
         for (int i = a; i <= b; i++) {
-            const float* c = &cen[3 * (size_t)idx[i]];
-            for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]); }
+            const int t = idx[i];
+            const float* c = &cen[3 * (size_t)t];
+            for (int k = 0; k < 3; k++) {
+                clo[k] = std::min(clo[k], c[k]); chi[k] = std::max(chi[k], c[k]);
+                whole.lo[k] = std::min(whole.lo[k], blo[3 * (size_t)t + k]); whole.hi[k] = std::max(whole.hi[k], bhi[3 * (size_t)t + k]);
+            }
         }
         struct Bin { float lo[3], hi[3]; int n; };
         Bin bins[3][NB];
@@ -240,6 +246,9 @@ struct Builder {
                 if (cost < best) { best = cost; best_axis = k; best_bin = j; }
             }
         }
+        // a range that fits a leaf is split further only where the surface-area heuristic says the extra node pays for itself
+        // (cost of a triangle test = 1, cost of the extra node slot = node_cost)
+        if (cnt <= LEAF_MAX && (best_axis < 0 || best + node_cost * half_area(whole) >= (float)cnt * half_area(whole))) return id;
         int mid;
         if (best_axis >= 0) {
             const int k = best_axis;
@@ -332,6 +341,7 @@ struct Builder {
         const std::string mode = mode_env ? mode_env : "sah";
         if (mode == "sah" && n > LEAF_MAX) {
             idx = order;  // start from the Morton order: equal-cost ties keep spatial locality
+            if (const char* nc = getenv("SPCBPT_BVH_NODE_COST")) node_cost = (float)atof(nc);
             snodes.reserve((size_t)n);
             sah_build(cen, 0, n - 1, 1);
             order = idx;
@@ -441,7 +451,7 @@ struct Collapser {
             float lo = 1e30f, hi = -1e30f;
             for (int i = 0; i < n; i++) { lo = std::min(lo, s[i].lo[k]); hi = std::max(hi, s[i].hi[k]); }
             org[k] = lo; ext[k] = hi - lo;
-            int e = -100;  // 2^-100: any exponent works for a flat box (all q = 0)
+            int e = 0;  // flat box (all q = 0): scale 1 keeps the inverted box of an empty slot inverted on this axis too
             if (ext[k] > 0.0f) { int fe; std::frexp((double)ext[k] / 255.0, &fe); e = fe; }  // 2^fe > ext / 255
             e = std::max(-120, std::min(120, e));
             for (;; e++) {  // make sure the largest hi is reachable in float arithmetic
@@ -463,6 +473,8 @@ struct Collapser {
                 qlo[k] |= (uint32_t)a << (8 * i);
                 qhi[k] |= (uint32_t)b2 << (8 * i);
             }
+        for (int i = n; i < 4; i++)
+            for (int k = 0; k < 3; k++) qlo[k] |= 255u << (8 * i);  // empty slot: inverted box (qhi stays 0)
         uint32_t w[16];
         memcpy(&w[0], &org[0], 4); memcpy(&w[1], &org[1], 4); memcpy(&w[2], &org[2], 4);
         w[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16);

@@ -35,7 +35,11 @@ struct Check {
         bool seen_empty = false;
         for (int i = 0; i < 4; i++) {
             const uint32_t ref = refs[i];
-            if (ref == 0xffffffffu) { seen_empty = true; continue; }
+            if (ref == 0x80000000u) {
+                seen_empty = true;
+                for (int k = 0; k < 3; k++) if (((qlo[k] >> (8 * i)) & 0xffu) != 255u || ((qhi[k] >> (8 * i)) & 0xffu) != 0u) ok = false;
+                continue;
+            }
             if (seen_empty) ok = false;  // used slots come first
             float slo[3], shi[3];
             for (int k = 0; k < 3; k++) {

@@ -1,0 +1,22 @@
+"""Share of wave-clocks the SPCBPT_eye megakernel spends per phase (counting build), bench scene."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g
+p = g.load_package()
+scene = p.scenes.bedroom()
+W, H = 1920, 1080
+r = p.Renderer(scene, 0)
+c = scene.camera
+r.set_camera_lookat(c["eye"], c["lookat"], c["up"], c["fov"], W / H)
+r.resize(W, H)
+r.set_light_trace(100000, 52, 1)
+r.set_subspace()
+if "--trained" in sys.argv: r.preprocess(2000000, 2000000, True)
+r.render_frame("SPCBPT_eye", 0)
+r.enable_counters(True); r.reset_counters()
+r.launch("SPCBPT_eye", 1)
+r.sync()
+ph = r.phase_clocks()
+tot = sum(ph.values())
+print({k: round(v / tot, 3) for k, v in ph.items()})

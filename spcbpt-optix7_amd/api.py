@@ -508,9 +508,10 @@ class Renderer:
         return c.as_dict()
 
     def phase_clocks(self):
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 9)()
         self._chk(self.lib.spcbpt_debug_phase_clocks(self.h, out), "debug_phase_clocks")
-        return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect"), [int(v) for v in out]))
+        return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect", "node_slots", "node_lanes", "tri_slots", "tri_lanes"),
+                        [int(v) for v in out]))
 
     def reset_counters(self):
         self._chk(self.lib.spcbpt_reset_counters(self.h), "reset_counters")

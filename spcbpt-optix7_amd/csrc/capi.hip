@@ -716,13 +716,14 @@ int spcbpt_get_counters(spcbpt_ctx* c, spcbpt_counters* o) {
     o->eye_paths = h[C_EYE]; o->light_paths = h[C_LIGHT];
     return SPCBPT_OK;
 }
-int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[5]) {
+int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[9]) {
     CTX_CHECK(c);
     if (!out) return SPCBPT_ERR_INVALID_ARG;
     unsigned long long h[C_COUNT];
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 5; i++) out[i] = h[C_PUBLIC + i] << 4;
+    for (int i = 5; i < 9; i++) out[i] = h[C_PUBLIC + i];
     return SPCBPT_OK;
 }
 int spcbpt_reset_counters(spcbpt_ctx* c) {

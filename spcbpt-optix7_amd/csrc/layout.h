@@ -73,6 +73,7 @@ enum CounterSlot {
     C_CLOSEST = 0, C_SHADOW, C_NODE, C_TRI, C_VERTEX, C_TEX, C_TREE, C_CMF, C_CONN, C_GQ, C_LVCW, C_PIX, C_EYE, C_LIGHT,
     C_PUBLIC,  // slots above are spcbpt_counters; the rest are wave-clock totals of the megakernel phases (>> 4), developer only
     C_T_REGEN = C_PUBLIC, C_T_CLOSEST, C_T_SHADE, C_T_POOL, C_T_CONNECT,
+    C_U_NODE_SLOTS, C_U_NODE_LANES, C_U_TRI_SLOTS, C_U_TRI_LANES,  // lane utilisation of the traversal loops: slots = 64 x wave iterations
     C_COUNT
 };
 

@@ -18,5 +18,8 @@ r.enable_counters(True); r.reset_counters()
 r.launch("SPCBPT_eye", 1)
 r.sync()
 ph = r.phase_clocks()
-tot = sum(ph.values())
-print({k: round(v / tot, 3) for k, v in ph.items()})
+names = ("regen", "closest", "shade", "shadow_pool", "connect")
+tot = sum(ph[k] for k in names)
+print({k: round(ph[k] / tot, 3) for k in names})
+print("node-loop lane utilisation", round(ph["node_lanes"] / max(1, ph["node_slots"]), 3), "tri-loop", round(ph["tri_lanes"] / max(1, ph["tri_slots"]), 3),
+      "wave node iterations", ph["node_slots"] // 64, "wave tri iterations", ph["tri_slots"] // 64)

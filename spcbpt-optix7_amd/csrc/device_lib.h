@@ -227,14 +227,14 @@ SPC_DEV uint32_t stack_word(int ref, int count) {
 #define SPC_NODE_STEP(TMIN, TMAX)                                                                                     \
     do {                                                                                                              \
         const size_t nb__ = (size_t)node * NODE_QUADS;                                                                \
-        const float4 q0__ = ldq(S.nodes, nb__ + 0), q1__ = ldq(S.nodes, nb__ + 1), q2__ = ldq(S.nodes, nb__ + 2),      \
-                     q3__ = ldq(S.nodes, nb__ + 3);                                                                   \
+        const float4 Q0 = ldq(S.nodes, nb__ + 0), Q1 = ldq(S.nodes, nb__ + 1), Q2 = ldq(S.nodes, nb__ + 2),            \
+                     Q3 = ldq(S.nodes, nb__ + 3);                                                                     \
         cn.add(C_NODE); /* one 64-B visit */                                                                          \
         SPC_UTIL_COUNT(C_U_NODE_LANES, C_U_NODE_SLOTS)                                                                \
-        const uint32_t ref__[4] = {__float_as_uint(q2__.z), __float_as_uint(q2__.w), __float_as_uint(q3__.x),         \
-                                   __float_as_uint(q3__.y)};                                                          \
+        const uint32_t ref__[4] = {__float_as_uint(Q2.z), __float_as_uint(Q2.w), __float_as_uint(Q3.x),               \
+                                   __float_as_uint(Q3.y)};                                                            \
         uint32_t k__[4];                                                                                              \
-        slab4q(q0__, q1__, q2__, ood, inv, TMIN, TMAX, k__);                                                          \
+        slab4q(Q0, Q1, Q2, ood, inv, TMIN, TMAX, k__);                                                                \
         /* sort the four keys ascending: nearest child first (5 compare-exchanges); misses (0xffffffff) end up last */ \
         SPC_CSWAP__(0, 1) SPC_CSWAP__(2, 3) SPC_CSWAP__(0, 2) SPC_CSWAP__(1, 3) SPC_CSWAP__(1, 2)                      \
         const uint32_t r0__ = sel4u(ref__, k__[0] & 3u), r1__ = sel4u(ref__, k__[1] & 3u),                            \
@@ -267,6 +267,8 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     int leaf_count = 0;  // triangles left in the current leaf
     while (node != kTravDone) {
         if (node >= 0) SPC_NODE_STEP(tmin, best_t);
+        // (a single 64-B fetch per iteration serving node OR triangle lanes was measured: 14.0 ms vs 11.1 ms per frame --
+        // a lane that reaches a leaf then waits a whole iteration for its first triangle)
         if (node < 0 && leaf_count <= 0) {
             SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
         } else if (node < 0) {
@@ -277,7 +279,7 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
             SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)
             bool cull = false;
             if (!ANY) {
-                // emitter flag lives in quad 3; only fetched for closest-hit rays
+                // emitter flag lives in quad 3; only fetched for closest-hit rays (single-sided emitters, q16)
                 cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
             }
             float t, u, v;
@@ -296,61 +298,79 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     return best_tri >= 0;
 }
 
-// ---- wave-cooperative any-hit traversal ------------------------------------------------------------------------------
-// The CONNECTION_N shadow rays of the 64 eye vertices of a wave (192 rays) are pooled in LDS and every lane of the wave --
-// including lanes whose own path has ended -- pulls rays from the pool until it is empty.  Shadow rays differ wildly in
-// length (45 % are occluded after a few nodes, the rest cross the whole scene): with one ray per lane the wave waits for its
-// longest ray and the measured VALU lane utilisation of any-hit traversal is 21 %; pulling keeps the lanes busy.
-//   s_org[64]   origin of the rays owned by lane l (its eye vertex)
-//   s_ray[192]  ray it * 64 + l: direction.xyz, length (< 0: no ray in this slot)
+// ---- wave-cooperative traversal: one closest-hit ray per lane + a pool of shadow rays -----------------------------------
+// Per iteration of the megakernel a wave has up to 64 closest-hit rays (the next path segments) and up to 192 shadow rays
+// (CONNECTION_N per eye vertex of the previous segment).  Neither depends on the other, so both are traced in ONE pass:
+// every lane first traces its own closest-hit ray, then pulls shadow rays from an LDS pool until it is empty -- lanes
+// without a path (ended, or waiting for the next tile) pull from the start.  Ray lengths differ by two orders of magnitude
+// (45 % of the shadow rays are occluded after a few nodes, others cross the whole scene): with one ray per lane per phase
+// the wave waits for its longest ray (measured: 21 % VALU lane utilisation in any-hit traversal); pulling keeps lanes busy.
+//   s_org[64]   origin of the shadow rays owned by lane l (its eye vertex)
+//   s_ray[192]  shadow ray it * 64 + l: direction.xyz, length (< 0: no ray in this slot)
 //   s_vis[192]  out: 1 = unoccluded
-//   s_next      pool cursor, must be 64 on entry (rays 0..63 are claimed statically by lane id)
-// Wave-scope fences order the LDS traffic; all 64 lanes must call this together.
+//   s_next      pool cursor, must be 0 on entry
+// Wave-scope fences around the call order the LDS traffic; all 64 lanes must call this together.
 static constexpr int POOL_RAYS = 64 * SPCBPT_CONNECTION_N;
 template <bool COUNT, int BLOCK, int STACK_LDS>
-SPC_DEV void shadow_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, const float4* s_org, const float4* s_ray, uint8_t* s_vis,
-                         uint32_t* s_next, Counts<COUNT>& cn) {
-    uint32_t r = threadIdx.x & 63;
-    bool done = false;
-    f3 o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f), ood = mk3(0.0f);
-    float tmax = 0.0f;
-    int node = kTravDone, leaf_count = 0;  // kTravDone = this lane holds no ray
+SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, bool own, f3 own_o, f3 own_d, HitRec& own_hit,
+                        const float4* s_org, const float4* s_ray, uint8_t* s_vis, uint32_t* s_next, Counts<COUNT>& cn) {
+    uint32_t r = 0;
+    bool closest = own, done = false;
+    f3 o = own_o, d = own_d;
+    f3 inv = safe_inv(d), ood = o * inv;
+    float best_t = 1e16f, best_u = 0.0f, best_v = 0.0f;
+    int best_tri = -1;
+    int node = own ? 0 : kTravDone, leaf_count = 0;  // kTravDone = this lane holds no ray
+    st.sp = 0;
+    if (own) cn.add(C_CLOSEST);
+    own_hit.t = 1e16f; own_hit.tri = -1; own_hit.u = own_hit.v = 0.0f;
     while (true) {
-        while (node == kTravDone && !done) {  // acquire the next ray of the pool
+        while (node == kTravDone && !done) {  // acquire the next shadow ray of the pool
+            r = atomicAdd(s_next, 1u);
             if (r >= (uint32_t)POOL_RAYS) { done = true; break; }
             const float4 rq = s_ray[r];
-            if (rq.w < 0.0f) { r = atomicAdd(s_next, 1u); continue; }
+            if (rq.w < 0.0f) continue;
             const float4 oq = s_org[r & 63u];
             o = mk3(oq.x, oq.y, oq.z); d = mk3(rq.x, rq.y, rq.z);
             inv = safe_inv(d); ood = o * inv;
-            tmax = rq.w - kEps;
+            best_t = rq.w - kEps;
             node = 0; st.sp = 0;
             cn.add(C_SHADOW);
         }
         if (!__any(node != kTravDone)) break;
         if (node != kTravDone) {
             bool finished = false, occluded = false;
-            if (node >= 0) { SPC_NODE_STEP(kEps, tmax); finished = node == kTravDone; }
+            if (node >= 0) { SPC_NODE_STEP(kEps, best_t); finished = node == kTravDone; }
             if (node < 0 && leaf_count <= 0) {
-                SPC_TRAV_POP();
+                SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
                 finished = node == kTravDone;
             } else if (node < 0) {
-                const size_t base = (size_t)(~node) * 4;
+                const int tri = ~node;
+                const size_t base = (size_t)tri * 4;
                 const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
                 cn.add(C_TRI);
                 SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)
+                bool cull = false;
+                if (closest) cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;  // single-sided emitters
                 float t, u, v;
-                if (tri_test(a, b, c, o, d, kEps, tmax, false, t, u, v)) {
+                const bool h = tri_test(a, b, c, o, d, kEps, best_t, cull, t, u, v);
+                if (h && !closest) {
                     occluded = true; finished = true; node = kTravDone;
                 } else {
-                    node -= 1;
+                    if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }
+                    node -= 1;  // ~(tri + 1)
                     leaf_count -= 1;
                     if (leaf_count == 0) { SPC_TRAV_POP(); finished = node == kTravDone; }
                 }
             }
             if (finished) {
-                s_vis[r] = occluded ? (uint8_t)0 : (uint8_t)1;
-                r = atomicAdd(s_next, 1u);
+                if (closest) {
+                    own_hit.t = best_t; own_hit.tri = best_tri; own_hit.u = best_u; own_hit.v = best_v;
+                    closest = false;
+                    best_tri = -1;
+                } else {
+                    s_vis[r] = occluded ? (uint8_t)0 : (uint8_t)1;
+                }
             }
         }
     }

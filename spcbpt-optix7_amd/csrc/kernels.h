@@ -29,6 +29,9 @@ void launch_wf_gen(const KParams& p, const WfState& wf, bool count, hipStream_t 
 void launch_wf_bounce(const KParams& p, const WfState& wf, int bounce, bool count, size_t bound, hipStream_t s);
 void launch_wf_film(const KParams& p, const WfState& wf, hipStream_t s);
 
-static const int kStackLds = 20;  // LDS traversal-stack entries per lane (20 KB per block); with the 16.4 KB shadow-ray pool of k_spcbpt four blocks fit a CU
+#ifndef SPC_STACK_LDS
+#define SPC_STACK_LDS 20
+#endif
+static const int kStackLds = SPC_STACK_LDS;  // LDS traversal-stack entries per lane (20 KB per block); with the 16.4 KB shadow-ray pool of k_spcbpt four blocks fit a CU
 
 }  // namespace spc

@@ -16,7 +16,10 @@ namespace spc {
 static constexpr int BLOCK = 256;
 static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
 #ifndef SPC_WAVES
-#define SPC_WAVES 4  // measured on MI355X (bedroom 1080p): 2 -> 38.8 ms, 3 -> 31.6, 4 -> 28.3, 5 -> 29.3; minimum waves per SIMD requested from the register allocator for the megakernel
+// minimum waves per SIMD requested from the register allocator for the megakernel.  Measured on MI355X (bedroom 1080p, ms per
+// frame) with the pooled if-if traversal: 2 (241 VGPR, no scratch) -> 12.86, 3 (168 VGPR, 252 B scratch) -> 10.72,
+// 4 (128 VGPR, 452 B) -> 11.01, 5 (96 VGPR, 688 B) -> 14.16.  (Before the pooled traversal 4 was the optimum.)
+#define SPC_WAVES 3
 #endif
 
 // pixel of this lane: 8x8 tile per wave, 4 tiles (in x) per block, bands of 8 rows selected by (row_begin, row_step)
@@ -68,6 +71,13 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0;
     cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0;
 
+    // software pipeline: the vertex built in iteration i is connected in iteration i + 1, in the same traversal pass that
+    // extends the path by its next segment (the next direction is drawn before the connections, hit_program.cu:324-337)
+    bool has_vertex = false, has_ray = false;
+    int lslot[SPCBPT_CONNECTION_N];
+    float conn_pmf[SPCBPT_CONNECTION_N];
+#pragma unroll
+    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lslot[it] = 0; conn_pmf[it] = 1.0f; w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f); }
     long long t_ph = COUNT ? clock64() : 0;
 #define SPC_PHASE(slot) do { if (COUNT) { const long long t1__ = clock64(); if (lane == 0) cn.add(slot, (unsigned)((t1__ - t_ph) >> 4)); t_ph = t1__; } } while (0)
     while (true) {
@@ -89,6 +99,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                 const uint32_t slot = (uint32_t)(64 - pool_left + my_rank);
                 if (tile_pixel(p, pool_tile, slot, x, y)) {
                     alive = true;
+                    has_ray = true;
                     w.dir = camera_ray(p, x, y, w.seed);
                     w.origin = ld3(p.eye);
                     w.done = false;
@@ -113,18 +124,39 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             continue;
         }
         SPC_PHASE(C_T_REGEN);
-        // ---- phase A (live lanes): extend the path, build the vertex, draw the CONNECTION_N light vertices
-        bool finished = false, has_vertex = false;
-        int lslot[SPCBPT_CONNECTION_N];
-        float conn_pmf[SPCBPT_CONNECTION_N];
+        // ---- traversal pass: the next segment of every live path and the shadow rays of the vertices built last iteration
+        if (lane == 0) *w_next = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        HitRec h;
+        trace_pool(S, st, alive && has_ray, w.origin, w.dir, h, w_org, w_ray, w_vis, w_next, cn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        SPC_PHASE(C_T_POOL);
+        // ---- connect the unoccluded pairs of the previous vertex, in connection order
+        if (has_vertex) {
 #pragma unroll
-        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lslot[it] = 0; conn_pmf[it] = 1.0f; }
-        if (alive) {
-            HitRec h;
-            cn.add(C_CLOSEST);
-            const bool hit_any = traverse<false, COUNT>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn);
-            SPC_PHASE(C_T_CLOSEST);
-            if (!hit_any) {
+            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                if (w_ray[it * 64 + lane].w >= 0.0f && w_vis[it * 64 + lane]) {
+                    LightVertex b;
+                    const float4* src = reinterpret_cast<const float4*>(p.lvc + lslot[it]);
+                    float4* dst = reinterpret_cast<float4*>(&b);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) dst[q] = src[q];
+                    f3 res = connect_vertices(p, cur, b, cn);
+                    if (is_invalid(res)) res = mk3(0.0f);
+                    res = res / conn_pmf[it];
+                    if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+                }
+            }
+        }
+        has_vertex = false;
+        bool finished = alive && !has_ray;  // the path ended at that vertex (Russian roulette / depth): nothing was traced
+        SPC_PHASE(C_T_CONNECT);
+        // ---- the new segment: miss, emitter, or a new vertex with its CONNECTION_N resampled light vertices
+        if (alive && has_ray) {
+            has_ray = false;
+            if (h.tri < 0) {
                 finished = true;  // __miss__BDPTVertex
             } else {
                 const Geom g = local_geometry(S, h);
@@ -162,7 +194,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                         w_ray[it * 64 + lane] = rq;
                     }
                     w_org[lane] = make_float4(cur.c.pos.x, cur.c.pos.y, cur.c.pos.z, 0.0f);
-                    if (w.done || depth > 50) finished = true;  // the loop-top test of raygen.cu:361 (after this vertex's connections)
+                    // the loop-top test of raygen.cu:361: a path that ends here still connects this vertex (next iteration)
+                    has_ray = !(w.done || depth > 50);
                 }
             }
         }
@@ -170,37 +203,11 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
 #pragma unroll
             for (int it = 0; it < SPCBPT_CONNECTION_N; it++) w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f);
         }
-        if (lane == 0) *w_next = 64u;
-        SPC_PHASE(C_T_SHADE);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- phase B (all 64 lanes, dead ones included): the wave's shadow rays, pulled from the LDS pool
-        if (__any(has_vertex)) shadow_pool(S, st, w_org, w_ray, w_vis, w_next, cn);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        SPC_PHASE(C_T_POOL);
-        // ---- phase C: connect the unoccluded pairs, in connection order
-        if (has_vertex) {
-#pragma unroll
-            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                if (w_ray[it * 64 + lane].w >= 0.0f && w_vis[it * 64 + lane]) {
-                    LightVertex b;
-                    const float4* src = reinterpret_cast<const float4*>(p.lvc + lslot[it]);
-                    float4* dst = reinterpret_cast<float4*>(&b);
-#pragma unroll
-                    for (int q = 0; q < 6; q++) dst[q] = src[q];
-                    f3 res = connect_vertices(p, cur, b, cn);
-                    if (is_invalid(res)) res = mk3(0.0f);
-                    res = res / conn_pmf[it];
-                    if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
-                }
-            }
-        }
         if (alive && finished) {
             film_write(p, x, y, result);
             alive = false;
         }
-        SPC_PHASE(C_T_CONNECT);
+        SPC_PHASE(C_T_SHADE);
     }
 #undef SPC_PHASE
     cn.flush(p.counters);

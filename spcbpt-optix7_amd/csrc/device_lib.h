@@ -549,14 +549,18 @@ SPC_DEV int tree_label(const float* tree, f3 position, f3 normal, f3 dir, Counts
     if (!tree) return 0;
     int node = 0;
     while (true) {
-        const float4 q0 = ldq(tree, (size_t)node * TREE_QUADS);
+        // the whole 48-B node in one round trip (the child index used to be a second, dependent load per level)
+        const float4 q0 = ldq(tree, (size_t)node * TREE_QUADS), q1 = ldq(tree, (size_t)node * TREE_QUADS + 1),
+                     q2 = ldq(tree, (size_t)node * TREE_QUADS + 2);
         cn.add(C_TREE);
         const uint32_t meta = __float_as_uint(q0.w);
         if (meta & 4u) return (int)(meta >> 3);
         const uint32_t type = meta & 3u;
         const f3 p = type == 0 ? position : (type == 1 ? normal : dir);
-        const int ind = (p.x > q0.x ? 1 : 0) + (p.y > q0.y ? 2 : 0) + (p.z > q0.z ? 4 : 0);
-        node = reinterpret_cast<const int*>(tree)[(size_t)node * (TREE_QUADS * 4) + 4 + ind];
+        const bool bx = p.x > q0.x, by = p.y > q0.y, bz = p.z > q0.z;
+        const float4 qz = bz ? q2 : q1;                                   // children 4..7 : 0..3
+        const float c0 = by ? qz.z : qz.x, c1 = by ? qz.w : qz.y;          // +2
+        node = __float_as_int(bx ? c1 : c0);                              // +1
     }
 }
 

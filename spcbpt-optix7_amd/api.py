@@ -508,9 +508,9 @@ class Renderer:
         return c.as_dict()
 
     def phase_clocks(self):
-        out = (C.c_uint64 * 9)()
+        out = (C.c_uint64 * 10)()
         self._chk(self.lib.spcbpt_debug_phase_clocks(self.h, out), "debug_phase_clocks")
-        return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect", "node_slots", "node_lanes", "tri_slots", "tri_lanes"),
+        return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect", "node_slots", "node_lanes", "tri_slots", "tri_lanes", "sample_lane_clocks"),
                         [int(v) for v in out]))
 
     def reset_counters(self):

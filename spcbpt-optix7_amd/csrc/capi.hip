@@ -716,7 +716,7 @@ int spcbpt_get_counters(spcbpt_ctx* c, spcbpt_counters* o) {
     o->eye_paths = h[C_EYE]; o->light_paths = h[C_LIGHT];
     return SPCBPT_OK;
 }
-int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[9]) {
+int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[10]) {
     CTX_CHECK(c);
     if (!out) return SPCBPT_ERR_INVALID_ARG;
     unsigned long long h[C_COUNT];
@@ -724,6 +724,7 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[9]) {
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 5; i++) out[i] = h[C_PUBLIC + i] << 4;
     for (int i = 5; i < 9; i++) out[i] = h[C_PUBLIC + i];
+    out[9] = h[C_T_SAMPLE] << 4;  // summed over lanes (every lane that samples adds its own clock delta)
     return SPCBPT_OK;
 }
 int spcbpt_reset_counters(spcbpt_ctx* c) {

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
                     cur = mid;
                     has_vertex = true;
+                    long long t_s0 = COUNT ? clock64() : 0;
                     // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419).  Only the
                     // position quad of the light vertex is fetched here (visibilityTest, cuProg.h:463-487); the connection
                     // itself does not consume random numbers, so drawing all three first leaves the RNG stream unchanged.
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                         }
                         w_ray[it * 64 + lane] = rq;
                     }
+                    if (COUNT) cn.add(C_T_SAMPLE, (unsigned)((clock64() - t_s0) >> 4));
                     w_org[lane] = make_float4(cur.c.pos.x, cur.c.pos.y, cur.c.pos.z, 0.0f);
                     // the loop-top test of raygen.cu:361: a path that ends here still connects this vertex (next iteration)
                     has_ray = !(w.done || depth > 50);

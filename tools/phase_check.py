@@ -21,5 +21,7 @@ ph = r.phase_clocks()
 names = ("regen", "closest", "shade", "shadow_pool", "connect")
 tot = sum(ph[k] for k in names)
 print({k: round(ph[k] / tot, 3) for k in names})
+cnt = r.counters()
+print("resampling lane-clocks per vertex", ph["sample_lane_clocks"] / max(1, cnt["surface_vertices"]), "shade wave-clocks per wave-vertex (64 lanes)", ph["shade"] / max(1, cnt["surface_vertices"] / 64))
 print("node-loop lane utilisation", round(ph["node_lanes"] / max(1, ph["node_slots"]), 3), "tri-loop", round(ph["tri_lanes"] / max(1, ph["tri_slots"]), 3),
       "wave node iterations", ph["node_slots"] // 64, "wave tri iterations", ph["tri_slots"] // 64)

@@ -75,61 +75,144 @@ bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& 
     return ok;
 }
 
-// Minimal OBJ reader: v, vt, f (fan triangulation, negative indices, v / v/vt / v//vn / v/vt/vn).
+// OBJ reader with the semantics of the reference's vendored (old-API) tinyobj as scene_shift.cpp:187-250 consumes it; pinned
+// bit-exactly against that loader by tests/test_scene_file.py (vectors: tests/golden/ref_loaders.npz).  Restated behaviour:
+//  * leading blanks are skipped; `#` lines are comments; `v`, `vn` (only counted), `vt`, `f`, and the group breaks
+//    `usemtl`, `g`, `o`; everything else is ignored (a missing .mtl only produces a warning there);
+//  * face corners are i, i/j, i//k or i/j/k; index 0 means 0, negative indices are relative to the current counts;
+//  * faces collect into a group that is flushed into ONE shape at every `usemtl` / `g` / `o` and at end of file;
+//    vertices are de-duplicated per flush on the whole (v, vn, vt) triple -- normals are discarded later but still split
+//    vertices -- and created in fan order (corner 0, k-1, k);
+//  * a texcoord pair is appended only for corners that carry a vt index, so the UV array of a shape with mixed corners is
+//    shorter than (and misaligned with) the position array; scene_shift.cpp:204-207 pads it with zeros at the END.  The
+//    misalignment is the reference's behaviour and is kept.
+struct ObjCorner {
+    int v, vn, vt;
+    bool operator<(const ObjCorner& o) const {
+        if (v != o.v) return v < o.v;
+        if (vn != o.vn) return vn < o.vn;
+        return vt < o.vt;
+    }
+};
+int obj_fix_index(int idx, int n) { return idx > 0 ? idx - 1 : (idx == 0 ? 0 : n + idx); }
+// One number of a `v` / `vt` line.  The reference's loader does not use strtod: its grammar is [sign] digits [. digits]
+// [(e|E) [sign] digits] -- ".5" or "-.5" are NOT numbers and read as 0 -- and its value is assembled as
+// sign * ldexp(m * 5^e, e) with m accumulated digit by digit in double (fraction digit k adds d * 10^-k).  Restated so
+// that coordinates are bit-identical, including the quirks.
+float obj_float(const char*& p) {
+    p += strspn(p, " \t");
+    const char* q = p;
+    const char* end = p + strcspn(p, " \t\r");
+    p = end;
+    if (q >= end) return 0.0f;
+    double sign = 1.0;
+    if (*q == '+' || *q == '-') { sign = *q == '-' ? -1.0 : 1.0; q++; }
+    double m = 0.0;
+    int digits = 0;
+    while (q != end && *q >= '0' && *q <= '9') { m = m * 10.0 + (double)(*q - '0'); q++; digits++; }
+    if (digits == 0) return 0.0f;  // also covers a lone sign and a leading '.'
+    int e = 0;
+    if (q != end && *q == '.') {
+        q++;
+        for (int k = 1; q != end && *q >= '0' && *q <= '9'; q++, k++) m += (double)(*q - '0') * pow(10.0, (double)-k);
+    }
+    if (q != end && (*q == 'e' || *q == 'E')) {
+        q++;
+        int es = 1;
+        if (q != end && (*q == '+' || *q == '-')) { es = *q == '-' ? -1 : 1; q++; }
+        else if (!(q != end && *q >= '0' && *q <= '9')) return 0.0f;  // empty exponent: the whole number fails
+        int ed = 0;
+        while (q != end && *q >= '0' && *q <= '9') { e = e * 10 + (*q - '0'); q++; ed++; }
+        if (ed == 0) return 0.0f;
+        e *= es;
+    }
+    return (float)(sign * ldexp(m * pow(5.0, (double)e), e));
+}
 bool load_obj(const std::string& path, spcbpt_scene_file& s, int material) {
     FILE* f = fopen(path.c_str(), "r");
     if (!f) return false;
     std::vector<float> pos, tc;
-    std::map<std::pair<int, int>, uint32_t> cache;
-    char line[kMaxLine];
-    auto vertex = [&](int vi, int ti) -> uint32_t {
-        auto key = std::make_pair(vi, ti);
-        auto it = cache.find(key);
-        if (it != cache.end()) return it->second;
-        uint32_t id = (uint32_t)(s.V.size() / 3);
-        s.V.push_back(pos[3 * (size_t)vi]); s.V.push_back(pos[3 * (size_t)vi + 1]); s.V.push_back(pos[3 * (size_t)vi + 2]);
-        if (ti >= 0) { s.UV.push_back(tc[2 * (size_t)ti]); s.UV.push_back(tc[2 * (size_t)ti + 1]); }
-        else { s.UV.push_back(0.0f); s.UV.push_back(0.0f); }  // scene_shift.cpp:204-207
-        cache[key] = id;
-        return id;
-    };
-    while (fgets(line, kMaxLine, f)) {
-        if (line[0] == 'v' && line[1] == ' ') {
-            float x, y, z;
-            if (sscanf(line + 2, "%f %f %f", &x, &y, &z) == 3) { pos.push_back(x); pos.push_back(y); pos.push_back(z); }
-        } else if (line[0] == 'v' && line[1] == 't') {
-            float u = 0, v = 0;
-            if (sscanf(line + 2, "%f %f", &u, &v) >= 1) { tc.push_back(u); tc.push_back(v); }
-        } else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t')) {
-            std::vector<uint32_t> poly;
-            char* p = line + 1;
-            while (*p) {
-                while (*p == ' ' || *p == '\t') p++;
-                if (!*p || *p == '\n' || *p == '\r') break;
-                int vi = 0, ti = 0;
-                bool has_t = false;
-                char* end;
-                vi = (int)strtol(p, &end, 10);
-                if (end == p) break;
-                p = end;
-                if (*p == '/') {
-                    p++;
-                    if (*p != '/') { ti = (int)strtol(p, &end, 10); has_t = end != p; p = end; }
-                    if (*p == '/') { p++; strtol(p, &end, 10); p = end; }
-                }
-                const int nv = (int)(pos.size() / 3), nt = (int)(tc.size() / 2);
-                vi = vi < 0 ? nv + vi : vi - 1;
-                ti = has_t ? (ti < 0 ? nt + ti : ti - 1) : -1;
-                if (vi < 0 || vi >= nv) { fclose(f); return false; }
-                if (ti >= nt) ti = -1;
-                poly.push_back(vertex(vi, ti));
-            }
-            for (size_t k = 2; k < poly.size(); k++) {
-                s.I.push_back(poly[0]); s.I.push_back(poly[k - 1]); s.I.push_back(poly[k]);
+    int n_normals = 0;
+    std::vector<std::vector<ObjCorner>> group;
+    char raw[8192];
+    auto flush = [&]() {
+        if (group.empty()) return;
+        std::map<ObjCorner, uint32_t> cache;
+        const size_t v0 = s.V.size() / 3;  // first vertex of this shape in the soup
+        std::vector<float> uv;             // this shape's texcoords, tinyobj style (only corners with a vt)
+        auto vertex = [&](const ObjCorner& c) -> uint32_t {
+            auto it = cache.find(c);
+            if (it != cache.end()) return it->second;
+            const uint32_t id = (uint32_t)(s.V.size() / 3);
+            const bool ok = c.v >= 0 && (size_t)c.v * 3 + 2 < pos.size();
+            for (int k = 0; k < 3; k++) s.V.push_back(ok ? pos[3 * (size_t)c.v + k] : 0.0f);
+            if (c.vt >= 0 && (size_t)c.vt * 2 + 1 < tc.size()) { uv.push_back(tc[2 * (size_t)c.vt]); uv.push_back(tc[2 * (size_t)c.vt + 1]); }
+            cache[c] = id;
+            return id;
+        };
+        for (const auto& face : group) {
+            if (face.size() < 3) continue;
+            for (size_t k = 2; k < face.size(); k++) {
+                const uint32_t a = vertex(face[0]), b = vertex(face[k - 1]), c = vertex(face[k]);
+                s.I.push_back(a); s.I.push_back(b); s.I.push_back(c);
                 s.M.push_back(material);
             }
         }
+        const size_t nv = s.V.size() / 3 - v0;
+        uv.resize(2 * nv, 0.0f);  // scene_shift.cpp:204-207 (pads, never truncates: uv.size() <= 2 nv by construction)
+        s.UV.insert(s.UV.end(), uv.begin(), uv.end());
+        group.clear();
+    };
+    while (fgets(raw, sizeof(raw), f)) {
+        size_t n = strlen(raw);
+        while (n > 0 && (raw[n - 1] == '\n' || raw[n - 1] == '\r')) raw[--n] = 0;
+        const char* p = raw + strspn(raw, " \t");
+        if (*p == 0 || *p == '#') continue;
+        auto blank = [](char c) { return c == ' ' || c == '\t'; };
+        if (p[0] == 'v' && blank(p[1])) {
+            p += 2;
+            const float x = obj_float(p), y = obj_float(p), z = obj_float(p);
+            pos.push_back(x); pos.push_back(y); pos.push_back(z);
+        } else if (p[0] == 'v' && p[1] == 'n' && blank(p[2])) {
+            n_normals++;
+        } else if (p[0] == 'v' && p[1] == 't' && blank(p[2])) {
+            p += 3;
+            const float u = obj_float(p), v = obj_float(p);
+            tc.push_back(u); tc.push_back(v);
+        } else if (p[0] == 'f' && blank(p[1])) {
+            p += 2;
+            p += strspn(p, " \t");
+            std::vector<ObjCorner> face;
+            const int nv = (int)(pos.size() / 3), nt = (int)(tc.size() / 2);
+            while (*p && *p != '\r' && *p != '\n') {
+                ObjCorner c = {-1, -1, -1};
+                c.v = obj_fix_index(atoi(p), nv);
+                p += strcspn(p, "/ \t\r");
+                if (*p == '/') {
+                    p++;
+                    if (*p == '/') {  // i//k
+                        p++;
+                        c.vn = obj_fix_index(atoi(p), n_normals);
+                        p += strcspn(p, "/ \t\r");
+                    } else {          // i/j or i/j/k
+                        c.vt = obj_fix_index(atoi(p), nt);
+                        p += strcspn(p, "/ \t\r");
+                        if (*p == '/') {
+                            p++;
+                            c.vn = obj_fix_index(atoi(p), n_normals);
+                            p += strcspn(p, "/ \t\r");
+                        }
+                    }
+                }
+                face.push_back(c);
+                p += strspn(p, " \t\r");
+            }
+            group.push_back(face);
+        } else if ((strncmp(p, "usemtl", 6) == 0 && blank(p[6])) || (p[0] == 'g' && blank(p[1])) || (p[0] == 'o' && blank(p[1]))) {
+            flush();
+        }
     }
+    flush();
     fclose(f);
     return true;
 }

@@ -61,6 +61,54 @@ def ref_vectors():
     np.savez(os.path.join(HERE, "ref_camera.npz"), cams=np.array(cams, dtype=np.float32))
 
 
+
+OBJ_CASES = {
+    # authored here (data, not reference text): the OBJ features the scene hand-off can meet
+    "tri_quad_fan": "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 1.5 0\nf 1 2 3\nf 1 2 3 4\nf 1 2 3 4 5\n",
+    "uv_shared_and_split": "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvt 0.5 0.5\n"
+                           "f 1/1 2/2 3/3\nf 1/1 3/3 4/4\nf 1/5 2/2 4/4\n",
+    "negative_and_normals": "v 0 0 0\nv 2 0 0\nv 2 2 0\nvn 0 0 1\nvt 0.25 0.75\nf -3//1 -2//1 -1//1\nv 0 2 0\nf -4/1/1 -2/1/1 -1/1/1\n",
+    "groups_and_objects": "o first\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\ng second\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf 4 5 6\no third\nf 1 5 3\n",
+    "mixed_uv_then_none": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0.1 0.2\nvt 0.3 0.4\nvt 0.5 0.6\nf 1/1 2/2 3/3\nf 2 4 3\n",
+    "comments_blank_tabs": "# a comment\n\nv\t0 0 0\nv 1   0 0\n  v 0 1 0\n#f 1 2 3\nf 1 2 3\n\n",
+    "number_formats": "v 0.1 1e-3 123456.789\nv -0.000123 3.14159265358979 .5\nv 5. -7 +2.5E+2\nv 1 2\nv 1e 2e+ -x\nv 0.30000001 7.0E-08 16777217\nvt 0.333333333 0.6666667\nvt 1\nvt 2 3\nf 1/1 2/2 3/3\nf 4/1 1/2 2/3\nf 5/1 6/2 1/3\n",
+    "zero_index_and_short_faces": "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 0 2 3\nf 1 2\nf 1 2 3\n",
+    "usemtl_splits_shapes": "v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nusemtl a\nf 1 2 3\nusemtl b\nf 2 4 3\n",
+}
+
+
+def ref_loaders():
+    """Row f1 pins: the reference's vendored tinyobj (old API) and stb_image, driven as scene_shift.cpp drives them."""
+    import tempfile
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref.so"))
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, text in OBJ_CASES.items():
+            p = os.path.join(d, name + ".obj")
+            open(p, "w").write(text)
+            nv, ni = C.c_int(), C.c_int()
+            sv, si = (C.c_int * 16)(), (C.c_int * 16)()
+            ns = lib.ref_obj_load(p.encode(), C.byref(nv), C.byref(ni), sv, si, 16, None, None, None)
+            pos = np.zeros((nv.value, 3), np.float32); uv = np.zeros((nv.value, 2), np.float32); idx = np.zeros(ni.value, np.uint32)
+            lib.ref_obj_load(p.encode(), C.byref(nv), C.byref(ni), sv, si, 16, pos.ctypes.data_as(C.c_void_p),
+                             uv.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p))
+            out[name + "__text"] = np.frombuffer(text.encode(), dtype=np.uint8)
+            out[name + "__pos"] = pos; out[name + "__uv"] = uv; out[name + "__idx"] = idx
+            out[name + "__shape_v"] = np.array(sv[:ns], np.int32); out[name + "__shape_i"] = np.array(si[:ns], np.int32)
+        rng = np.random.default_rng(11)
+        for k, (w, h) in enumerate([(1, 1), (5, 3), (16, 16)]):
+            rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+            p = os.path.join(d, f"t{k}.ppm")
+            open(p, "wb").write(b"P6\n# made by make_golden\n%d %d\n255\n" % (w, h) + rgb.tobytes())
+            ww, hh = C.c_int(), C.c_int()
+            px = np.zeros((h, w, 4), np.uint8)
+            rc = lib.ref_image_load(p.encode(), C.byref(ww), C.byref(hh), px.ctypes.data_as(C.c_void_p), px.nbytes)
+            assert rc == 0 and (ww.value, hh.value) == (w, h)
+            out[f"ppm{k}__file"] = np.frombuffer(open(p, "rb").read(), dtype=np.uint8)
+            out[f"ppm{k}__rgba"] = px
+    np.savez_compressed(os.path.join(HERE, "ref_loaders.npz"), **out)
+
+
 def survey_kat():
     np.savez(os.path.join(HERE, "survey_kat.npz"),
              tea4_7_3=np.uint32(2175312897),
@@ -100,6 +148,7 @@ def oracle_regression():
 
 if __name__ == "__main__":
     ref_vectors()
+    ref_loaders()
     survey_kat()
     oracle_regression()
     print("golden vectors written to", HERE)

@@ -268,8 +268,9 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
  * its phases since the last reset: [0] regeneration, [1] closest-hit traversal, [2] vertex + resampling, [3] pooled shadow
  * traversal, [4] connection + film (only ratios are meaningful); [5..8] lane utilisation of the traversal loops of all
  * kernels: node-loop slots (64 x wave iterations) and lanes, triangle-loop slots and lanes; [9] lane-clocks of the two-stage
- * resampling (part of [2], summed over the lanes that sample). */
-int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[10]);
+ * resampling (part of [2], summed over the lanes that sample); [10..13] 100 MHz wall clock of the megakernel's waves: earliest
+ * start, latest end, sum of ends, number of waves (how long the last waves run alone). */
+int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[14]);
 /* Enable/disable event counting in the kernels (off for timed runs). */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 

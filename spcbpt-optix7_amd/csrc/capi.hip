@@ -716,7 +716,7 @@ int spcbpt_get_counters(spcbpt_ctx* c, spcbpt_counters* o) {
     o->eye_paths = h[C_EYE]; o->light_paths = h[C_LIGHT];
     return SPCBPT_OK;
 }
-int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[10]) {
+int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[14]) {
     CTX_CHECK(c);
     if (!out) return SPCBPT_ERR_INVALID_ARG;
     unsigned long long h[C_COUNT];
@@ -724,12 +724,14 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[10]) {
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 5; i++) out[i] = h[C_PUBLIC + i] << 4;
     for (int i = 5; i < 9; i++) out[i] = h[C_PUBLIC + i];
-    out[9] = h[C_T_SAMPLE] << 4;  // summed over lanes (every lane that samples adds its own clock delta)
+    out[9] = h[C_T_SAMPLE] << 4;
+    out[10] = h[C_W_START_MIN]; out[11] = h[C_W_END_MAX]; out[12] = h[C_W_END_SUM]; out[13] = h[C_W_WAVES];  // summed over lanes (every lane that samples adds its own clock delta)
     return SPCBPT_OK;
 }
 int spcbpt_reset_counters(spcbpt_ctx* c) {
     CTX_CHECK(c);
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, C_COUNT * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters + C_W_START_MIN, 0xff, sizeof(unsigned long long), c->stream));
     return SPCBPT_OK;
 }
 int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; return SPCBPT_OK; }

@@ -37,8 +37,12 @@ SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
 // The SPCBPT megakernel: persistent waves with per-lane path regeneration.  A wave pulls 8x8 pixel tiles from a global
 // queue (one atomicAdd per tile); a lane whose eye path ends writes its pixel and immediately starts the next
 // pixel-sample of the wave's pool, so the 64 lanes stay busy although path lengths differ by an order of magnitude.
-// Every iteration runs the same phases for all live lanes: closest-hit traversal -> vertex -> 3 x (two-stage
-// resampling, shadow traversal, connection).  The queue counter saturates, so every wave reaches the exit.
+// Every iteration runs the same phases for all live lanes: pooled traversal pass -> connections of the previous vertex ->
+// new vertex + two-stage resampling.  The queue counter saturates, so every wave reaches the exit.
+// Known cost: an eye path may live for 50 bounces (a dependent chain of milliseconds); once the queue is empty the waves drain
+// their last paths with ever fewer live lanes -- measured with the wave clocks of the counting build, the average wave has
+// left after 83 % of the kernel span.  Ordering the queue by the longest path each tile held in the previous frame did not
+// shorten that (long paths are decided by Russian roulette, not by the pixel).
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
@@ -78,6 +82,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     float conn_pmf[SPCBPT_CONNECTION_N];
 #pragma unroll
     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lslot[it] = 0; conn_pmf[it] = 1.0f; w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f); }
+    const unsigned long long w_start = COUNT ? wall_clock64() : 0ull;
     long long t_ph = COUNT ? clock64() : 0;
 #define SPC_PHASE(slot) do { if (COUNT) { const long long t1__ = clock64(); if (lane == 0) cn.add(slot, (unsigned)((t1__ - t_ph) >> 4)); t_ph = t1__; } } while (0)
     while (true) {
@@ -212,6 +217,13 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
         SPC_PHASE(C_T_SHADE);
     }
 #undef SPC_PHASE
+    if (COUNT && p.counters && lane == 0) {
+        const unsigned long long w_end = wall_clock64();
+        atomicMin(&p.counters[C_W_START_MIN], w_start);
+        atomicMax(&p.counters[C_W_END_MAX], w_end);
+        atomicAdd(&p.counters[C_W_END_SUM], w_end);
+        atomicAdd(&p.counters[C_W_WAVES], 1ull);
+    }
     cn.flush(p.counters);
 }
 

@@ -25,3 +25,8 @@ cnt = r.counters()
 print("resampling lane-clocks per vertex", ph["sample_lane_clocks"] / max(1, cnt["surface_vertices"]), "shade wave-clocks per wave-vertex (64 lanes)", ph["shade"] / max(1, cnt["surface_vertices"] / 64))
 print("node-loop lane utilisation", round(ph["node_lanes"] / max(1, ph["node_slots"]), 3), "tri-loop", round(ph["tri_lanes"] / max(1, ph["tri_slots"]), 3),
       "wave node iterations", ph["node_slots"] // 64, "wave tri iterations", ph["tri_slots"] // 64)
+
+if ph["waves"]:
+    total = (ph["wave_end_max"] - ph["wave_start_min"]) / 100.0   # microseconds
+    mean_end = (ph["wave_end_sum"] / ph["waves"] - ph["wave_start_min"]) / 100.0
+    print(f"waves {ph['waves']}: kernel span {total:.0f} us, mean wave end at {mean_end:.0f} us -> the average wave idles {100 * (1 - mean_end / total):.1f} % of the span")

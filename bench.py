@@ -211,7 +211,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel_ms": round(k_ms, 4), "launches": k_n},
             "kernels_ms": {"spcbpt_render": round(k_ms, 4), "light_trace": round(lt_ms, 4), "lvc_compact": round(cp_ms, 4),
-                           "sampler_build": round(sb_ms, 4)},
+                           "sampler_build": round(sb_ms, 4),
+                           "note": "HIP-event spans per stream; the light pass of frame f+1 is enqueued on its own stream and runs "
+                                   "under the drain phase of frame f's eye kernel, so its span includes waiting for free slots"},
             "events_per_eye_path": {k: round(v / max(c_eye["eye_paths"], 1), 3) for k, v in c_eye.items()
                                     if k in ("closest_rays", "shadow_rays", "node_visits", "tri_tests", "surface_vertices",
                                              "connections", "tree_nodes", "cmf_probes")},

@@ -44,18 +44,28 @@ static void dev_free(T*& p) {
     p = nullptr;
 }
 
-void Context::time_begin(const char* name) {
+void Context::time_begin(const char* name, hipStream_t s) {
     if (!timing) return;
     TimedSpan sp;
     sp.name = name;
+    sp.s = s ? s : stream;
     (void)hipEventCreate(&sp.a);
     (void)hipEventCreate(&sp.b);
-    (void)hipEventRecord(sp.a, stream);
+    (void)hipEventRecord(sp.a, sp.s);
     spans.push_back(sp);
 }
 void Context::time_end() {
     if (!timing || spans.empty()) return;
-    (void)hipEventRecord(spans.back().b, stream);
+    (void)hipEventRecord(spans.back().b, spans.back().s);
+}
+int Context::sync_all() {
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    if (rstream != stream) HIP_TRY(this, hipStreamSynchronize(rstream));
+    return 0;
+}
+// the members d_lvc / d_vals2 / d_cmfs / d_subspace / d_sampler_counts always name the set of the light pass in progress
+void Context::select_set(int s) {
+    d_lvc = set_lvc[s]; d_vals2 = set_vals2[s]; d_cmfs = set_cmfs[s]; d_subspace = set_subspace[s]; d_sampler_counts = set_counts[s];
 }
 void Context::resolve_spans() {
     for (auto& sp : spans) {
@@ -72,17 +82,19 @@ void Context::resolve_spans() {
     spans.clear();
 }
 
-int Context::ensure_spill(size_t threads) {
+int Context::ensure_spill(size_t threads, bool render) {
     const int entries = std::max(0, 3 * bvh_depth - kStackLds);  // a 4-wide node pushes up to 3 children
     kp.spill_entries = entries;
     if (entries == 0) { kp.spill = nullptr; return 0; }
     const size_t need = threads * (size_t)entries;
-    if (need > spill_capacity) {
-        dev_free(d_spill);
-        HIP_TRY(this, dev_alloc(&d_spill, need));
-        spill_capacity = need;
+    uint32_t*& buf = render ? d_spill_r : d_spill;   // one area per stream: kernels of both may be in flight together
+    size_t& cap = render ? spill_r_capacity : spill_capacity;
+    if (need > cap) {
+        dev_free(buf);   // hipFree waits for the device
+        HIP_TRY(this, dev_alloc(&buf, need));
+        cap = need;
     }
-    kp.spill = d_spill;
+    kp.spill = buf;
     return 0;
 }
 
@@ -110,6 +122,7 @@ int Context::upload_tree(const spcbpt_tree_node* t, int n, float*& d_tree, std::
 
 int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_tree_node* lt, int nl, const float* q, const float* g) {
     if (!et || !lt || !q || !g || ne < 1 || nl < 1) { error = "set_subspace: all four of eye_tree, light_tree, q, cmf_gamma are required"; return SPCBPT_ERR_INVALID_ARG; }
+    if (sync_all()) return SPCBPT_ERR_HIP;  // a render launch may still be reading the tuple that is replaced in place
     int rc = upload_tree(et, ne, d_eye_tree, h_eye_tree);
     if (rc) return rc;
     rc = upload_tree(lt, nl, d_light_tree, h_light_tree);
@@ -150,14 +163,18 @@ int Context::set_light_trace(const spcbpt_light_trace_params& p) {
 
 int Context::ensure_lvc_capacity(size_t n) {
     if (n <= lvc_capacity) return 0;
-    dev_free(d_lvc); dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_vals2); dev_free(d_weights);
-    dev_free(d_wsorted); dev_free(d_prefix); dev_free(d_cmfs);
-    HIP_TRY(this, dev_alloc(&d_lvc, n));
+    if (sync_all()) return SPCBPT_ERR_HIP;
+    dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_weights);
+    dev_free(d_wsorted); dev_free(d_prefix);
+    for (int s = 0; s < 2; s++) {   // what the eye pass reads is double-buffered (see context.h)
+        dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
+        HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
+    }
+    select_set(lset);
     HIP_TRY(this, dev_alloc(&d_keys, n)); HIP_TRY(this, dev_alloc(&d_keys2, n));
-    HIP_TRY(this, dev_alloc(&d_vals, n)); HIP_TRY(this, dev_alloc(&d_vals2, n));
+    HIP_TRY(this, dev_alloc(&d_vals, n));
     HIP_TRY(this, dev_alloc(&d_weights, n));
     HIP_TRY(this, dev_alloc(&d_wsorted, n)); HIP_TRY(this, dev_alloc(&d_prefix, n));
-    HIP_TRY(this, dev_alloc(&d_cmfs, n));
     lvc_capacity = n;
     lvc_count = 0;
     have_sampler = false;
@@ -187,6 +204,10 @@ int Context::launch_light(uint32_t frame) {
     int rc = ensure_spill(((size_t)lt.core_count + 255) / 256 * 256);
     if (rc) return rc;
     kp.counters = counting ? d_counters : nullptr;
+    // write the set the eye pass is NOT reading; it was last read by the render launch before the previous one
+    lset ^= 1;
+    select_set(lset);
+    if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_render[lset], 0));
     HIP_TRY(this, hipMemsetAsync(d_core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), stream));
     HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), stream));
     kp.path_counter = d_sampler_counts + 1;
@@ -251,6 +272,9 @@ int Context::build_sampler() {
     if (fetch_counts()) return SPCBPT_ERR_HIP;
     kp.lvc = d_lvc; kp.subspace = d_subspace; kp.cmfs = d_cmfs; kp.jump = reinterpret_cast<const int32_t*>(d_vals2);
     kp.sampler_counts = d_sampler_counts;
+    eset = lset;
+    HIP_TRY(this, hipEventRecord(ev_sampler[eset], stream));
+    ev_sampler_set[eset] = true;
     have_sampler = true;
     return 0;
 }
@@ -263,35 +287,47 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }
     kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
     kp.counters = counting ? d_counters : nullptr;
+    if (spcbpt_alg) {
+        // the sampler tables this launch reads (set `eset`) were built on `stream`
+        kp.lvc = set_lvc[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset];
+        kp.jump = reinterpret_cast<const int32_t*>(set_vals2[eset]); kp.sampler_counts = set_counts[eset];
+        if (rstream != stream && ev_sampler_set[eset]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[eset], 0));
+    }
     if (spcbpt_alg && !eye_megakernel) {
         kp.n_tiles = (uint32_t)render_tile_count(kp);
-        time_begin(name);
+        time_begin(name, rstream);
         int rcw = launch_wavefront();
         time_end();
         if (rcw) return rcw;
         HIP_TRY(this, hipGetLastError());
+        HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
+        ev_render_set[eset] = true;
         return 0;
     }
-    int rc = ensure_spill((size_t)render_thread_count(kp));
+    int rc = ensure_spill((size_t)render_thread_count(kp), true);
     if (rc) return rc;
     if (spcbpt_alg) {
         kp.n_tiles = (uint32_t)render_tile_count(kp);
         kp.work_counter = d_work_counter;
-        HIP_TRY(this, hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), stream));
+        HIP_TRY(this, hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), rstream));
         if (!blocks_per_cu[counting]) blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
     }
-    time_begin(name);
-    if (spcbpt_alg) launch_spcbpt(kp, counting, num_cus * blocks_per_cu[counting], stream);
-    else launch_pt(kp, counting, stream);
+    time_begin(name, rstream);
+    if (spcbpt_alg) launch_spcbpt(kp, counting, num_cus * blocks_per_cu[counting], rstream);
+    else launch_pt(kp, counting, rstream);
     time_end();
     HIP_TRY(this, hipGetLastError());
+    if (spcbpt_alg) {
+        HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
+        ev_render_set[eset] = true;
+    }
     return 0;
 }
 
 // Wavefront eye pass: state arrays for `slots` path slots (a multiple of 64) in one allocation.
 int Context::ensure_wf(size_t slots) {
     if (slots > wf_slots_capacity) {
-        HIP_TRY(this, hipStreamSynchronize(stream));
+        HIP_TRY(this, hipStreamSynchronize(rstream));
         dev_free(d_wf_block);
         d_wf_block = nullptr;
         // float4 per slot: WF_ARRAYS state arrays + 3 x (conn_ray, conn_rec, contrib); dwords per slot: 2 queues + 3 vis
@@ -321,23 +357,23 @@ int Context::launch_wavefront() {
     if (slots == 0) return 0;
     int rc = ensure_wf(slots);
     if (rc) return rc;
-    rc = ensure_spill(slots * SPCBPT_CONNECTION_N);  // one traversal stack per shadow-ray record
+    rc = ensure_spill(slots * SPCBPT_CONNECTION_N, true);  // one traversal stack per shadow-ray record
     if (rc) return rc;
-    HIP_TRY(this, hipMemsetAsync(wf.counts, 0, (size_t)WF_MAX_BOUNCES * WFC_ROW * sizeof(uint32_t), stream));
-    launch_wf_gen(kp, wf, counting, stream);
+    HIP_TRY(this, hipMemsetAsync(wf.counts, 0, (size_t)WF_MAX_BOUNCES * WFC_ROW * sizeof(uint32_t), rstream));
+    launch_wf_gen(kp, wf, counting, rstream);
     size_t bound = slots;
     int b = 0;
     for (; b < WF_MAX_BOUNCES - 1; b++) {
-        launch_wf_bounce(kp, wf, b, counting, bound, stream);
+        launch_wf_bounce(kp, wf, b, counting, bound, rstream);
         if ((b & 7) == 7) {
-            HIP_TRY(this, hipMemcpyAsync(h_wf_counts, wf.counts + (size_t)(b + 1) * WFC_ROW, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(this, hipStreamSynchronize(stream));
+            HIP_TRY(this, hipMemcpyAsync(h_wf_counts, wf.counts + (size_t)(b + 1) * WFC_ROW, sizeof(uint32_t), hipMemcpyDeviceToHost, rstream));
+            HIP_TRY(this, hipStreamSynchronize(rstream));
             bound = h_wf_counts[0];
             if (bound == 0) { b++; break; }
         }
     }
     wf_bounces_last = b;
-    launch_wf_film(kp, wf, stream);
+    launch_wf_film(kp, wf, rstream);
     return 0;
 }
 
@@ -386,10 +422,16 @@ Context::~Context() {
     dev_free(d_nodes); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
     dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);
-    dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_lvc); dev_free(d_keys); dev_free(d_keys2);
-    dev_free(d_vals); dev_free(d_vals2); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix); dev_free(d_cmfs);
-    dev_free(d_subspace); dev_free(d_sampler_counts); dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
+    dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
+    dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
+    for (int s = 0; s < 2; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
+    dev_free(d_spill_r); dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
+    if (rstream && rstream != stream) (void)hipStreamDestroy(rstream);
     if (stream) (void)hipStreamDestroy(stream);
+    for (int s = 0; s < 2; s++) {
+        if (ev_sampler[s]) (void)hipEventDestroy(ev_sampler[s]);
+        if (ev_render[s]) (void)hipEventDestroy(ev_render[s]);
+    }
 }
 
 }  // namespace spc
@@ -432,6 +474,15 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         if (e__ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e__); delete c; return SPCBPT_ERR_HIP; } \
     } while (0)
     CREATE_TRY(hipStreamCreate(&c->stream));
+    {
+        const char* ov = getenv("SPCBPT_OVERLAP");
+        if (ov && std::string(ov) == "0") c->rstream = c->stream;
+        else CREATE_TRY(hipStreamCreate(&c->rstream));
+        for (int s = 0; s < 2; s++) {
+            CREATE_TRY(hipEventCreateWithFlags(&c->ev_sampler[s], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
+        }
+    }
 
     // ---- scene assembly (scene_shift.cpp:64-154, 184-328)
     std::vector<float> V(sc->vertices, sc->vertices + 3 * (size_t)sc->n_vertices);
@@ -514,9 +565,12 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     }
     CREATE_TRY(dev_alloc(&c->d_tex, texs.size()));
     if (!texs.empty()) CREATE_TRY(hipMemcpy(c->d_tex, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
-    CREATE_TRY(dev_alloc(&c->d_subspace, (size_t)SPCBPT_NUM_SUBSPACE));
-    CREATE_TRY(dev_alloc(&c->d_sampler_counts, (size_t)2));
-    CREATE_TRY(hipMemset(c->d_sampler_counts, 0, 2 * sizeof(int)));
+    for (int s = 0; s < 2; s++) {
+        CREATE_TRY(dev_alloc(&c->set_subspace[s], (size_t)SPCBPT_NUM_SUBSPACE));
+        CREATE_TRY(dev_alloc(&c->set_counts[s], (size_t)2));
+        CREATE_TRY(hipMemset(c->set_counts[s], 0, 2 * sizeof(int)));
+    }
+    c->select_set(0);
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
@@ -542,7 +596,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
 int spcbpt_destroy(spcbpt_ctx* c) {
     if (!c) return SPCBPT_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)c->sync_all();
     delete c;
     return SPCBPT_OK;
 }
@@ -581,7 +635,7 @@ int spcbpt_set_camera_lookat(spcbpt_ctx* c, const float eye[3], const float look
 int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
     CTX_CHECK(c);
     if (w < 1 || h < 1 || (long long)w * h > (1ll << 28)) { c->error = "bad image size"; return SPCBPT_ERR_INVALID_ARG; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     dev_free(c->d_accum); dev_free(c->d_frame);
     HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
     HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
@@ -600,7 +654,7 @@ int spcbpt_set_subspace(spcbpt_ctx* c, const spcbpt_tree_node* et, int ne, const
 int spcbpt_set_light_trace(spcbpt_ctx* c, const spcbpt_light_trace_params* p) {
     CTX_CHECK(c);
     if (!p) { c->error = "null params"; return SPCBPT_ERR_INVALID_ARG; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     return c->set_light_trace(*p);
 }
 
@@ -638,7 +692,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
         HIP_TRY(c, hipMemcpyAsync(c->d_lvc, verts, (size_t)count * sizeof(LightVertex), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     int h[2] = {count, 0};
     HIP_TRY(c, hipMemcpyAsync(c->d_sampler_counts, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     c->lvc_count = count;
     c->keys_ready = false;
     c->have_sampler = false;
@@ -662,7 +716,7 @@ int spcbpt_sampler_read(spcbpt_ctx* c, spcbpt_subspace* sub, float* cmfs, int32_
     CTX_CHECK(c);
     if (!c->have_sampler) { c->error = "no sampler built"; return SPCBPT_ERR_STATE; }
     if (!sub || !vc || !pc) return SPCBPT_ERR_INVALID_ARG;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     std::vector<DSubspace> h(SPCBPT_NUM_SUBSPACE);
     HIP_TRY(c, hipMemcpy(h.data(), c->d_subspace, h.size() * sizeof(DSubspace), hipMemcpyDeviceToHost));
     for (int i = 0; i < SPCBPT_NUM_SUBSPACE; i++) {
@@ -680,14 +734,14 @@ int spcbpt_sampler_read(spcbpt_ctx* c, spcbpt_subspace* sub, float* cmfs, int32_
 int spcbpt_read_accum(spcbpt_ctx* c, float* out) {
     CTX_CHECK(c);
     if (!out || !c->d_accum) { c->error = "no accum buffer"; return SPCBPT_ERR_STATE; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     HIP_TRY(c, hipMemcpy(out, c->d_accum, (size_t)c->kp.width * c->kp.height * 16, hipMemcpyDeviceToHost));
     return SPCBPT_OK;
 }
 int spcbpt_read_frame(spcbpt_ctx* c, uint8_t* out) {
     CTX_CHECK(c);
     if (!out || !c->d_frame) { c->error = "no frame buffer"; return SPCBPT_ERR_STATE; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     HIP_TRY(c, hipMemcpy(out, c->d_frame, (size_t)c->kp.width * c->kp.height * 4, hipMemcpyDeviceToHost));
     return SPCBPT_OK;
 }
@@ -700,7 +754,7 @@ int spcbpt_accum_device_ptr(spcbpt_ctx* c, void** p) {
 int spcbpt_clear_accum(spcbpt_ctx* c) {
     CTX_CHECK(c);
     if (!c->d_accum) return SPCBPT_ERR_STATE;
-    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->kp.width * c->kp.height * 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->kp.width * c->kp.height * 16, c->rstream));  // ordered with the render launches
     return SPCBPT_OK;
 }
 
@@ -708,7 +762,7 @@ int spcbpt_get_counters(spcbpt_ctx* c, spcbpt_counters* o) {
     CTX_CHECK(c);
     if (!o) return SPCBPT_ERR_INVALID_ARG;
     unsigned long long h[C_COUNT];
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     o->closest_rays = h[C_CLOSEST]; o->shadow_rays = h[C_SHADOW]; o->node_visits = h[C_NODE]; o->tri_tests = h[C_TRI];
     o->surface_vertices = h[C_VERTEX]; o->textured_hits = h[C_TEX]; o->tree_nodes = h[C_TREE]; o->cmf_probes = h[C_CMF];
@@ -720,7 +774,7 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[14]) {
     CTX_CHECK(c);
     if (!out) return SPCBPT_ERR_INVALID_ARG;
     unsigned long long h[C_COUNT];
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 5; i++) out[i] = h[C_PUBLIC + i] << 4;
     for (int i = 5; i < 9; i++) out[i] = h[C_PUBLIC + i];
@@ -730,6 +784,7 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[14]) {
 }
 int spcbpt_reset_counters(spcbpt_ctx* c) {
     CTX_CHECK(c);
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, C_COUNT * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_counters + C_W_START_MIN, 0xff, sizeof(unsigned long long), c->stream));
     return SPCBPT_OK;
@@ -737,7 +792,7 @@ int spcbpt_reset_counters(spcbpt_ctx* c) {
 int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; return SPCBPT_OK; }
 
 int spcbpt_stream(spcbpt_ctx* c, void** s) { CTX_CHECK(c); if (!s) return SPCBPT_ERR_INVALID_ARG; *s = (void*)c->stream; return SPCBPT_OK; }
-int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SPCBPT_OK; }
+int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); if (c->sync_all()) return SPCBPT_ERR_HIP; return SPCBPT_OK; }
 
 int spcbpt_kernel_time(spcbpt_ctx* c, const char* name, double* avg_ms, int* launches) {
     CTX_CHECK(c);
@@ -768,7 +823,7 @@ int spcbpt_trace_closest(spcbpt_ctx* c, const float* rays, int n, float* out_t, 
     if (rc) { dev_free(d_rays); return rc; }
     HIP_TRY(c, dev_alloc(&d_t, (size_t)n)); HIP_TRY(c, dev_alloc(&d_tri, (size_t)n)); HIP_TRY(c, dev_alloc(&d_uv, (size_t)n * 2));
     launch_trace_closest(c->kp, d_rays, n, d_t, d_tri, d_uv, c->stream);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = c->sync_all() ? hipErrorUnknown : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost);
@@ -784,7 +839,7 @@ int spcbpt_trace_any(spcbpt_ctx* c, const float* rays, int n, int32_t* out_visib
     if (rc) { dev_free(d_rays); return rc; }
     HIP_TRY(c, dev_alloc(&d_vis, (size_t)n));
     launch_trace_any(c->kp, d_rays, n, d_vis, c->stream);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = c->sync_all() ? hipErrorUnknown : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(out_visible, d_vis, (size_t)n * 4, hipMemcpyDeviceToHost);
     dev_free(d_rays); dev_free(d_vis);
     if (e != hipSuccess) { c->error = hipGetErrorString(e); return SPCBPT_ERR_HIP; }

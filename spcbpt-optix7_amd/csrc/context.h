@@ -17,11 +17,30 @@ struct Preprocessor;
 struct TimedSpan {
     std::string name;
     hipEvent_t a, b;
+    hipStream_t s;
 };
 
 struct Context {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // light pass, sampler build, preprocessing, uploads
+    // Render launches ("pt", "SPCBPT_eye") run on their own stream.  The eye megakernel ends with a drain phase (paths of up
+    // to 50 bounces finishing with ever fewer live lanes: the average wave has left after 83 % of the kernel span), and the
+    // light pass + sampler build of the NEXT frame do not depend on it.  With the sampler tables double-buffered, the host
+    // loop launch("light trace") -> build_sampler -> launch("SPCBPT_eye") keeps its meaning while frame f+1's light pass
+    // fills the idle machine under frame f's drain.  SPCBPT_OVERLAP=0 puts everything back on one stream.
+    hipStream_t rstream = nullptr;
+    hipEvent_t ev_sampler[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr};
+    bool ev_sampler_set[2] = {false, false}, ev_render_set[2] = {false, false};
+    int lset = 0, eset = 0;  // buffer set of the light pass / sampler build in progress, and of the sampler eye launches use
+    LightVertex* set_lvc[2] = {nullptr, nullptr};
+    uint32_t* set_vals2[2] = {nullptr, nullptr};
+    float* set_cmfs[2] = {nullptr, nullptr};
+    DSubspace* set_subspace[2] = {nullptr, nullptr};
+    int* set_counts[2] = {nullptr, nullptr};
+    uint32_t* d_spill_r = nullptr;   // traversal-stack spill area of the render stream (d_spill serves `stream`)
+    size_t spill_r_capacity = 0;
+    int sync_all();
+    void select_set(int s);
     std::string error;
     KParams kp;
     // scene
@@ -83,10 +102,10 @@ struct Context {
     std::map<std::string, std::pair<double, int>> times;
 
     ~Context();
-    void time_begin(const char* name);
+    void time_begin(const char* name, hipStream_t s = nullptr);
     void time_end();
     void resolve_spans();
-    int ensure_spill(size_t threads);
+    int ensure_spill(size_t threads, bool render = false);
     int ensure_temp(size_t bytes);
     int ensure_wf(size_t slots);
     int launch_wavefront();

@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--light-paths", type=int, default=100_000)
     ap.add_argument("--tuple", default="minimal", choices=["minimal", "trained"])
+    ap.add_argument("--scene-route", default="gltf", choices=["gltf", "memory"],
+                    help="gltf: write the generated scene as glTF 2.0 and read it back with the C++ reader (default); memory: hand the arrays over directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
     ap.add_argument("--write-image", default="")
@@ -111,6 +113,13 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     scene = make_scene(pkg, args.scene, args.tris)
+    if args.scene_route == "gltf":
+        # BASELINE config 2: "bedroom-class glTF scene" -- the generated scene goes to disk as glTF 2.0 (binary buffers + PPM
+        # textures) and comes back through the library's C++ glTF reader (spcbpt_gltf_load), every rank for itself
+        import tempfile
+        with tempfile.TemporaryDirectory(prefix="spcbpt_bench_") as tmp:
+            scene, warn = pkg.load_gltf(pkg.scenes.write_gltf(scene, tmp, args.scene))
+            if warn: print("glTF warnings:", warn, file=sys.stderr)
     r = pkg.Renderer(scene, local_rank)
     cam = scene.camera
     r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
@@ -202,7 +211,7 @@ def main():
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} scene ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
+            "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
                        "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},

@@ -365,6 +365,13 @@ int spcbpt_get_subspace(spcbpt_ctx* ctx,
  * and stays valid until spcbpt_scene_file_free.  Needs no GPU. */
 typedef struct spcbpt_scene_file spcbpt_scene_file;
 int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt_scene_file** out);
+/* glTF 2.0 (.gltf with external / base64 buffers, or .glb) into the same handle, read the way the reference's own glTF route
+ * reads it (sutil::loadScene + processGLTFNode, sutil/Scene.cpp:119-210, 266-550; never called by the reference app): root
+ * nodes = nodes without a parent, transform = parent * matrix^T * T * R * S in fp32, TRIANGLES primitives with POSITION /
+ * TEXCOORD_0 / indices, baseColor / metallic / roughness factors, baseColorTexture (binary PPM images only), first perspective
+ * camera.  Quad lights come from the caller or from this build's root `extras.spcbpt_quad_lights`.  On failure the message
+ * is written to `error` (may be NULL). */
+int spcbpt_gltf_load(const char* path, spcbpt_scene_file** out, char* error, int error_capacity);
 int spcbpt_scene_file_desc(spcbpt_scene_file* s, spcbpt_scene_desc* desc);
 int spcbpt_scene_file_camera(spcbpt_scene_file* s, float eye[3], float lookat[3], float up[3], float* fov_y_deg,
                              int* width, int* height);

@@ -176,6 +176,25 @@ def load_scene_file(scene_path: str, data_root: str):
     rc = lib.spcbpt_scene_file_load(scene_path.encode(), data_root.encode(), C.byref(h))
     if rc != 0:
         raise SpcbptError(f"spcbpt_scene_file_load({scene_path}) failed ({rc})")
+    return _scene_from_handle(lib, h, os.path.basename(scene_path))
+
+
+def load_gltf(path: str, lights=None):
+    """Reads a glTF 2.0 file (.gltf / .glb) with the library's C++ reader (spcbpt_gltf_load).  `lights` (list of quad-light
+    dicts) replaces whatever the file's `extras.spcbpt_quad_lights` holds.  Returns (scene, warnings)."""
+    lib = load_library()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.spcbpt_gltf_load(path.encode(), C.byref(h), err, 512)
+    if rc != 0:
+        raise SpcbptError(f"spcbpt_gltf_load({path}) failed ({rc}): {err.value.decode()}")
+    scene, warn = _scene_from_handle(lib, h, os.path.basename(path))
+    if lights is not None:
+        scene.lights = list(lights)
+    return scene, warn
+
+
+def _scene_from_handle(lib, h, name):
     try:
         d = SceneDesc()
         lib.spcbpt_scene_file_desc(h, C.byref(d))
@@ -203,7 +222,7 @@ def load_scene_file(scene_path: str, data_root: str):
         cam = dict(eye=tuple(eye), lookat=tuple(look), up=tuple(up), fov=fov.value, width=w.value, height=hh.value)
         warn = lib.spcbpt_scene_file_warnings(h).decode()
         return Scene(vertices=V, indices=I, tri_material=M, materials=mats, lights=lights, texcoords=UV, textures=texs,
-                     camera=cam, name=os.path.basename(scene_path)), warn
+                     camera=cam, name=name), warn
     finally:
         lib.spcbpt_scene_file_free(h)
 
@@ -291,6 +310,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_train_records_clear": [vp],
         "spcbpt_preprocess_stage": [vp, i32, i32],
         "spcbpt_get_gamma": [vp, vp],
+        "spcbpt_gltf_load": [C.c_char_p, C.POINTER(vp), C.c_char_p, i32],
         "spcbpt_scene_file_load": [C.c_char_p, C.c_char_p, C.POINTER(vp)],
         "spcbpt_scene_file_desc": [vp, C.POINTER(SceneDesc)],
         "spcbpt_scene_file_camera": [vp, f32p, f32p, f32p, f32p, C.POINTER(i32), C.POINTER(i32)],
@@ -319,7 +339,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
-    "spcbpt_get_gamma", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
+    "spcbpt_get_gamma", "spcbpt_gltf_load", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
     "spcbpt_scene_file_warnings", "spcbpt_scene_file_free",
 ]
 

@@ -1,0 +1,499 @@
+// glTF 2.0 ingestion (BASELINE config 2 words the bench scene as "bedroom-class glTF scene").
+// What is read, and how, follows the reference's own glTF route sutil::loadScene / processGLTFNode (sutil/Scene.cpp:266-550,
+// 119-210) -- a route the reference app never calls (optixPathTracer.cpp:735-736), so this row is a widening, not the hot path:
+//   * every node that is nobody's child is a root (the `scenes` array is ignored);
+//   * node transform = parent * matrix^T * T * R * S in fp32 (the vendored tinygltf does not load T/R/S when `matrix` is present);
+//   * only TRIANGLES primitives; POSITION float3, TEXCOORD_0 float2, indices u16 / u32 (u8 and none are accepted here too);
+//     buffer-view byteStride honoured; instances are baked: world position = node_xform * (p, 1);
+//   * materials: baseColorFactor, metallicFactor, roughnessFactor, baseColorTexture -> texture -> image (the reference leaves
+//     absent factors uninitialised; the glTF defaults 1 / 1 / 1 are used);
+//   * a perspective camera node gives eye = xform * origin, up = xform * +Y, fovY in degrees; the reference keeps
+//     sutil::Camera's default look-at (0, 0, 0) -- kept, unless the node carries this build's `extras.spcbpt_lookat`.
+// Lights: glTF has no area lights and the reference adds its quad lights in the app, so they come from the caller, or from
+// this build's root-level `extras.spcbpt_quad_lights` = [{position, u, v, emission, divLevel}] (u, v absolute corners as in
+// the .scene format).  Images: binary PPM (uri or bufferView with mimeType image/x-portable-pixmap) -- PNG/JPEG decoding (stb
+// in the reference) is not rebuilt; such images produce a warning and the material keeps its flat colour.
+// The mesh / transform / camera arithmetic is pinned bit-exactly against the reference's vendored tinygltf + sutil::Matrix4x4 /
+// Quaternion (oracle/_ref/libref_gltf.so, tests/golden/ref_gltf.npz, tests/test_gltf.py).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "scene_file.h"
+
+namespace {
+
+// ---- a small JSON reader (objects keep insertion order; numbers are doubles) ------------------------------------------
+struct J {
+    enum Type { Null, Bool, Num, Str, Arr, Obj } t = Null;
+    bool b = false;
+    double n = 0;
+    std::string s;
+    std::vector<J> a;
+    std::vector<std::pair<std::string, J>> o;
+    const J* get(const char* k) const {
+        if (t != Obj) return nullptr;
+        for (auto& kv : o) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+    double num(const char* k, double d) const { const J* v = get(k); return v && v->t == Num ? v->n : d; }
+    int integer(const char* k, int d) const { const J* v = get(k); return v && v->t == Num ? (int)v->n : d; }
+    std::string str(const char* k, const char* d = "") const { const J* v = get(k); return v && v->t == Str ? v->s : std::string(d); }
+    size_t size() const { return t == Arr ? a.size() : 0; }
+};
+struct JParser {
+    const char* p; const char* end; std::string err;
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+    bool fail(const char* m) { if (err.empty()) err = m; return false; }
+    static void utf8(std::string& out, unsigned c) {
+        if (c < 0x80) out += (char)c;
+        else if (c < 0x800) { out += (char)(0xC0 | (c >> 6)); out += (char)(0x80 | (c & 63)); }
+        else { out += (char)(0xE0 | (c >> 12)); out += (char)(0x80 | ((c >> 6) & 63)); out += (char)(0x80 | (c & 63)); }
+    }
+    bool str(std::string& out) {
+        if (p >= end || *p != '"') return fail("expected string");
+        p++;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                p++;
+                if (p >= end) return fail("bad escape");
+                switch (*p) {
+                    case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                    case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                    case 'u': {
+                        if (end - p < 5) return fail("bad \\u");
+                        unsigned c = (unsigned)strtoul(std::string(p + 1, p + 5).c_str(), nullptr, 16);
+                        utf8(out, c); p += 4; break;
+                    }
+                    default: out += *p;
+                }
+                p++;
+            } else out += *p++;
+        }
+        if (p >= end) return fail("unterminated string");
+        p++;
+        return true;
+    }
+    bool value(J& v, int depth = 0) {
+        if (depth > 64) return fail("nesting too deep");
+        ws();
+        if (p >= end) return fail("unexpected end");
+        if (*p == '{') {
+            v.t = J::Obj; p++; ws();
+            if (p < end && *p == '}') { p++; return true; }
+            while (true) {
+                ws();
+                std::string k;
+                if (!str(k)) return false;
+                ws();
+                if (p >= end || *p != ':') return fail("expected ':'");
+                p++;
+                v.o.emplace_back(k, J());
+                if (!value(v.o.back().second, depth + 1)) return false;
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == '}') { p++; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (*p == '[') {
+            v.t = J::Arr; p++; ws();
+            if (p < end && *p == ']') { p++; return true; }
+            while (true) {
+                v.a.emplace_back();
+                if (!value(v.a.back(), depth + 1)) return false;
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == ']') { p++; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (*p == '"') { v.t = J::Str; return str(v.s); }
+        if (end - p >= 4 && !strncmp(p, "true", 4)) { v.t = J::Bool; v.b = true; p += 4; return true; }
+        if (end - p >= 5 && !strncmp(p, "false", 5)) { v.t = J::Bool; v.b = false; p += 5; return true; }
+        if (end - p >= 4 && !strncmp(p, "null", 4)) { v.t = J::Null; p += 4; return true; }
+        char* e = nullptr;
+        v.n = strtod(p, &e);
+        if (e == p) return fail("unexpected character");
+        v.t = J::Num; p = e;
+        return true;
+    }
+};
+
+bool read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0) { fclose(f); return false; }
+    out.resize((size_t)n);
+    const bool ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    fclose(f);
+    return ok;
+}
+bool base64(const std::string& in, size_t from, std::vector<uint8_t>& out) {
+    auto val = [](char c) -> int {
+        if (c >= 'A' && c <= 'Z') return c - 'A';
+        if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+        if (c >= '0' && c <= '9') return c - '0' + 52;
+        if (c == '+') return 62;
+        if (c == '/') return 63;
+        return -1;
+    };
+    unsigned acc = 0; int bits = 0;
+    for (size_t i = from; i < in.size(); i++) {
+        if (in[i] == '=') break;
+        const int v = val(in[i]);
+        if (v < 0) continue;
+        acc = (acc << 6) | (unsigned)v; bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)((acc >> bits) & 0xff)); }
+    }
+    return true;
+}
+
+// ---- sutil::Matrix4x4 / Quaternion arithmetic, restated (row-major, fp32, sums started at 0 and added left to right) --------
+struct M4 { float m[16]; };
+M4 m4_identity() { M4 r; for (int i = 0; i < 16; i++) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f; return r; }
+M4 m4_mul(const M4& a, const M4& b) {  // sutil/Matrix.h:339-355
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float sum = 0.0f;
+            for (int k = 0; k < 4; k++) sum += a.m[i * 4 + k] * b.m[k * 4 + j];
+            r.m[i * 4 + j] = sum;
+        }
+    return r;
+}
+void m4_apply(const M4& a, const float v[4], float out[4]) {  // sutil/Matrix.h:425-446
+    for (int i = 0; i < 4; i++) {
+        float sum = 0.0f;
+        for (int j = 0; j < 4; j++) sum += a.m[i * 4 + j] * v[j];
+        out[i] = sum;
+    }
+}
+M4 m4_from_quat(float qx, float qy, float qz, float qw) {  // sutil/Quaternion.h:239-269
+    M4 r = m4_identity();
+    float* m = r.m;
+    m[0] = 1.0f - 2.0f * qy * qy - 2.0f * qz * qz; m[1] = 2.0f * qx * qy - 2.0f * qz * qw; m[2] = 2.0f * qx * qz + 2.0f * qy * qw;
+    m[4] = 2.0f * qx * qy + 2.0f * qz * qw; m[5] = 1.0f - 2.0f * qx * qx - 2.0f * qz * qz; m[6] = 2.0f * qy * qz - 2.0f * qx * qw;
+    m[8] = 2.0f * qx * qz - 2.0f * qy * qw; m[9] = 2.0f * qy * qz + 2.0f * qx * qw; m[10] = 1.0f - 2.0f * qx * qx - 2.0f * qy * qy;
+    return r;
+}
+
+struct Gltf {
+    J root;
+    std::string dir;
+    std::vector<std::vector<uint8_t>> buffers;
+    std::vector<uint8_t> glb_bin;
+    spcbpt_scene_file* out = nullptr;
+    std::string err;
+    bool camera_done = false;
+    std::vector<int> image_tex;  // glTF image -> 1-based texture id of the handle, 0 = unusable
+
+    const J* arr(const char* k) const { const J* v = root.get(k); return v && v->t == J::Arr ? v : nullptr; }
+    const J* at(const char* k, int i) const { const J* v = arr(k); return v && i >= 0 && (size_t)i < v->a.size() ? &v->a[(size_t)i] : nullptr; }
+    bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+
+    bool load_buffers() {
+        const J* bs = arr("buffers");
+        if (!bs) return true;
+        for (size_t i = 0; i < bs->a.size(); i++) {
+            const J& b = bs->a[i];
+            std::vector<uint8_t> data;
+            const std::string uri = b.str("uri");
+            if (uri.empty()) {
+                if (i == 0 && !glb_bin.empty()) data = glb_bin;
+                else return fail("buffer without uri");
+            } else if (uri.compare(0, 5, "data:") == 0) {
+                const size_t c = uri.find(";base64,");
+                if (c == std::string::npos) return fail("data: uri is not base64");
+                base64(uri, c + 8, data);
+            } else if (!read_file(dir + uri, data)) return fail("cannot read buffer " + uri);
+            const size_t want = (size_t)b.num("byteLength", 0);
+            if (data.size() < want) return fail("buffer " + uri + " is shorter than its byteLength");
+            buffers.push_back(std::move(data));
+        }
+        return true;
+    }
+
+    struct View { const uint8_t* base = nullptr; size_t stride = 0, count = 0; int comp = 0, ncomp = 0; bool normalized = false; };
+    bool accessor(int idx, View& v) {
+        const J* a = at("accessors", idx);
+        if (!a) return fail("bad accessor index");
+        if (a->get("sparse")) return fail("sparse accessors are not supported");
+        const J* bv = at("bufferViews", a->integer("bufferView", -1));
+        if (!bv) return fail("accessor without bufferView");
+        const int b = bv->integer("buffer", -1);
+        if (b < 0 || (size_t)b >= buffers.size()) return fail("bad buffer index");
+        v.comp = a->integer("componentType", 0);
+        const std::string type = a->str("type");
+        v.ncomp = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : type == "MAT4" ? 16 : 0;
+        const size_t csize = v.comp == 5126 || v.comp == 5125 ? 4 : v.comp == 5123 || v.comp == 5122 ? 2 : v.comp == 5121 || v.comp == 5120 ? 1 : 0;
+        if (!csize || !v.ncomp) return fail("accessor type not supported");
+        v.count = (size_t)a->num("count", 0);
+        v.normalized = a->get("normalized") && a->get("normalized")->b;
+        const size_t elem = csize * (size_t)v.ncomp;
+        v.stride = (size_t)bv->num("byteStride", 0);
+        if (v.stride == 0) v.stride = elem;  // Scene.cpp:104-117
+        const size_t off = (size_t)bv->num("byteOffset", 0) + (size_t)a->num("byteOffset", 0);
+        if (v.count && off + (v.count - 1) * v.stride + elem > buffers[(size_t)b].size()) return fail("accessor reaches past its buffer");
+        v.base = buffers[(size_t)b].data() + off;
+        return true;
+    }
+
+    int texture_of_image(int img) {
+        if (img < 0 || (size_t)img >= image_tex.size()) return 0;
+        if (image_tex[(size_t)img] >= 0) return image_tex[(size_t)img];
+        image_tex[(size_t)img] = 0;
+        const J* im = at("images", img);
+        std::vector<uint8_t> rgba;
+        int w = 0, h = 0;
+        bool ok = false;
+        const std::string uri = im ? im->str("uri") : std::string();
+        if (!uri.empty() && uri.compare(0, 5, "data:") != 0) {
+            ok = spc_loader::load_ppm(dir + uri, rgba, w, h);
+            if (!ok) out->warnings += "image " + uri + " is not a readable binary PPM (PNG/JPEG are not decoded); ";
+        } else {
+            out->warnings += "embedded images are not decoded; ";
+        }
+        if (!ok) return 0;
+        out->tex_pixels.push_back(std::move(rgba));
+        spcbpt_texture t; t.rgba = nullptr; t.width = w; t.height = h;
+        out->textures.push_back(t);
+        image_tex[(size_t)img] = (int)out->textures.size();
+        return image_tex[(size_t)img];
+    }
+
+    bool materials() {
+        const J* ms = arr("materials");
+        const size_t n = ms ? ms->a.size() : 0;
+        const J* imgs = arr("images");
+        image_tex.assign(imgs ? imgs->a.size() : 0, -1);
+        for (size_t i = 0; i <= n; i++) {  // one extra: the default material for primitives without one
+            spcbpt_material m;
+            memset(&m, 0, sizeof(m));
+            m.base_color[0] = m.base_color[1] = m.base_color[2] = 1.0f;
+            m.metallic = 1.0f; m.roughness = 1.0f;   // glTF defaults
+            m.specular = 0.5f; m.sheen_tint = 0.5f; m.clearcoat_gloss = 1.0f;  // MaterialData() values of the .scene route (q17)
+            if (i < n) {
+                const J* pbr = ms->a[i].get("pbrMetallicRoughness");
+                if (pbr) {
+                    const J* c = pbr->get("baseColorFactor");
+                    if (c && c->size() >= 3) for (int k = 0; k < 3; k++) m.base_color[k] = (float)c->a[(size_t)k].n;
+                    m.metallic = (float)pbr->num("metallicFactor", 1.0);
+                    m.roughness = (float)pbr->num("roughnessFactor", 1.0);
+                    const J* bt = pbr->get("baseColorTexture");
+                    if (bt) {
+                        const J* tx = at("textures", bt->integer("index", -1));
+                        if (tx) m.albedo_tex = texture_of_image(tx->integer("source", -1));
+                    }
+                }
+            } else {
+                m.metallic = 0.0f; m.roughness = 0.5f;
+            }
+            out->materials.push_back(m);
+        }
+        return true;
+    }
+
+    bool mesh_instance(int mesh, const M4& xf) {
+        const J* me = at("meshes", mesh);
+        if (!me) return fail("bad mesh index");
+        const J* prims = me->get("primitives");
+        if (!prims || prims->t != J::Arr) return true;
+        const int default_mat = (int)out->materials.size() - 1;
+        for (const J& pr : prims->a) {
+            if (pr.integer("mode", 4) != 4) { out->warnings += "non-triangle primitive skipped; "; continue; }  // Scene.cpp:453-457
+            const J* attrs = pr.get("attributes");
+            const int pa = attrs ? attrs->integer("POSITION", -1) : -1;
+            if (pa < 0) return fail("primitive without POSITION");
+            View pos, uv, idx;
+            if (!accessor(pa, pos)) return false;
+            if (pos.comp != 5126 || pos.ncomp != 3) return fail("POSITION must be float VEC3");
+            const int ta = attrs->integer("TEXCOORD_0", -1);
+            const bool has_uv = ta >= 0;
+            if (has_uv) {
+                if (!accessor(ta, uv)) return false;
+                if (uv.ncomp != 2 || uv.count < pos.count) return fail("TEXCOORD_0 must be VEC2 with one entry per vertex");
+                if (uv.comp != 5126 && !(uv.normalized && (uv.comp == 5121 || uv.comp == 5123))) return fail("TEXCOORD_0 must be float or normalized u8/u16");
+            }
+            const uint32_t base = (uint32_t)(out->V.size() / 3);
+            for (size_t i = 0; i < pos.count; i++) {
+                float p[4], w[4];
+                memcpy(p, pos.base + i * pos.stride, 12);
+                p[3] = 1.0f;
+                m4_apply(xf, p, w);
+                out->V.push_back(w[0]); out->V.push_back(w[1]); out->V.push_back(w[2]);
+                float t[2] = {0.0f, 0.0f};
+                if (has_uv) {
+                    const uint8_t* q = uv.base + i * uv.stride;
+                    if (uv.comp == 5126) memcpy(t, q, 8);
+                    else if (uv.comp == 5121) { t[0] = q[0] / 255.0f; t[1] = q[1] / 255.0f; }
+                    else { uint16_t h2[2]; memcpy(h2, q, 4); t[0] = h2[0] / 65535.0f; t[1] = h2[1] / 65535.0f; }
+                }
+                out->UV.push_back(t[0]); out->UV.push_back(t[1]);
+            }
+            int mat = pr.integer("material", -1);
+            if (mat < 0 || mat >= default_mat) mat = default_mat;
+            const int ia = pr.integer("indices", -1);
+            size_t n_idx = pos.count;
+            if (ia >= 0) {
+                if (!accessor(ia, idx)) return false;
+                if (idx.ncomp != 1 || (idx.comp != 5121 && idx.comp != 5123 && idx.comp != 5125)) return fail("indices must be unsigned SCALARs");
+                n_idx = idx.count;
+            }
+            for (size_t i = 0; i + 3 <= n_idx; i += 3) {
+                uint32_t tri[3];
+                for (int k = 0; k < 3; k++) {
+                    uint32_t v = (uint32_t)(i + (size_t)k);
+                    if (ia >= 0) {
+                        const uint8_t* q = idx.base + (i + (size_t)k) * idx.stride;
+                        if (idx.comp == 5125) memcpy(&v, q, 4);
+                        else if (idx.comp == 5123) { uint16_t h2; memcpy(&h2, q, 2); v = h2; }
+                        else v = *q;
+                    }
+                    if (v >= pos.count) return fail("index out of range");
+                    tri[k] = base + v;
+                }
+                out->I.push_back(tri[0]); out->I.push_back(tri[1]); out->I.push_back(tri[2]);
+                out->M.push_back(mat);
+            }
+        }
+        return true;
+    }
+
+    bool node(int id, const M4& parent, int depth) {
+        const J* nd = at("nodes", id);
+        if (!nd) return fail("bad node index");
+        if (depth > 256) return fail("node hierarchy too deep (cycle?)");
+        auto vec = [&](const char* k, size_t n, std::vector<float>& v) {
+            const J* a = nd->get(k);
+            if (!a || a->t != J::Arr || a->a.size() < n) return false;
+            v.resize(n);
+            for (size_t i = 0; i < n; i++) v[i] = (float)a->a[i].n;
+            return true;
+        };
+        std::vector<float> t, r, s, mt;
+        M4 T = m4_identity(), R = m4_identity(), S = m4_identity(), Mx = m4_identity();
+        if (vec("matrix", 16, mt)) {  // column-major -> transpose; the reference's tinygltf drops T/R/S of a node that has a matrix
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Mx.m[i * 4 + j] = mt[(size_t)(j * 4 + i)];
+        } else {
+            if (vec("translation", 3, t)) { T.m[3] = t[0]; T.m[7] = t[1]; T.m[11] = t[2]; }
+            if (vec("rotation", 4, r)) R = m4_from_quat(r[0], r[1], r[2], r[3]);
+            if (vec("scale", 3, s)) { S.m[0] = s[0]; S.m[5] = s[1]; S.m[10] = s[2]; }
+        }
+        const M4 xf = m4_mul(m4_mul(m4_mul(m4_mul(parent, Mx), T), R), S);  // Scene.cpp:156
+        const int cam = nd->integer("camera", -1), mesh = nd->integer("mesh", -1);
+        if (cam >= 0) {
+            const J* c = at("cameras", cam);
+            if (!c || c->str("type") != "perspective") return true;  // Scene.cpp:163-167: skipped, children too
+            if (!camera_done) {
+                const float o[4] = {0, 0, 0, 1}, u[4] = {0, 1, 0, 0};
+                float e[4], up[4];
+                m4_apply(xf, o, e); m4_apply(xf, u, up);
+                for (int k = 0; k < 3; k++) { out->eye[k] = e[k]; out->up[k] = up[k]; out->lookat[k] = 0.0f; }
+                const J* pp = c->get("perspective");
+                out->fov = (float)(pp ? pp->num("yfov", 0.6) : 0.6) * 180.0f / (float)M_PI;
+                const J* ex = nd->get("extras");
+                const J* la = ex ? ex->get("spcbpt_lookat") : nullptr;
+                if (la && la->size() >= 3) for (int k = 0; k < 3; k++) out->lookat[k] = (float)la->a[(size_t)k].n;
+                camera_done = true;
+            }
+        } else if (mesh >= 0) {
+            if (!mesh_instance(mesh, xf)) return false;
+        }
+        const J* ch = nd->get("children");
+        if (ch && ch->t == J::Arr)
+            for (const J& c : ch->a) if (!node((int)c.n, xf, depth + 1)) return false;
+        return true;
+    }
+
+    bool lights() {
+        const J* ex = root.get("extras");
+        const J* ls = ex ? ex->get("spcbpt_quad_lights") : nullptr;
+        if (!ls || ls->t != J::Arr) return true;
+        for (const J& l : ls->a) {
+            spcbpt_quad_light q;
+            memset(&q, 0, sizeof(q));
+            auto v3 = [&](const char* k, float* d) {
+                const J* a = l.get(k);
+                if (!a || a->size() < 3) return false;
+                for (int i = 0; i < 3; i++) d[i] = (float)a->a[(size_t)i].n;
+                return true;
+            };
+            if (!v3("position", q.position) || !v3("u", q.u) || !v3("v", q.v) || !v3("emission", q.emission)) return fail("spcbpt_quad_lights entry needs position, u, v, emission");
+            q.div_level = l.integer("divLevel", 1);
+            out->lights.push_back(q);
+        }
+        return true;
+    }
+
+    bool run() {
+        if (!load_buffers() || !materials()) return false;
+        const J* nodes = arr("nodes");
+        const size_t n = nodes ? nodes->a.size() : 0;
+        std::vector<char> is_root(n, 1);
+        for (size_t i = 0; i < n; i++) {
+            const J* ch = nodes->a[i].get("children");
+            if (ch && ch->t == J::Arr)
+                for (const J& c : ch->a) if (c.t == J::Num && c.n >= 0 && (size_t)c.n < n) is_root[(size_t)c.n] = 0;
+        }
+        for (size_t i = 0; i < n; i++)
+            if (is_root[i] && !node((int)i, m4_identity(), 0)) return false;
+        return lights();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int spcbpt_gltf_load(const char* path, spcbpt_scene_file** out, char* error, int error_capacity) {
+    if (!path || !out) return SPCBPT_ERR_INVALID_ARG;
+    *out = nullptr;
+    auto report = [&](const std::string& m) {
+        if (error && error_capacity > 0) { strncpy(error, m.c_str(), (size_t)error_capacity - 1); error[error_capacity - 1] = 0; }
+        return SPCBPT_ERR_INVALID_ARG;
+    };
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return report(std::string("cannot read ") + path);
+    Gltf g;
+    const std::string p(path);
+    const size_t slash = p.find_last_of('/');
+    g.dir = slash == std::string::npos ? std::string() : p.substr(0, slash + 1);
+    const char* json = reinterpret_cast<const char*>(file.data());
+    size_t json_len = file.size();
+    if (file.size() >= 20 && !memcmp(file.data(), "glTF", 4)) {  // binary container: 12-byte header, then JSON and BIN chunks
+        uint32_t total, clen, ctype;
+        memcpy(&total, file.data() + 8, 4);
+        memcpy(&clen, file.data() + 12, 4); memcpy(&ctype, file.data() + 16, 4);
+        if (ctype != 0x4E4F534Au || 20 + (size_t)clen > file.size()) return report("malformed .glb (JSON chunk)");
+        json = reinterpret_cast<const char*>(file.data() + 20); json_len = clen;
+        const size_t next = 20 + (size_t)clen;
+        if (next + 8 <= file.size()) {
+            uint32_t blen, btype;
+            memcpy(&blen, file.data() + next, 4); memcpy(&btype, file.data() + next + 4, 4);
+            if (btype == 0x004E4942u && next + 8 + (size_t)blen <= file.size()) g.glb_bin.assign(file.data() + next + 8, file.data() + next + 8 + blen);
+        }
+    }
+    JParser jp{json, json + json_len, std::string()};
+    if (!jp.value(g.root) || g.root.t != J::Obj) return report("JSON: " + (jp.err.empty() ? std::string("not an object") : jp.err));
+    spcbpt_scene_file* s = new spcbpt_scene_file();
+    g.out = s;
+    if (!g.run()) {
+        const std::string m = g.err;
+        delete s;
+        return report("glTF: " + m);
+    }
+    for (size_t i = 0; i < s->textures.size(); i++) s->textures[i].rgba = s->tex_pixels[i].data();
+    *out = s;
+    return SPCBPT_OK;
+}
+
+}  // extern "C"

@@ -4,10 +4,11 @@
 //                runs to the first line containing '}'
 //   hand-off     OptiXPathTracer/scene_shift.cpp:32-328: only color / metallic / roughness / albedo texture reach the renderer
 //                (q17), the k-th mesh block uses the k-th pushed material, OBJ normals are discarded, missing UVs are zero
-// OBJ reading follows what the old tinyobj API gives scene_shift.cpp (triangulated fans, one vertex per distinct v/vt pair).
-// Textures: binary PPM (P6) only — the reference decodes JPEG/PNG through stb_image, which is not part of this build; other
-// formats are reported in the warnings string and the material renders with its flat colour.
-// PARITY UNPINNED: the reference's loader cannot be compiled here (sutil.h needs the CMake-generated sampleConfig.h).
+// OBJ reading has the semantics of the reference's vendored old-API tinyobj and PPM decoding those of its stb_image; both are
+// pinned bit-exactly against those loaders (oracle/_ref, tests/golden/ref_loaders.npz, tests/test_scene_file.py).
+// Textures: binary PPM (P6) only — the reference decodes JPEG/PNG through stb_image, which is not rebuilt here; other formats
+// are reported in the warnings string and the material renders with its flat colour.
+// The `.scene` grammar itself is PARITY UNPINNED: sceneLoader.cpp needs the CMake-generated sampleConfig.h (via sutil.h).
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -16,37 +17,9 @@
 #include <vector>
 
 #include "../../include/spcbpt.h"
+#include "scene_file.h"
 
-struct spcbpt_scene_file {
-    std::vector<float> V, UV;
-    std::vector<uint32_t> I;
-    std::vector<int32_t> M;
-    std::vector<spcbpt_material> materials;
-    std::vector<spcbpt_quad_light> lights;
-    std::vector<std::vector<uint8_t>> tex_pixels;
-    std::vector<spcbpt_texture> textures;
-    float eye[3] = {0, 0, 0}, lookat[3] = {0, 0, -1}, up[3] = {0, 1, 0};
-    float fov = 35.0f;
-    int width = 1920, height = 1001;  // sceneLoader.cpp:201-203 defaults (parsed, ignored by the app)
-    int n_mesh_blocks = 0;
-    std::string warnings;
-};
-
-namespace {
-
-const int kMaxLine = 2048;
-
-struct MatParam {  // MaterialParameter defaults (material_parameters.h:16-32)
-    float color[3] = {1, 1, 1};
-    float metallic = 0.0f, roughness = 0.5f;
-    std::string tex = "None";
-};
-
-std::string fix_slashes(std::string p) {
-    for (auto& ch : p) if (ch == '\\') ch = '/';
-    return p;
-}
-
+namespace spc_loader {
 bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -73,6 +46,23 @@ bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& 
     }
     fclose(f);
     return ok;
+}
+}  // namespace spc_loader
+
+namespace {
+using spc_loader::load_ppm;
+
+const int kMaxLine = 2048;
+
+struct MatParam {  // MaterialParameter defaults (material_parameters.h:16-32)
+    float color[3] = {1, 1, 1};
+    float metallic = 0.0f, roughness = 0.5f;
+    std::string tex = "None";
+};
+
+std::string fix_slashes(std::string p) {
+    for (auto& ch : p) if (ch == '\\') ch = '/';
+    return p;
 }
 
 // OBJ reader with the semantics of the reference's vendored (old-API) tinyobj as scene_shift.cpp:187-250 consumes it; pinned

@@ -1,0 +1,28 @@
+// Private to csrc/: the loaded-scene handle behind spcbpt_scene_file_* (scene_file.cpp: `.scene` + OBJ; gltf_file.cpp: glTF 2.0).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/spcbpt.h"
+
+struct spcbpt_scene_file {
+    std::vector<float> V, UV;
+    std::vector<uint32_t> I;
+    std::vector<int32_t> M;
+    std::vector<spcbpt_material> materials;
+    std::vector<spcbpt_quad_light> lights;
+    std::vector<std::vector<uint8_t>> tex_pixels;
+    std::vector<spcbpt_texture> textures;
+    float eye[3] = {0, 0, 0}, lookat[3] = {0, 0, -1}, up[3] = {0, 1, 0};
+    float fov = 35.0f;
+    int width = 1920, height = 1001;  // sceneLoader.cpp:201-203 defaults (parsed, ignored by the app)
+    int n_mesh_blocks = 0;
+    std::string warnings;
+};
+
+
+namespace spc_loader {
+// binary PPM (P6, maxval 255) -> RGBA8, pinned against the reference's stb_image (tests/test_scene_file.py)
+bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h);
+}

@@ -289,3 +289,89 @@ def write_scene(scene: Scene, data_root: str, rel_dir: str) -> str:
     with open(path, "w") as f:
         f.write("\n".join(lines))
     return path
+
+
+def write_gltf(scene: Scene, out_dir: str, name: str = "scene", binary: bool = False) -> str:
+    """Writes `scene` as glTF 2.0 (`name`.gltf + `name`.bin + binary-PPM textures, or one `name`.glb when `binary`): one mesh
+    with one TRIANGLES primitive per material (float POSITION / TEXCOORD_0, u32 indices), pbrMetallicRoughness factors, a
+    perspective camera node, and this build's extensions `extras.spcbpt_quad_lights` (root) / `extras.spcbpt_lookat` (camera
+    node) that csrc/gltf_file.cpp reads back.  Returns the path of the .gltf / .glb file."""
+    import json
+    import os
+    import struct
+    os.makedirs(out_dir, exist_ok=True)
+    V = np.ascontiguousarray(scene.vertices, dtype=np.float32)
+    UV = np.zeros((V.shape[0], 2), np.float32) if scene.texcoords is None else np.ascontiguousarray(scene.texcoords, dtype=np.float32)
+    I = np.ascontiguousarray(scene.indices, dtype=np.uint32)
+    M = np.asarray(scene.tri_material)
+    blob = bytearray()
+    views, accessors, prims = [], [], []
+
+    def add(data: bytes, target=None):
+        while len(blob) % 4: blob.append(0)
+        v = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(data)}
+        if target: v["target"] = target
+        blob.extend(data)
+        views.append(v)
+        return len(views) - 1
+
+    for k in range(len(scene.materials)):
+        tri = I[M == k]
+        if tri.shape[0] == 0: continue
+        used, inv = np.unique(tri.reshape(-1), return_inverse=True)
+        p, t, idx = V[used], UV[used], inv.astype(np.uint32)
+        vp = add(p.tobytes(), 34962); vt = add(t.tobytes(), 34962); vi = add(idx.tobytes(), 34963)
+        accessors += [
+            {"bufferView": vp, "componentType": 5126, "count": int(p.shape[0]), "type": "VEC3",
+             "min": [float(x) for x in p.min(0)], "max": [float(x) for x in p.max(0)]},
+            {"bufferView": vt, "componentType": 5126, "count": int(t.shape[0]), "type": "VEC2"},
+            {"bufferView": vi, "componentType": 5125, "count": int(idx.shape[0]), "type": "SCALAR"}]
+        a0 = len(accessors) - 3
+        prims.append({"attributes": {"POSITION": a0, "TEXCOORD_0": a0 + 1}, "indices": a0 + 2, "material": k, "mode": 4})
+    mats, textures, images = [], [], []
+    for k, m in enumerate(scene.materials):
+        pbr = {"baseColorFactor": [float(x) for x in m.get("color", (1, 1, 1))] + [1.0],
+               "metallicFactor": float(m.get("metallic", 0.0)), "roughnessFactor": float(m.get("roughness", 0.5))}
+        if m.get("albedo_tex", 0) > 0:
+            t = m["albedo_tex"] - 1
+            img = np.ascontiguousarray(scene.textures[t], dtype=np.uint8)
+            fn = f"{name}_tex{t}.ppm"
+            with open(os.path.join(out_dir, fn), "wb") as f:
+                f.write(b"P6\n%d %d\n255\n" % (img.shape[1], img.shape[0]) + img[..., :3].tobytes())
+            images.append({"uri": fn, "mimeType": "image/x-portable-pixmap"})
+            textures.append({"source": len(images) - 1})
+            pbr["baseColorTexture"] = {"index": len(textures) - 1}
+        mats.append({"name": f"mat{k}", "pbrMetallicRoughness": pbr, "doubleSided": True})
+    cam = scene.camera or dict(eye=(0, 0, 5), lookat=(0, 0, 0), up=(0, 1, 0), fov=35.0)
+    # the camera node only carries position and up (what the reference's loader reads): a translation, no rotation
+    nodes = [{"mesh": 0, "name": "geometry"},
+             {"camera": 0, "name": "camera", "translation": [float(x) for x in cam["eye"]],
+              "extras": {"spcbpt_lookat": [float(x) for x in cam["lookat"]]}}]
+    doc = {"asset": {"version": "2.0", "generator": "spcbpt-optix7_amd/scenes.py"},
+           "scene": 0, "scenes": [{"nodes": [0, 1]}], "nodes": nodes,
+           "meshes": [{"name": scene.name, "primitives": prims}],
+           "cameras": [{"type": "perspective", "perspective": {"yfov": float(np.deg2rad(cam.get("fov", 35.0))), "znear": 0.01,
+                                                                 "aspectRatio": 16.0 / 9.0}}],
+           "materials": mats, "accessors": accessors, "bufferViews": views,
+           "extras": {"spcbpt_quad_lights": [dict(position=[float(x) for x in l["position"]], u=[float(x) for x in l["u"]],
+                                                  v=[float(x) for x in l["v"]], emission=[float(x) for x in l["emission"]],
+                                                  divLevel=int(l.get("div_level", 1))) for l in scene.lights]}}
+    if textures: doc["textures"] = textures; doc["images"] = images
+    if binary:
+        doc["buffers"] = [{"byteLength": len(blob)}]
+        js = json.dumps(doc, separators=(",", ":")).encode()
+        js += b" " * (-len(js) % 4)
+        while len(blob) % 4: blob.append(0)
+        path = os.path.join(out_dir, name + ".glb")
+        with open(path, "wb") as f:
+            f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(blob)))
+            f.write(struct.pack("<II", len(js), 0x4E4F534A)); f.write(js)
+            f.write(struct.pack("<II", len(blob), 0x004E4942)); f.write(bytes(blob))
+        return path
+    doc["buffers"] = [{"uri": name + ".bin", "byteLength": len(blob)}]
+    with open(os.path.join(out_dir, name + ".bin"), "wb") as f:
+        f.write(bytes(blob))
+    path = os.path.join(out_dir, name + ".gltf")
+    with open(path, "w") as f:
+        json.dump(doc, f)
+    return path

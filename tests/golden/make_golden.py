@@ -109,6 +109,122 @@ def ref_loaders():
     np.savez_compressed(os.path.join(HERE, "ref_loaders.npz"), **out)
 
 
+def gltf_cases():
+    """Authored glTF files (data, not reference text): name -> {filename: bytes}, main file first."""
+    import base64, json, struct
+    rng = np.random.default_rng(5)
+    cases = {}
+
+    def quad_mesh(n=4):
+        p = rng.normal(size=(n, 3)).astype(np.float32)
+        t = rng.random(size=(n, 2)).astype(np.float32)
+        return p, t
+
+    def doc_base():
+        return {"asset": {"version": "2.0"}}
+
+    # 1. nested TRS + matrix child, u16 indices
+    p, t = quad_mesh(5)
+    idx = np.array([0, 1, 2, 2, 3, 4, 0, 2, 4], np.uint16)
+    blob = p.tobytes() + t.tobytes() + idx.tobytes() + b"\0\0"
+    d = doc_base()
+    d.update(buffers=[{"uri": "a.bin", "byteLength": len(blob)}],
+             bufferViews=[{"buffer": 0, "byteOffset": 0, "byteLength": 60}, {"buffer": 0, "byteOffset": 60, "byteLength": 40},
+                          {"buffer": 0, "byteOffset": 100, "byteLength": 18}],
+             accessors=[{"bufferView": 0, "componentType": 5126, "count": 5, "type": "VEC3"},
+                        {"bufferView": 1, "componentType": 5126, "count": 5, "type": "VEC2"},
+                        {"bufferView": 2, "componentType": 5123, "count": 9, "type": "SCALAR"}],
+             materials=[{"pbrMetallicRoughness": {"baseColorFactor": [0.8, 0.4, 0.2, 1.0], "metallicFactor": 0.25, "roughnessFactor": 0.6}}],
+             meshes=[{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2, "material": 0}]}],
+             nodes=[{"translation": [1.5, -2.25, 0.125], "rotation": [0.18257419, 0.36514837, 0.54772256, 0.73029674], "scale": [2.0, 0.5, 1.25], "children": [1]},
+                    {"mesh": 0, "matrix": [0.0, 1.0, 0.0, 0.0, -1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 3.0, 4.0, 5.0, 1.0]}],
+             scenes=[{"nodes": [0]}], scene=0)
+    cases["trs_nested"] = {"m.gltf": json.dumps(d).encode(), "a.bin": blob}
+
+    # 2. interleaved view with byteStride + accessor byteOffset, u32 indices, node with BOTH matrix and TRS
+    p, t = quad_mesh(6)
+    inter = np.zeros((6, 5), np.float32); inter[:, :3] = p; inter[:, 3:] = t
+    idx = np.array([5, 4, 3, 2, 1, 0], np.uint32)
+    blob = b"\x11" * 8 + inter.tobytes() + idx.tobytes()
+    d = doc_base()
+    d.update(buffers=[{"uri": "b.bin", "byteLength": len(blob)}],
+             bufferViews=[{"buffer": 0, "byteOffset": 8, "byteLength": 120, "byteStride": 20}, {"buffer": 0, "byteOffset": 128, "byteLength": 24}],
+             accessors=[{"bufferView": 0, "byteOffset": 0, "componentType": 5126, "count": 6, "type": "VEC3"},
+                        {"bufferView": 0, "byteOffset": 12, "componentType": 5126, "count": 6, "type": "VEC2"},
+                        {"bufferView": 1, "componentType": 5125, "count": 6, "type": "SCALAR"}],
+             meshes=[{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2}]}],
+             nodes=[{"mesh": 0, "matrix": [2.0, 0, 0, 0, 0, 2.0, 0, 0, 0, 0, 2.0, 0, 0.5, 0.25, -1.0, 1.0], "translation": [0.1, 0.2, 0.3],
+                     "rotation": [0.0, 0.70710678, 0.0, 0.70710678], "scale": [1.0, 3.0, 1.0]}])
+    cases["interleaved_matrix_and_trs"] = {"m.gltf": json.dumps(d).encode(), "b.bin": blob}
+
+    # 3. two primitives / materials (one without UVs, one material without factors), a LINES primitive that is skipped,
+    #    the same mesh instanced twice, a node outside scenes[0], base64 buffer
+    p1, t1 = quad_mesh(3); p2, _ = quad_mesh(4)
+    i1 = np.array([0, 1, 2], np.uint16); i2 = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    blob = p1.tobytes() + t1.tobytes() + p2.tobytes() + i1.tobytes() + b"\0\0" + i2.tobytes()
+    off = [0, 36, 60, 108, 116]
+    d = doc_base()
+    d.update(buffers=[{"uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode(), "byteLength": len(blob)}],
+             bufferViews=[{"buffer": 0, "byteOffset": off[0], "byteLength": 36}, {"buffer": 0, "byteOffset": off[1], "byteLength": 24},
+                          {"buffer": 0, "byteOffset": off[2], "byteLength": 48}, {"buffer": 0, "byteOffset": off[3], "byteLength": 6},
+                          {"buffer": 0, "byteOffset": off[4], "byteLength": 12}],
+             accessors=[{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"},
+                        {"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC3"}, {"bufferView": 3, "componentType": 5123, "count": 3, "type": "SCALAR"},
+                        {"bufferView": 4, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+             materials=[{"pbrMetallicRoughness": {"baseColorFactor": [0.1, 0.2, 0.3, 1.0]}}, {"name": "plain"},
+                        {"pbrMetallicRoughness": {"metallicFactor": 0.0, "roughnessFactor": 0.05}}],
+             meshes=[{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 3, "material": 2},
+                                     {"attributes": {"POSITION": 2}, "indices": 4, "material": 0},
+                                     {"attributes": {"POSITION": 2}, "indices": 4, "material": 1, "mode": 1}]}],
+             nodes=[{"mesh": 0}, {"mesh": 0, "translation": [10.0, 0.0, 0.0]}, {"mesh": 0, "scale": [-1.0, 1.0, 1.0], "rotation": [0.5, 0.5, 0.5, 0.5]}],
+             scenes=[{"nodes": [0, 1]}], scene=0)
+    cases["multi_prim_instances_base64"] = {"m.gltf": json.dumps(d).encode()}
+
+    # 4. camera under a transformed parent + mesh; as .glb
+    p, t = quad_mesh(3)
+    idx = np.array([0, 1, 2], np.uint32)
+    blob = p.tobytes() + t.tobytes() + idx.tobytes()
+    d = doc_base()
+    d.update(buffers=[{"byteLength": len(blob)}],
+             bufferViews=[{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 24}, {"buffer": 0, "byteOffset": 60, "byteLength": 12}],
+             accessors=[{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"},
+                        {"bufferView": 2, "componentType": 5125, "count": 3, "type": "SCALAR"}],
+             cameras=[{"type": "orthographic", "orthographic": {"xmag": 1, "ymag": 1, "zfar": 10, "znear": 0.1}},
+                      {"type": "perspective", "perspective": {"yfov": 0.6108652381980153, "aspectRatio": 1.7777, "znear": 0.01}}],
+             meshes=[{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2}]}],
+             nodes=[{"children": [1, 2, 3], "translation": [0.0, 1.0, 0.0], "rotation": [0.0, 0.38268343, 0.0, 0.92387953]},
+                    {"camera": 0}, {"camera": 1, "translation": [1.0, 2.0, 3.0], "rotation": [0.25881905, 0.0, 0.0, 0.96592583]}, {"mesh": 0}])
+    js = json.dumps(d, separators=(",", ":")).encode(); js += b" " * (-len(js) % 4)
+    glb = struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(blob)) + struct.pack("<II", len(js), 0x4E4F534A) + js + struct.pack("<II", len(blob), 0x004E4942) + blob
+    cases["camera_glb"] = {"m.glb": glb}
+    return cases
+
+
+def ref_gltf():
+    """Row f2 pins: the reference's vendored tinygltf + sutil Matrix4x4/Quaternion walking the model as sutil::loadScene does."""
+    import tempfile
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_gltf.so"))
+    out = {}
+    for name, files in gltf_cases().items():
+        with tempfile.TemporaryDirectory() as d:
+            for fn, data in files.items():
+                open(os.path.join(d, fn), "wb").write(data)
+            main = os.path.join(d, next(iter(files)))
+            nv, nt, nm = C.c_int(), C.c_int(), C.c_int()
+            rc = lib.ref_gltf_load(main.encode(), C.byref(nv), C.byref(nt), C.byref(nm), None, None, None, None, None, None)
+            assert rc == 0, name
+            pos = np.zeros((nv.value, 3), np.float32); uv = np.zeros((nv.value, 2), np.float32)
+            idx = np.zeros((nt.value, 3), np.uint32); tm = np.zeros(nt.value, np.int32)
+            mats = np.zeros((max(nm.value, 1), 6), np.float32); cam = np.zeros(9, np.float32)
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            lib.ref_gltf_load(main.encode(), C.byref(nv), C.byref(nt), C.byref(nm), vp(pos), vp(uv), vp(idx), vp(tm), vp(mats), vp(cam))
+            for fn, data in files.items():
+                out[f"{name}__file__{fn}"] = np.frombuffer(data, dtype=np.uint8)
+            out[name + "__pos"] = pos; out[name + "__uv"] = uv; out[name + "__idx"] = idx; out[name + "__tri_mat"] = tm
+            out[name + "__materials"] = mats[: nm.value]; out[name + "__camera"] = cam
+    np.savez_compressed(os.path.join(HERE, "ref_gltf.npz"), **out)
+
+
 def survey_kat():
     np.savez(os.path.join(HERE, "survey_kat.npz"),
              tea4_7_3=np.uint32(2175312897),
@@ -149,6 +265,7 @@ def oracle_regression():
 if __name__ == "__main__":
     ref_vectors()
     ref_loaders()
+    ref_gltf()
     survey_kat()
     oracle_regression()
     print("golden vectors written to", HERE)

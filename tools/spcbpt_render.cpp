@@ -20,7 +20,7 @@ static void die(spcbpt_ctx* c, const char* what, int rc) {
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s <file.scene> <data_root> [--alg pt|SPCBPT_eye] [--dim=WxH] [--frames N] [--train-paths N] [--minimal] [--out prefix]\n", argv[0]);
+        fprintf(stderr, "usage: %s <file.scene | file.gltf | file.glb> <data_root (ignored for glTF)> [--alg pt|SPCBPT_eye] [--dim=WxH] [--frames N] [--train-paths N] [--minimal] [--out prefix]\n", argv[0]);
         return 0;
     }
     std::string alg = "SPCBPT_eye", out = "render";
@@ -37,7 +37,13 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "Unknown option '%s'\n", argv[i]); return 1; }
     }
     spcbpt_scene_file* sf = nullptr;
-    if (spcbpt_scene_file_load(argv[1], argv[2], &sf)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
+    const std::string in(argv[1]);
+    const bool gltf = in.size() > 5 && (in.compare(in.size() - 5, 5, ".gltf") == 0 || in.compare(in.size() - 4, 4, ".glb") == 0);
+    char load_err[512] = {0};
+    if (gltf ? spcbpt_gltf_load(argv[1], &sf, load_err, sizeof(load_err)) : spcbpt_scene_file_load(argv[1], argv[2], &sf)) {
+        fprintf(stderr, "cannot read %s %s\n", argv[1], load_err);
+        return 1;
+    }
     if (*spcbpt_scene_file_warnings(sf)) fprintf(stderr, "scene warnings: %s\n", spcbpt_scene_file_warnings(sf));
     spcbpt_scene_desc desc;
     spcbpt_scene_file_desc(sf, &desc);

@@ -274,10 +274,14 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[14]);
 /* Enable/disable event counting in the kernels (off for timed runs). */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 
-/* The HIP stream all launches of this context go to (hipStream_t as void*),
- * so a caller can bracket launches with its own events. */
+/* Streams.  A context owns two non-blocking HIP streams: the one returned here (hipStream_t as void*) carries "light trace",
+ * the sampler build, LVC import/export copies and the preprocessing; render launches ("pt", "SPCBPT_eye") go to a second one,
+ * ordered against the first with events, so that the next frame's light pass can run while an eye kernel drains.
+ * spcbpt_sync waits for both (the CUDA_SYNC_CHECK() of the reference's loop); spcbpt_sync_light waits only for the light /
+ * sampler stream -- what a multi-GPU host needs before it all-gathers the LVC shard (no reference counterpart). */
 int spcbpt_stream(spcbpt_ctx* ctx, void** stream);
 int spcbpt_sync(spcbpt_ctx* ctx);
+int spcbpt_sync_light(spcbpt_ctx* ctx);
 
 /* Kernel timing measured with HIP events on the context's stream: average
  * milliseconds per launch of `name` since the last reset, and launch count. */

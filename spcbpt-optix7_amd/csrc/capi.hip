@@ -473,11 +473,13 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         hipError_t e__ = (expr);                                                                                   \
         if (e__ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e__); delete c; return SPCBPT_ERR_HIP; } \
     } while (0)
-    CREATE_TRY(hipStreamCreate(&c->stream));
+    // non-blocking streams: a host that drives collectives on the legacy default stream (torch) must not be serialised with
+    // the render stream; every hand-over in this file is an explicit event or synchronize
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         const char* ov = getenv("SPCBPT_OVERLAP");
         if (ov && std::string(ov) == "0") c->rstream = c->stream;
-        else CREATE_TRY(hipStreamCreate(&c->rstream));
+        else CREATE_TRY(hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking));
         for (int s = 0; s < 2; s++) {
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_sampler[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
@@ -588,6 +590,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     c->kp.scene.lights = c->d_lights; c->kp.scene.tex = c->d_tex; c->kp.scene.n_lights = c->n_lights; c->kp.scene.n_mats = c->n_mats;
     c->kp.sampler_counts = c->d_sampler_counts;
     c->kp.row_step = 1;
+    CREATE_TRY(hipDeviceSynchronize());   // the uploads above went through the default stream; the context's streams do not wait for it
 #undef CREATE_TRY
     *out = c;
     return SPCBPT_OK;
@@ -639,8 +642,9 @@ int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
     dev_free(c->d_accum); dev_free(c->d_frame);
     HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
     HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
-    HIP_TRY(c, hipMemset(c->d_accum, 0, (size_t)w * h * 16));
-    HIP_TRY(c, hipMemset(c->d_frame, 0, (size_t)w * h * 4));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)w * h * 16, c->rstream));
+    HIP_TRY(c, hipMemsetAsync(c->d_frame, 0, (size_t)w * h * 4, c->rstream));
+    HIP_TRY(c, hipStreamSynchronize(c->rstream));
     c->kp.width = w; c->kp.height = h; c->kp.accum = c->d_accum; c->kp.frame = c->d_frame;
     return SPCBPT_OK;
 }
@@ -792,6 +796,7 @@ int spcbpt_reset_counters(spcbpt_ctx* c) {
 int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; return SPCBPT_OK; }
 
 int spcbpt_stream(spcbpt_ctx* c, void** s) { CTX_CHECK(c); if (!s) return SPCBPT_ERR_INVALID_ARG; *s = (void*)c->stream; return SPCBPT_OK; }
+int spcbpt_sync_light(spcbpt_ctx* c) { CTX_CHECK(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SPCBPT_OK; }
 int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); if (c->sync_all()) return SPCBPT_ERR_HIP; return SPCBPT_OK; }
 
 int spcbpt_kernel_time(spcbpt_ctx* c, const char* name, double* avg_ms, int* launches) {
@@ -812,7 +817,7 @@ static int trace_common(spcbpt_ctx* c, const float* rays, int n, float** d_rays)
     for (size_t i = 0; i < (size_t)n * 8; i++)
         if (!std::isfinite(rays[i]) && !(i % 8 == 7)) { c->error = "non-finite ray component"; return SPCBPT_ERR_INVALID_ARG; }
     HIP_TRY(c, dev_alloc(d_rays, (size_t)n * 8));
-    HIP_TRY(c, hipMemcpy(*d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpyAsync(*d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
     return c->ensure_spill(((size_t)n + 255) / 256 * 256);
 }
 int spcbpt_trace_closest(spcbpt_ctx* c, const float* rays, int n, float* out_t, int32_t* out_tri, float* out_uv) {

@@ -92,7 +92,9 @@ class FrameExchanger:
         import torch.distributed as dist
         r = self.r
         dv, dc, cap = r.lvc_export()
-        r.sync()  # the context's stream -> torch's stream hand-off
+        # hand-off from the context's light stream to torch's stream; the render stream is NOT waited for, so the previous
+        # frame's eye kernel may still be draining while the shards travel
+        r.sync_light()
         my_count = device_view(dc, 8, self.device).view(torch.int32)[:1]
         dist.all_gather_into_tensor(self.counts, my_count.clone())
         counts = self.counts.cpu().tolist()   # one small D2H per frame (the sampler build needs the total on the host anyway)
@@ -110,7 +112,7 @@ class FrameExchanger:
         for k, c in enumerate(counts):
             self.cat_buf[off: off + c * VERTEX_BYTES].copy_(out[k * nbytes: k * nbytes + c * VERTEX_BYTES])
             off += c * VERTEX_BYTES
-        torch.cuda.synchronize(self.device)
+        torch.cuda.current_stream(self.device).synchronize()   # torch's stream only (a device-wide sync would wait for the eye kernel)
         r.lvc_import_device(self.cat_buf.data_ptr(), total)
         return total
 

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
     if (rc) die(nullptr, "spcbpt_create", rc);
     int nt, nn, depth;
     CHECK(ctx, spcbpt_scene_info(ctx, &nt, &nn, &depth));
-    printf("scene: %d triangles, LBVH %d nodes depth %d\n", nt, nn, depth);
+    printf("scene: %d triangles, BVH %d nodes depth %d\n", nt, nn, depth);
     CHECK(ctx, spcbpt_set_camera_lookat(ctx, eye, lookat, up, fov, (float)width / (float)height));
     CHECK(ctx, spcbpt_resize(ctx, width, height));
     spcbpt_light_trace_params lt = {100000, 52, 1, 0, 0, 1};

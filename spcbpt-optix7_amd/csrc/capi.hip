@@ -60,7 +60,8 @@ void Context::time_end() {
 }
 int Context::sync_all() {
     HIP_TRY(this, hipStreamSynchronize(stream));
-    if (rstream != stream) HIP_TRY(this, hipStreamSynchronize(rstream));
+    for (int k = 0; k < 2; k++)
+        if (rstreams[k] && rstreams[k] != stream) HIP_TRY(this, hipStreamSynchronize(rstreams[k]));
     return 0;
 }
 // the members d_lvc / d_vals2 / d_cmfs / d_subspace / d_sampler_counts always name the set of the light pass in progress
@@ -87,8 +88,8 @@ int Context::ensure_spill(size_t threads, bool render) {
     kp.spill_entries = entries;
     if (entries == 0) { kp.spill = nullptr; return 0; }
     const size_t need = threads * (size_t)entries;
-    uint32_t*& buf = render ? d_spill_r : d_spill;   // one area per stream: kernels of both may be in flight together
-    size_t& cap = render ? spill_r_capacity : spill_capacity;
+    uint32_t*& buf = render ? d_spill_rs[rk] : d_spill;   // one area per stream: kernels of all three may be in flight together
+    size_t& cap = render ? spill_rs_capacity[rk] : spill_capacity;
     if (need > cap) {
         dev_free(buf);   // hipFree waits for the device
         HIP_TRY(this, dev_alloc(&buf, need));
@@ -287,6 +288,10 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }
     kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
     kp.counters = counting ? d_counters : nullptr;
+    rk ^= 1;   // consecutive render launches alternate streams (see context.h)
+    if (spcbpt_alg && !eye_megakernel) rk = 0;   // the per-phase kernels share one set of queues: no overlap between their frames
+    rstream = rstreams[rk];
+    kp.result = d_result[rk];
     if (spcbpt_alg) {
         // the sampler tables this launch reads (set `eset`) were built on `stream`
         kp.lvc = set_lvc[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset];
@@ -302,14 +307,14 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         HIP_TRY(this, hipGetLastError());
         HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
         ev_render_set[eset] = true;
-        return 0;
+        return finish_frame();
     }
     int rc = ensure_spill((size_t)render_thread_count(kp), true);
     if (rc) return rc;
     if (spcbpt_alg) {
         kp.n_tiles = (uint32_t)render_tile_count(kp);
-        kp.work_counter = d_work_counter;
-        HIP_TRY(this, hipMemsetAsync(d_work_counter, 0, sizeof(uint32_t), rstream));
+        kp.work_counter = d_work_counter + rk;
+        HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
         if (!blocks_per_cu[counting]) blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
     }
     time_begin(name, rstream);
@@ -321,6 +326,16 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
         ev_render_set[eset] = true;
     }
+    return finish_frame();
+}
+
+// merge this launch's `result` into accum / frame, after the previous launch's merge (the only cross-frame ordering)
+int Context::finish_frame() {
+    if (ev_merge_set[rk ^ 1] && rstreams[0] != rstreams[1]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_merge[rk ^ 1], 0));
+    launch_film_merge(kp, rstream);
+    HIP_TRY(this, hipGetLastError());
+    HIP_TRY(this, hipEventRecord(ev_merge[rk], rstream));
+    ev_merge_set[rk] = true;
     return 0;
 }
 
@@ -425,8 +440,12 @@ Context::~Context() {
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < 2; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
-    dev_free(d_spill_r); dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
-    if (rstream && rstream != stream) (void)hipStreamDestroy(rstream);
+    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
+    for (int s = 0; s < 2; s++) {
+        if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
+        if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
+        dev_free(d_result[s]); dev_free(d_spill_rs[s]);
+    }
     if (stream) (void)hipStreamDestroy(stream);
     for (int s = 0; s < 2; s++) {
         if (ev_sampler[s]) (void)hipEventDestroy(ev_sampler[s]);
@@ -478,8 +497,12 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         const char* ov = getenv("SPCBPT_OVERLAP");
-        if (ov && std::string(ov) == "0") c->rstream = c->stream;
-        else CREATE_TRY(hipStreamCreateWithFlags(&c->rstream, hipStreamNonBlocking));
+        for (int s = 0; s < 2; s++) {
+            if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
+            else CREATE_TRY(hipStreamCreateWithFlags(&c->rstreams[s], hipStreamNonBlocking));
+            CREATE_TRY(hipEventCreateWithFlags(&c->ev_merge[s], hipEventDisableTiming));
+        }
+        c->rstream = c->rstreams[0];
         for (int s = 0; s < 2; s++) {
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_sampler[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
@@ -582,7 +605,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         const char* mode = getenv("SPCBPT_EYE_PASS");
         c->eye_megakernel = !(mode && std::string(mode) == "wavefront");
     }
-    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)1));
+    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)2));
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
     CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
     memset(&c->kp, 0, sizeof(c->kp));
@@ -642,6 +665,10 @@ int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
     dev_free(c->d_accum); dev_free(c->d_frame);
     HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
     HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
+    for (int s = 0; s < 2; s++) {
+        dev_free(c->d_result[s]);
+        HIP_TRY(c, dev_alloc(&c->d_result[s], (size_t)w * h * 4));
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)w * h * 16, c->rstream));
     HIP_TRY(c, hipMemsetAsync(c->d_frame, 0, (size_t)w * h * 4, c->rstream));
     HIP_TRY(c, hipStreamSynchronize(c->rstream));
@@ -758,7 +785,9 @@ int spcbpt_accum_device_ptr(spcbpt_ctx* c, void** p) {
 int spcbpt_clear_accum(spcbpt_ctx* c) {
     CTX_CHECK(c);
     if (!c->d_accum) return SPCBPT_ERR_STATE;
-    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->kp.width * c->kp.height * 16, c->rstream));  // ordered with the render launches
+    if (c->sync_all()) return SPCBPT_ERR_HIP;   // merges of both render streams may still be pending
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->kp.width * c->kp.height * 16, c->rstreams[0]));
+    HIP_TRY(c, hipStreamSynchronize(c->rstreams[0]));
     return SPCBPT_OK;
 }
 

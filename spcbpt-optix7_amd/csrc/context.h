@@ -28,7 +28,15 @@ struct Context {
     // light pass + sampler build of the NEXT frame do not depend on it.  With the sampler tables double-buffered, the host
     // loop launch("light trace") -> build_sampler -> launch("SPCBPT_eye") keeps its meaning while frame f+1's light pass
     // fills the idle machine under frame f's drain.  SPCBPT_OVERLAP=0 puts everything back on one stream.
-    hipStream_t rstream = nullptr;
+    hipStream_t rstream = nullptr;              // = rstreams[rk], the stream of the render launch being issued
+    // Consecutive render launches alternate between two streams, each with its own work counter, spill area and `result`
+    // buffer: frame f+1's eye kernel starts filling the machine while frame f's drains.  Only the film merges (running mean +
+    // tone map from `result` into accum/frame) are chained, by ev_merge, so the image is the same as with one stream.
+    hipStream_t rstreams[2] = {nullptr, nullptr};
+    int rk = 0;
+    float* d_result[2] = {nullptr, nullptr};
+    hipEvent_t ev_merge[2] = {nullptr, nullptr};
+    bool ev_merge_set[2] = {false, false};
     hipEvent_t ev_sampler[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr};
     bool ev_sampler_set[2] = {false, false}, ev_render_set[2] = {false, false};
     int lset = 0, eset = 0;  // buffer set of the light pass / sampler build in progress, and of the sampler eye launches use
@@ -37,8 +45,8 @@ struct Context {
     float* set_cmfs[2] = {nullptr, nullptr};
     DSubspace* set_subspace[2] = {nullptr, nullptr};
     int* set_counts[2] = {nullptr, nullptr};
-    uint32_t* d_spill_r = nullptr;   // traversal-stack spill area of the render stream (d_spill serves `stream`)
-    size_t spill_r_capacity = 0;
+    uint32_t* d_spill_rs[2] = {nullptr, nullptr};   // traversal-stack spill areas of the render streams (d_spill serves `stream`)
+    size_t spill_rs_capacity[2] = {0, 0};
     int sync_all();
     void select_set(int s);
     std::string error;
@@ -118,6 +126,7 @@ struct Context {
     int fetch_counts();
     int build_sampler();
     int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs);
+    int finish_frame();
     // preprocess.hip
     Preprocessor* pre = nullptr;
     spcbpt_pretrace_path* d_pre_paths = nullptr;

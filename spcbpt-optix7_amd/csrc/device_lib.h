@@ -739,6 +739,10 @@ SPC_DEV uint32_t quant8(float x) {
 }
 SPC_DEV void film_write(const KParams& p, uint32_t x, uint32_t y, f3 result) {
     const size_t idx = (size_t)y * p.width + x;
+    if (p.result) {  // deferred: k_film_merge applies the running mean and the tone map in frame order
+        reinterpret_cast<float4*>(p.result)[idx] = make_float4(result.x, result.y, result.z, 1.0f);
+        return;
+    }
     float4* acc = reinterpret_cast<float4*>(p.accum);
     f3 c = result;
     if (p.subframe > 0) {

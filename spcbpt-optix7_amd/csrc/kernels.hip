@@ -808,6 +808,21 @@ int render_tile_count(const KParams& p) {
     const int nb = band_end > band_begin ? (band_end - band_begin + step - 1) / step : 0;
     return tiles_x * nb;
 }
+// accumulate + tone-map (raygen.cu:421-442) of one subframe from the `result` buffer a render kernel filled, for the pixels of
+// the selected bands.  Separate from the render kernels so that consecutive frames' render kernels may overlap.
+__global__ __launch_bounds__(BLOCK) void k_film_merge(const KParams p, const float* __restrict__ result) {
+    uint32_t x, y;
+    if (!lane_pixel(p, x, y)) return;
+    const float4 r = reinterpret_cast<const float4*>(result)[(size_t)y * p.width + x];
+    film_write(p, x, y, mk3(r.x, r.y, r.z));  // p.result is null here: the direct path
+}
+void launch_film_merge(const KParams& p, hipStream_t s) {
+    const int blocks = render_blocks(p);
+    if (blocks <= 0 || !p.result) return;
+    KParams q = p;
+    q.result = nullptr;
+    hipLaunchKernelGGL(k_film_merge, dim3(blocks), dim3(BLOCK), 0, s, q, p.result);
+}
 void launch_pt(const KParams& p, bool count, hipStream_t s) {
     const int blocks = render_blocks(p);
     if (blocks <= 0) return;

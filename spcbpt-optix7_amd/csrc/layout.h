@@ -96,6 +96,8 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     uint32_t width, height, subframe;
     int32_t row_begin, row_end, row_step;  // 8-row bands: see spcbpt_launch
     float* accum;        // float4 per pixel
+    float* result;       // float4 per pixel or null: radiance of THIS subframe, merged into accum/frame by k_film_merge (render
+                         // launches of consecutive frames overlap; only the merges are ordered)
     uint32_t* frame;     // RGBA8 per pixel
     // subspace tuple (subspaceMacroInfo)
     const float* eye_tree;

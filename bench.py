@@ -81,6 +81,8 @@ def main():
                     help="gltf: write the generated scene as glTF 2.0 and read it back with the C++ reader (default); memory: hand the arrays over directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
+    ap.add_argument("--render-streams", type=int, default=0,
+                    help="frames in flight per GPU (0 = 2 on one GPU, 4 when the frame is sharded: a rank's share of a frame does not fill the GPU)")
     ap.add_argument("--write-image", default="")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -112,6 +114,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
+    streams = args.render_streams if args.render_streams > 0 else (4 if world > 1 else 2)
+    os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     scene = make_scene(pkg, args.scene, args.tris)
     if args.scene_route == "gltf":
         # BASELINE config 2: "bedroom-class glTF scene" -- the generated scene goes to disk as glTF 2.0 (binary buffers + PPM
@@ -214,7 +218,7 @@ def main():
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
-                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+                       "frames_in_flight": streams, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -60,7 +60,7 @@ void Context::time_end() {
 }
 int Context::sync_all() {
     HIP_TRY(this, hipStreamSynchronize(stream));
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < n_render; k++)
         if (rstreams[k] && rstreams[k] != stream) HIP_TRY(this, hipStreamSynchronize(rstreams[k]));
     return 0;
 }
@@ -167,7 +167,7 @@ int Context::ensure_lvc_capacity(size_t n) {
     if (sync_all()) return SPCBPT_ERR_HIP;
     dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_weights);
     dev_free(d_wsorted); dev_free(d_prefix);
-    for (int s = 0; s < 2; s++) {   // what the eye pass reads is double-buffered (see context.h)
+    for (int s = 0; s < n_sets; s++) {   // what the eye pass reads exists once per frame in flight (see context.h)
         dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
         HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
     }
@@ -206,7 +206,7 @@ int Context::launch_light(uint32_t frame) {
     if (rc) return rc;
     kp.counters = counting ? d_counters : nullptr;
     // write the set the eye pass is NOT reading; it was last read by the render launch before the previous one
-    lset ^= 1;
+    lset = (lset + 1) % n_sets;
     select_set(lset);
     if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_render[lset], 0));
     HIP_TRY(this, hipMemsetAsync(d_core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), stream));
@@ -288,7 +288,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }
     kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
     kp.counters = counting ? d_counters : nullptr;
-    rk ^= 1;   // consecutive render launches alternate streams (see context.h)
+    rk = (rk + 1) % n_render;   // consecutive render launches rotate through the render streams (see context.h)
     if (spcbpt_alg && !eye_megakernel) rk = 0;   // the per-phase kernels share one set of queues: no overlap between their frames
     rstream = rstreams[rk];
     kp.result = d_result[rk];
@@ -331,11 +331,12 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
 
 // merge this launch's `result` into accum / frame, after the previous launch's merge (the only cross-frame ordering)
 int Context::finish_frame() {
-    if (ev_merge_set[rk ^ 1] && rstreams[0] != rstreams[1]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_merge[rk ^ 1], 0));
+    if (last_merge_k >= 0 && last_merge_k != rk && rstreams[last_merge_k] != rstream) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_merge[last_merge_k], 0));
     launch_film_merge(kp, rstream);
     HIP_TRY(this, hipGetLastError());
     HIP_TRY(this, hipEventRecord(ev_merge[rk], rstream));
     ev_merge_set[rk] = true;
+    last_merge_k = rk;
     return 0;
 }
 
@@ -439,15 +440,15 @@ Context::~Context() {
     dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
-    for (int s = 0; s < 2; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
+    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
     dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < kMaxRender; s++) {
         if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
         dev_free(d_result[s]); dev_free(d_spill_rs[s]);
     }
     if (stream) (void)hipStreamDestroy(stream);
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < kMaxSets; s++) {
         if (ev_sampler[s]) (void)hipEventDestroy(ev_sampler[s]);
         if (ev_render[s]) (void)hipEventDestroy(ev_render[s]);
     }
@@ -497,13 +498,17 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         const char* ov = getenv("SPCBPT_OVERLAP");
-        for (int s = 0; s < 2; s++) {
+        const char* nr = getenv("SPCBPT_RENDER_STREAMS");
+        c->n_render = nr ? std::max(1, std::min((int)Context::kMaxRender, atoi(nr))) : 2;
+        if (ov && std::string(ov) == "0") c->n_render = 1;
+        c->n_sets = c->n_render + 1;
+        for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
             else CREATE_TRY(hipStreamCreateWithFlags(&c->rstreams[s], hipStreamNonBlocking));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_merge[s], hipEventDisableTiming));
         }
         c->rstream = c->rstreams[0];
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < c->n_sets; s++) {
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_sampler[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
         }
@@ -590,7 +595,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     }
     CREATE_TRY(dev_alloc(&c->d_tex, texs.size()));
     if (!texs.empty()) CREATE_TRY(hipMemcpy(c->d_tex, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < c->n_sets; s++) {
         CREATE_TRY(dev_alloc(&c->set_subspace[s], (size_t)SPCBPT_NUM_SUBSPACE));
         CREATE_TRY(dev_alloc(&c->set_counts[s], (size_t)2));
         CREATE_TRY(hipMemset(c->set_counts[s], 0, 2 * sizeof(int)));
@@ -605,7 +610,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         const char* mode = getenv("SPCBPT_EYE_PASS");
         c->eye_megakernel = !(mode && std::string(mode) == "wavefront");
     }
-    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)2));
+    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)Context::kMaxRender));
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
     CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
     memset(&c->kp, 0, sizeof(c->kp));
@@ -665,7 +670,7 @@ int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
     dev_free(c->d_accum); dev_free(c->d_frame);
     HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
     HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < c->n_render; s++) {
         dev_free(c->d_result[s]);
         HIP_TRY(c, dev_alloc(&c->d_result[s], (size_t)w * h * 4));
     }

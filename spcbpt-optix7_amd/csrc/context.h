@@ -32,21 +32,25 @@ struct Context {
     // Consecutive render launches alternate between two streams, each with its own work counter, spill area and `result`
     // buffer: frame f+1's eye kernel starts filling the machine while frame f's drains.  Only the film merges (running mean +
     // tone map from `result` into accum/frame) are chained, by ev_merge, so the image is the same as with one stream.
-    hipStream_t rstreams[2] = {nullptr, nullptr};
-    int rk = 0;
-    float* d_result[2] = {nullptr, nullptr};
-    hipEvent_t ev_merge[2] = {nullptr, nullptr};
-    bool ev_merge_set[2] = {false, false};
-    hipEvent_t ev_sampler[2] = {nullptr, nullptr}, ev_render[2] = {nullptr, nullptr};
-    bool ev_sampler_set[2] = {false, false}, ev_render_set[2] = {false, false};
+    // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..4).  More frames in flight pay when one frame does not
+    // fill the GPU -- a rank of an 8-GPU job renders 1/8 of the image but its frame still ends with the same 50-bounce chain.
+    static const int kMaxRender = 4, kMaxSets = kMaxRender + 1;
+    int n_render = 2, n_sets = 3;   // n_sets = n_render + 1: one set per eye kernel in flight + the one the light pass writes
+    hipStream_t rstreams[kMaxRender] = {};
+    int rk = 0, last_merge_k = -1;
+    float* d_result[kMaxRender] = {};
+    hipEvent_t ev_merge[kMaxRender] = {};
+    bool ev_merge_set[kMaxRender] = {};
+    hipEvent_t ev_sampler[kMaxSets] = {}, ev_render[kMaxSets] = {};
+    bool ev_sampler_set[kMaxSets] = {}, ev_render_set[kMaxSets] = {};
     int lset = 0, eset = 0;  // buffer set of the light pass / sampler build in progress, and of the sampler eye launches use
-    LightVertex* set_lvc[2] = {nullptr, nullptr};
-    uint32_t* set_vals2[2] = {nullptr, nullptr};
-    float* set_cmfs[2] = {nullptr, nullptr};
-    DSubspace* set_subspace[2] = {nullptr, nullptr};
-    int* set_counts[2] = {nullptr, nullptr};
-    uint32_t* d_spill_rs[2] = {nullptr, nullptr};   // traversal-stack spill areas of the render streams (d_spill serves `stream`)
-    size_t spill_rs_capacity[2] = {0, 0};
+    LightVertex* set_lvc[kMaxSets] = {};
+    uint32_t* set_vals2[kMaxSets] = {};
+    float* set_cmfs[kMaxSets] = {};
+    DSubspace* set_subspace[kMaxSets] = {};
+    int* set_counts[kMaxSets] = {};
+    uint32_t* d_spill_rs[kMaxRender] = {};   // traversal-stack spill areas of the render streams (d_spill serves `stream`)
+    size_t spill_rs_capacity[kMaxRender] = {};
     int sync_all();
     void select_set(int s);
     std::string error;

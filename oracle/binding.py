@@ -124,6 +124,11 @@ class Oracle:
         """Test knob: double-precision CMF accumulation (product behaviour) instead of the reference's float prefix sums."""
         self.l.orc_set_cmf_double(self.h, int(on))
 
+    def set_skip_null_connections(self, on):
+        """Test knob: like the product, do not trace shadow rays of connections whose BSDF factor is exactly zero (DESIGN.md
+        d10).  The image is the same either way; only the shadow-ray / traversal event counts change."""
+        self.l.orc_set_skip_null_connections(self.h, int(on))
+
     def enable_counters(self, on):
         self.l.orc_enable_counters(self.h, int(on))
 

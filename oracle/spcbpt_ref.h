@@ -118,6 +118,9 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
     // test knob, NOT reference behaviour: accumulate the per-subspace CMFs in double (the product's device scan does);
     // false = the reference's serial float prefix sums (device_thrust.cu:273-286)
     bool cmf_double = false;
+    // test knob, NOT reference behaviour: do not trace the shadow ray of a connection whose BSDF factor is exactly zero
+    // (the product skips them; the image is unchanged, only the event counts differ)
+    bool skip_null_connections = false;
 
     float Gamma(int eye_id, int light_id) const {
         if (CMFGamma && Q) {
@@ -810,6 +813,10 @@ inline float3 spcbpt_sample(const Params& P, unsigned x, unsigned y) {
             float pmf_secondStage;
             const BDPTVertex& light_subpath = sampleSecondStage(P, light_id, payload.seed, pmf_secondStage);
             if (P.counters) P.counters->connections++;
+            if (P.skip_null_connections) {
+                const float3 cd = normalize(eye_subpath.position - light_subpath.position);
+                if (dot(eye_subpath.normal, -cd) <= 0.0f || dot(light_subpath.normal, cd) < 0.0f) continue;
+            }
             if (S.visibilityTest(eye_subpath.position, light_subpath.position, P.counters)) {
                 float pmf = P.sampler.path_count * pmf_secondStage * pmf_firstStage;
                 float3 res = connectVertex_SPCBPT(P, eye_subpath, light_subpath) / pmf;

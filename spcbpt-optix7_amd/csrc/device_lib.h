@@ -659,6 +659,14 @@ SPC_DEV VCore core_of(const LightVertex& b) {
     return c;
 }
 
+// A connection whose value is exactly zero whatever the visibility: the eye vertex sees the light vertex from
+// behind its own surface (bsdf_eval returns 0 for N.V <= 0), or the light vertex faces away (N.L <= 0 on a surface vertex,
+// the one-sided term on an emitter vertex).  Same vectors and the same normalize() as connect_vertices.
+SPC_DEV bool null_connection(f3 apos, f3 an, f3 bpos, f3 bn) {
+    const f3 connectDir = normalize(apos - bpos);
+    return dot(an, -connectDir) <= 0.0f || dot(bn, connectDir) < 0.0f;
+}
+
 // connectVertex_SPCBPT (raygen.cu:253-303) with rmis::general_connection / connection_lightSource
 // (rmis.h:212-247 / 281-313) fused: every BSDF lobe is fetched once.
 template <bool COUNT>

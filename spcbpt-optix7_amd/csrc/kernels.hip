@@ -191,11 +191,15 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                             lslot[it] = p.jump[ss.jump_bias + k];
                             cn.add(C_CONN);
                             const float4 bq0 = reinterpret_cast<const float4*>(p.lvc + lslot[it])[0];
+                            const float4 bq1 = reinterpret_cast<const float4*>(p.lvc + lslot[it])[1];
                             const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
                             const float len = sqrtf(dot(bias, bias));
                             const f3 sdir = bias / len;
-                            rq = make_float4(sdir.x, sdir.y, sdir.z, len);
                             conn_pmf[it] = (float)path_count * pmf2 * pmf1;
+                            // a pair that faces away on either side has a BSDF factor of exactly zero (bsdf_eval / the one-sided
+                            // emitter term of connect_vertices): its shadow ray cannot change the pixel and is not traced
+                            if (!null_connection(cur.c.pos, cur.c.n, mk3(bq0.x, bq0.y, bq0.z), mk3(bq1.x, bq1.y, bq1.z)))
+                                rq = make_float4(sdir.x, sdir.y, sdir.z, len);
                         }
                         w_ray[it * 64 + lane] = rq;
                     }

@@ -184,13 +184,16 @@ __global__ __launch_bounds__(WBLOCK) void k_wf_shade(const KParams p, const WfSt
                         const int kk = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
                         const int lslot = p.jump[ss.jump_bias + kk];
                         const float4 bq0 = reinterpret_cast<const float4*>(p.lvc + lslot)[0];
+                        const float4 bq1 = reinterpret_cast<const float4*>(p.lvc + lslot)[1];
                         const f3 bias = xyz(bq0) - mid.c.pos;
                         const float len = sqrtf(dot(bias, bias));
                         const f3 sdir = bias / len;
                         cn.add(C_CONN);
                         const float pmf = (float)path_count * pmf2 * pmf1;
                         conn_ray[k] = pack(sdir, len);
-                        conn_rec[k] = make_uint4((uint32_t)lslot, __float_as_uint(pmf), slot, (uint32_t)it);
+                        // zero-valued pairs are not traced (null_connection, device_lib.h)
+                        const bool null_conn = null_connection(mid.c.pos, mid.c.n, xyz(bq0), xyz(bq1));
+                        conn_rec[k] = make_uint4((uint32_t)lslot, __float_as_uint(pmf), null_conn ? 0xffffffffu : slot, (uint32_t)it);
                     } else {
                         conn_rec[k] = make_uint4(0u, 0u, 0xffffffffu, (uint32_t)it);
                     }

@@ -125,8 +125,9 @@ class Oracle:
         self.l.orc_set_cmf_double(self.h, int(on))
 
     def set_skip_null_connections(self, on):
-        """Test knob: like the product, do not trace shadow rays of connections whose BSDF factor is exactly zero (DESIGN.md
-        d10).  The image is the same either way; only the shadow-ray / traversal event counts change."""
+        """Test knob: like the product, skip work whose contribution is exactly zero -- shadow rays of connections whose BSDF
+        factor is zero and the rest of an eye path after a sampled direction with zero BSDF value (d11).  The
+        image is the same either way; only the event counts change."""
         self.l.orc_set_skip_null_connections(self.h, int(on))
 
     def enable_counters(self, on):

@@ -118,8 +118,9 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
     // test knob, NOT reference behaviour: accumulate the per-subspace CMFs in double (the product's device scan does);
     // false = the reference's serial float prefix sums (device_thrust.cu:273-286)
     bool cmf_double = false;
-    // test knob, NOT reference behaviour: do not trace the shadow ray of a connection whose BSDF factor is exactly zero
-    // (the product skips them; the image is unchanged, only the event counts differ)
+    // test knob, NOT reference behaviour: skip work whose contribution is exactly zero, as the product does -- the shadow ray
+    // of a connection whose BSDF factor is zero and the rest of an eye path whose sampled direction has a
+    // BSDF value of zero (d11).  The image is unchanged; only the event counts differ.
     bool skip_null_connections = false;
 
     float Gamma(int eye_id, int light_id) const {
@@ -423,6 +424,7 @@ inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const Hi
     if (Last.isOrigin) Mid.flux = Last.flux * pdf_G;
     else Mid.flux = Mid.flux * Last.flux * pdf_G;
     Next.flux = Eval(currentPbr, N, -ray_direction, prd->ray_direction);
+    if (P.skip_null_connections && !light_side && Next.flux.x == 0.0f && Next.flux.y == 0.0f && Next.flux.z == 0.0f) prd->done = true;  // d11
     Next.singlePdf = prd->pdf;
 
     Mid.lastPosition = Last.position;

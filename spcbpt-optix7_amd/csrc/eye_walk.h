@@ -17,7 +17,7 @@ struct WalkState {
 
 template <bool COUNT>
 SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
-                             WalkState& w, EyeVertex& mid, Counts<COUNT>& cn) {
+                             WalkState& w, EyeVertex& mid, Counts<COUNT>& cn, bool stop_dead_paths = false) {
     const DeviceScene& S = p.scene;
     Pbr pbr = load_pbr(S, g.mat);
     color_tex_sample(S, g, pbr, cn);
@@ -55,6 +55,10 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
     cn.add(C_VERTEX);
     // next segment + Russian roulette (the vertex itself is kept; hit_program.cu:324-337)
     w.next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
+    // a sampled direction whose BSDF value is exactly zero (it points below the surface) gives every later
+    // vertex a flux of exactly zero -- emitter hits and connections of the rest of the path contribute 0 (or NaN -> rejected).
+    // The render kernels end the path after this vertex's connections; the image is unchanged.
+    if (stop_dead_paths && w.next_flux.x == 0.0f && w.next_flux.y == 0.0f && w.next_flux.z == 0.0f) w.done = true;
     w.next_single_pdf = pdf;
     w.origin = g.P;
     w.dir = new_dir;

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     finished = true;
                 } else {
                     EyeVertex mid;
-                    eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
+                    eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn, true);
                     cur = mid;
                     has_vertex = true;
                     long long t_s0 = COUNT ? clock64() : 0;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(WBLOCK) void k_wf_shade(const KParams p, const WfSt
             } else {
                 surface = true;
                 EyeVertex mid;
-                eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn);
+                eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn, true);
                 store_eye_vertex(wf, slot, mid);
                 // shadow-ray records sit at fixed positions (connection-major: it * count + item), no compaction needed
                 for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {

@@ -15,6 +15,7 @@ namespace spc {
 
 static constexpr int BLOCK = 256;
 static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
+static_assert(STACK_LDS >= 19, "the pooled connections publish 19 dwords per eye vertex through the traversal-stack LDS");
 #ifndef SPC_WAVES
 // minimum waves per SIMD requested from the register allocator for the megakernel.  Measured on MI355X (bedroom 1080p, ms per
 // frame) with the pooled if-if traversal: 2 (241 VGPR, no scratch) -> 12.86, 3 (168 VGPR, 252 B scratch) -> 10.72,
@@ -50,8 +51,15 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     __shared__ float4 s_org[BLOCK];
     __shared__ uint8_t s_vis[(BLOCK / 64) * POOL_RAYS];
     __shared__ uint32_t s_next[BLOCK / 64];
+    __shared__ int32_t s_slot[(BLOCK / 64) * POOL_RAYS];   // LVC slot of connection it * 64 + lane
+    __shared__ float s_pmf[(BLOCK / 64) * POOL_RAYS];      // its resampling pmf (path_count * pmf2 * pmf1)
+    __shared__ uint8_t s_job[(BLOCK / 64) * POOL_RAYS];    // compacted list of the unoccluded connections of the wave
     const DeviceScene& S = p.scene;
     const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    int32_t* w_slot = s_slot + wave_in_block * POOL_RAYS;
+    float* w_pmf = s_pmf + wave_in_block * POOL_RAYS;
+    uint8_t* w_job = s_job + wave_in_block * POOL_RAYS;
+    uint32_t* w_stack = s_stack + wave_in_block * 64;      // [entry * BLOCK + lane]: free between two traversal passes
     float4* w_ray = s_ray + wave_in_block * POOL_RAYS;
     float4* w_org = s_org + wave_in_block * 64;
     uint8_t* w_vis = s_vis + wave_in_block * POOL_RAYS;
@@ -78,10 +86,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     // software pipeline: the vertex built in iteration i is connected in iteration i + 1, in the same traversal pass that
     // extends the path by its next segment (the next direction is drawn before the connections, hit_program.cu:324-337)
     bool has_vertex = false, has_ray = false;
-    int lslot[SPCBPT_CONNECTION_N];
-    float conn_pmf[SPCBPT_CONNECTION_N];
 #pragma unroll
-    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lslot[it] = 0; conn_pmf[it] = 1.0f; w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f); }
+    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f);
     const unsigned long long w_start = COUNT ? wall_clock64() : 0ull;
     long long t_ph = COUNT ? clock64() : 0;
 #define SPC_PHASE(slot) do { if (COUNT) { const long long t1__ = clock64(); if (lane == 0) cn.add(slot, (unsigned)((t1__ - t_ph) >> 4)); t_ph = t1__; } } while (0)
@@ -138,20 +144,74 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         SPC_PHASE(C_T_POOL);
-        // ---- connect the unoccluded pairs of the previous vertex, in connection order
-        if (has_vertex) {
+        // ---- connect the unoccluded pairs of the previous vertices.  Only ~1/4 of the 192 (lane, connection) slots of a wave
+        // hold an unoccluded pair, so the pairs are compacted into a job list and every lane -- whatever the state of its
+        // own path -- evaluates one job per round: the eye vertices are published through the (now idle) traversal-stack
+        // LDS, the results come back through the ray slots and each owner adds its own in connection order, which keeps
+        // the floating-point sums identical to evaluating them in place.
+        {
+            uint32_t my_live = 0u, n_jobs = 0u;
 #pragma unroll
             for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                if (w_ray[it * 64 + lane].w >= 0.0f && w_vis[it * 64 + lane]) {
+                const bool live = has_vertex && w_ray[it * 64 + lane].w >= 0.0f && w_vis[it * 64 + lane] != 0;
+                const unsigned long long m = __ballot(live);
+                if (live) {
+                    w_job[n_jobs + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(it * 64 + lane);
+                    my_live |= 1u << it;
+                }
+                n_jobs += (uint32_t)__popcll(m);
+            }
+            if (n_jobs != 0u) {
+                if (my_live) {  // publish this lane's eye vertex (position and lastNormalProjection already sit in w_org)
+                    uint32_t* col = w_stack + lane;
+                    col[0 * BLOCK] = __float_as_uint(cur.c.n.x); col[1 * BLOCK] = __float_as_uint(cur.c.n.y); col[2 * BLOCK] = __float_as_uint(cur.c.n.z);
+                    col[3 * BLOCK] = __float_as_uint(cur.c.color.x); col[4 * BLOCK] = __float_as_uint(cur.c.color.y); col[5 * BLOCK] = __float_as_uint(cur.c.color.z);
+                    col[6 * BLOCK] = __float_as_uint(cur.c.lastPos.x); col[7 * BLOCK] = __float_as_uint(cur.c.lastPos.y); col[8 * BLOCK] = __float_as_uint(cur.c.lastPos.z);
+                    col[9 * BLOCK] = __float_as_uint(cur.flux.x); col[10 * BLOCK] = __float_as_uint(cur.flux.y); col[11 * BLOCK] = __float_as_uint(cur.flux.z);
+                    col[12 * BLOCK] = __float_as_uint(cur.R3.x); col[13 * BLOCK] = __float_as_uint(cur.R3.y); col[14 * BLOCK] = __float_as_uint(cur.R3.z);
+                    col[15 * BLOCK] = __float_as_uint(cur.pdf); col[16 * BLOCK] = __float_as_uint(cur.singlePdf);
+                    col[17 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20);
+                    col[18 * BLOCK] = (uint32_t)cur.c.mat;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t j = lane; j < n_jobs; j += 64u) {
+                    const uint32_t slot = w_job[j], owner = slot & 63u;
+                    const uint32_t* col = w_stack + owner;
+                    const float4 po = w_org[owner];
+                    EyeVertex a;
+                    a.c.pos = mk3(po.x, po.y, po.z); a.c.lnp = po.w;
+                    a.c.n = mk3(__uint_as_float(col[0 * BLOCK]), __uint_as_float(col[1 * BLOCK]), __uint_as_float(col[2 * BLOCK]));
+                    a.c.color = mk3(__uint_as_float(col[3 * BLOCK]), __uint_as_float(col[4 * BLOCK]), __uint_as_float(col[5 * BLOCK]));
+                    a.c.lastPos = mk3(__uint_as_float(col[6 * BLOCK]), __uint_as_float(col[7 * BLOCK]), __uint_as_float(col[8 * BLOCK]));
+                    a.flux = mk3(__uint_as_float(col[9 * BLOCK]), __uint_as_float(col[10 * BLOCK]), __uint_as_float(col[11 * BLOCK]));
+                    a.R3 = mk3(__uint_as_float(col[12 * BLOCK]), __uint_as_float(col[13 * BLOCK]), __uint_as_float(col[14 * BLOCK]));
+                    a.pdf = __uint_as_float(col[15 * BLOCK]); a.singlePdf = __uint_as_float(col[16 * BLOCK]);
+                    const uint32_t ids = col[17 * BLOCK];
+                    a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)(ids >> 20);
+                    a.c.mat = (int)col[18 * BLOCK];
                     LightVertex b;
-                    const float4* src = reinterpret_cast<const float4*>(p.lvc + lslot[it]);
+                    const float4* src = reinterpret_cast<const float4*>(p.lvc + w_slot[slot]);
                     float4* dst = reinterpret_cast<float4*>(&b);
 #pragma unroll
                     for (int q = 0; q < 6; q++) dst[q] = src[q];
-                    f3 res = connect_vertices(p, cur, b, cn);
+                    f3 res = connect_vertices(p, a, b, cn);
                     if (is_invalid(res)) res = mk3(0.0f);
-                    res = res / conn_pmf[it];
-                    if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+                    res = res / w_pmf[slot];
+                    const bool ok = !is_invalid(res);
+                    res = res / (float)SPCBPT_CONNECTION_N;
+                    w_ray[slot] = make_float4(res.x, res.y, res.z, ok ? 1.0f : 0.0f);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                    if (my_live & (1u << it)) {
+                        const float4 r = w_ray[it * 64 + lane];
+                        if (r.w != 0.0f) result += mk3(r.x, r.y, r.z);
+                    }
                 }
             }
         }
@@ -188,14 +248,15 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                         const DSubspace ss = p.subspace[l];
                         if (ss.size != 0) {
                             const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
-                            lslot[it] = p.jump[ss.jump_bias + k];
+                            const int lslot = p.jump[ss.jump_bias + k];
+                            w_slot[it * 64 + lane] = lslot;
                             cn.add(C_CONN);
-                            const float4 bq0 = reinterpret_cast<const float4*>(p.lvc + lslot[it])[0];
-                            const float4 bq1 = reinterpret_cast<const float4*>(p.lvc + lslot[it])[1];
+                            const float4 bq0 = reinterpret_cast<const float4*>(p.lvc + lslot)[0];
+                            const float4 bq1 = reinterpret_cast<const float4*>(p.lvc + lslot)[1];
                             const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
                             const float len = sqrtf(dot(bias, bias));
                             const f3 sdir = bias / len;
-                            conn_pmf[it] = (float)path_count * pmf2 * pmf1;
+                            w_pmf[it * 64 + lane] = (float)path_count * pmf2 * pmf1;
                             // a pair that faces away on either side has a BSDF factor of exactly zero (bsdf_eval / the one-sided
                             // emitter term of connect_vertices): its shadow ray cannot change the pixel and is not traced
                             if (!null_connection(cur.c.pos, cur.c.n, mk3(bq0.x, bq0.y, bq0.z), mk3(bq1.x, bq1.y, bq1.z)))
@@ -204,7 +265,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                         w_ray[it * 64 + lane] = rq;
                     }
                     if (COUNT) cn.add(C_T_SAMPLE, (unsigned)((clock64() - t_s0) >> 4));
-                    w_org[lane] = make_float4(cur.c.pos.x, cur.c.pos.y, cur.c.pos.z, 0.0f);
+                    w_org[lane] = make_float4(cur.c.pos.x, cur.c.pos.y, cur.c.pos.z, cur.c.lnp);
                     // the loop-top test of raygen.cu:361: a path that ends here still connects this vertex (next iteration)
                     has_ray = !(w.done || depth > 50);
                 }

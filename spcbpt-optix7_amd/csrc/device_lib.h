@@ -85,26 +85,38 @@ struct Counts {
 // ---- software LBVH traversal: per-lane stack in LDS --------------------------
 // The stack is laid out entry-major ([entry][thread]) so the 64 lanes of a wave hit 64 consecutive
 // dwords = all LDS banks, conflict-free.  Entries beyond STACK_LDS spill to HBM (rare: LBVH depth).
+// The LDS column of a lane is NOT kept in a register: under the megakernel's pressure the allocator spilled it, and every push
+// and pop of the hot loop then began with a scratch reload and a vmcnt(0) wait that also drained the node fetches in
+// flight (measured: 16 M extra VMEM instructions and +1 ms per frame).  It is re-derived where needed from the wave's base
+// (wave-uniform, an SGPR) and the lane id (two v_mbcnt, volatile so that the result is never a long-lived value).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+SPC_DEV uint32_t lane_id_fresh() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 template <int BLOCK, int STACK_LDS>
 struct TravStack {
-    uint32_t* lds;    // BLOCK * STACK_LDS dwords
-    uint32_t* spill;  // per-thread spill area or null
+    lds_u32* wave_lds;  // column 0 of this wave inside the BLOCK * STACK_LDS dword array (wave-uniform)
+    uint32_t* spill;    // per-thread spill area or null
     int spill_entries;
     int sp;
     SPC_DEV void init(uint32_t* l, uint32_t* s, int se, size_t gtid) {
-        lds = l + threadIdx.x;
+        wave_lds = (lds_u32*)l + __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
         spill = s ? s + gtid * (size_t)se : nullptr;
         spill_entries = se;
         sp = 0;
     }
+    SPC_DEV lds_u32* column() const { return wave_lds + lane_id_fresh(); }
     SPC_DEV void push(uint32_t v) {
-        if (sp < STACK_LDS) lds[sp * BLOCK] = v;
+        if (sp < STACK_LDS) column()[sp * BLOCK] = v;
         else if (spill && sp - STACK_LDS < spill_entries) spill[sp - STACK_LDS] = v;
         sp++;
     }
     // pushes the (up to three) farther children of a node visit, farthest first; c1 >= c2 >= c3 (hits are sorted to the front)
     SPC_DEV void push_far(uint32_t r1, bool c1, uint32_t r2, bool c2, uint32_t r3, bool c3) {
         if (sp + 3 <= STACK_LDS) {  // common case: straight LDS stores at computed slots, no per-entry bounds logic
+            lds_u32* lds = column();
             if (c3) lds[sp * BLOCK] = r3;
             const int p2 = sp + (c3 ? 1 : 0);
             if (c2) lds[p2 * BLOCK] = r2;
@@ -119,7 +131,7 @@ struct TravStack {
     }
     SPC_DEV uint32_t pop() {
         sp--;
-        if (sp < STACK_LDS) return lds[sp * BLOCK];
+        if (sp < STACK_LDS) return column()[sp * BLOCK];
         if (spill && sp - STACK_LDS < spill_entries) return spill[sp - STACK_LDS];
         return 0xffffffffu;  // dropped subtree (stack deeper than LDS + spill): never reached when sized from the build depth
     }

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     __shared__ float s_pmf[(BLOCK / 64) * POOL_RAYS];      // its resampling pmf (path_count * pmf2 * pmf1)
     __shared__ uint8_t s_job[(BLOCK / 64) * POOL_RAYS];    // compacted list of the unoccluded connections of the wave
     const DeviceScene& S = p.scene;
-    const uint32_t lane = threadIdx.x & 63, wave_in_block = threadIdx.x >> 6;
+    // wave_in_block through readfirstlane: the per-wave LDS bases below are then wave-uniform values the compiler keeps in SGPRs
+    const uint32_t lane = threadIdx.x & 63, wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int32_t* w_slot = s_slot + wave_in_block * POOL_RAYS;
     float* w_pmf = s_pmf + wave_in_block * POOL_RAYS;
     uint8_t* w_job = s_job + wave_in_block * POOL_RAYS;
@@ -86,6 +87,13 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     // software pipeline: the vertex built in iteration i is connected in iteration i + 1, in the same traversal pass that
     // extends the path by its next segment (the next direction is drawn before the connections, hit_program.cu:324-337)
     bool has_vertex = false, has_ray = false;
+    // A path that ended at a vertex (Russian roulette / depth) still owes that vertex's connections, which are evaluated one
+    // iteration later.  Its lane does not wait for them: it parks the pixel and the radiance so far (`pend_*`), starts the next
+    // pixel-sample at once (`fresh`: the camera vertex is installed after the connect phase, which still reads `cur`), and
+    // writes the parked pixel when the connections have been added.
+    bool pend_valid = false, fresh = false;
+    uint32_t pend_xy = 0;
+    f3 pend_result = mk3(0.0f);
 #pragma unroll
     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f);
     const unsigned long long w_start = COUNT ? wall_clock64() : 0ull;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
 #define SPC_PHASE(slot) do { if (COUNT) { const long long t1__ = clock64(); if (lane == 0) cn.add(slot, (unsigned)((t1__ - t_ph) >> 4)); t_ph = t1__; } } while (0)
     while (true) {
         // ---- regeneration: hand pixel-samples of the pool to idle lanes
-        unsigned long long idle = __ballot(!alive);
+        unsigned long long idle = __ballot(!alive || !has_ray);
         while (idle != 0ull && !exhausted) {
             if (pool_left == 0) {
                 uint32_t t = 0;
@@ -106,19 +114,20 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             const int n_idle = __popcll(idle);
             const int take = n_idle < pool_left ? n_idle : pool_left;
             const int my_rank = __popcll(idle & ((1ull << lane) - 1ull));
-            if (!alive && my_rank < take) {
+            if ((!alive || !has_ray) && my_rank < take) {
                 const uint32_t slot = (uint32_t)(64 - pool_left + my_rank);
-                if (tile_pixel(p, pool_tile, slot, x, y)) {
+                uint32_t nx, ny;
+                if (tile_pixel(p, pool_tile, slot, nx, ny)) {
+                    if (alive) { pend_valid = true; pend_xy = x | (y << 16); pend_result = result; }
+                    x = nx; y = ny;
                     alive = true;
                     has_ray = true;
+                    fresh = true;
                     w.dir = camera_ray(p, x, y, w.seed);
                     w.origin = ld3(p.eye);
                     w.done = false;
                     w.next_flux = mk3(0.0f);
                     w.next_single_pdf = 1.0f;
-                    // init_EyeSubpath (raygen.cu:216-231)
-                    cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
-                    cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0;
                     result = mk3(0.0f);
                     depth = 0;
                     cn.add(C_PIX); cn.add(C_EYE);
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             }
             pool_left -= take;
             // slots that fall outside the image (partial tiles) are consumed; their lanes stay idle for this round
-            const unsigned long long still = __ballot(!alive);
+            const unsigned long long still = __ballot(!alive || !has_ray);
             if (still == idle && pool_left > 0) break;  // only out-of-image slots were handed out: avoid spinning
             idle = still;
         }
@@ -206,14 +215,26 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                f3 sum = pend_valid ? pend_result : result;
 #pragma unroll
                 for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                     if (my_live & (1u << it)) {
                         const float4 r = w_ray[it * 64 + lane];
-                        if (r.w != 0.0f) result += mk3(r.x, r.y, r.z);
+                        if (r.w != 0.0f) sum += mk3(r.x, r.y, r.z);
                     }
                 }
+                if (pend_valid) pend_result = sum;
+                else result = sum;
             }
+        }
+        if (pend_valid) {
+            film_write(p, pend_xy & 0xffffu, pend_xy >> 16, pend_result);
+            pend_valid = false;
+        }
+        if (fresh) {  // init_EyeSubpath (raygen.cu:216-231)
+            fresh = false;
+            cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
+            cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0;
         }
         has_vertex = false;
         bool finished = alive && !has_ray;  // the path ended at that vertex (Russian roulette / depth): nothing was traced

@@ -208,13 +208,18 @@ SPC_DEV void slab4q(const float4 q0, const float4 q1, const float4 q2, f3 ood, f
     const uint32_t nxb = sx ? hxb : lxb, fxb = sx ? lxb : hxb;
     const uint32_t nyb = sy ? hyb : lyb, fyb = sy ? lyb : hyb;
     const uint32_t nzb = sz ? hzb : lzb, fzb = sz ? lzb : hzb;
+    // near and far plane of an axis share the per-node constants: one packed FMA (v_pk_fma_f32) yields both distances
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, bx2 = {bx, bx}, by2 = {by, by}, bz2 = {bz, bz};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const float txn = fmaf((float)((nxb >> (8 * i)) & 0xffu), ax, bx), txf = fmaf((float)((fxb >> (8 * i)) & 0xffu), ax, bx);
-        const float tyn = fmaf((float)((nyb >> (8 * i)) & 0xffu), ay, by), tyf = fmaf((float)((fyb >> (8 * i)) & 0xffu), ay, by);
-        const float tzn = fmaf((float)((nzb >> (8 * i)) & 0xffu), az, bz), tzf = fmaf((float)((fzb >> (8 * i)) & 0xffu), az, bz);
-        const float t0 = fmaxf(fmaxf(txn, tyn), fmaxf(tzn, tmin));
-        const float t1 = fminf(fminf(txf, tyf), fminf(tzf, tmax));
+        const v2f qx = {(float)((nxb >> (8 * i)) & 0xffu), (float)((fxb >> (8 * i)) & 0xffu)};
+        const v2f qy = {(float)((nyb >> (8 * i)) & 0xffu), (float)((fyb >> (8 * i)) & 0xffu)};
+        const v2f qz = {(float)((nzb >> (8 * i)) & 0xffu), (float)((fzb >> (8 * i)) & 0xffu)};
+        const v2f tx = __builtin_elementwise_fma(qx, ax2, bx2), ty = __builtin_elementwise_fma(qy, ay2, by2),
+                  tz = __builtin_elementwise_fma(qz, az2, bz2);
+        const float t0 = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tmin));
+        const float t1 = fminf(fminf(tx.y, ty.y), fminf(tz.y, tmax));
         key[i] = (t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | (uint32_t)i) : 0xffffffffu;
     }
 }

@@ -581,6 +581,46 @@ SPC_DEV int tree_label(const float* tree, f3 position, f3 normal, f3 dir, Counts
     }
 }
 
+// Two independent classifications descended in lock-step: a descent is a chain of dependent 48-B fetches (one per level, up
+// to 15 levels), and the callers below always need two of them (eye-tree label of a new vertex + light-tree label for its
+// RMIS recursion; the two relabels of a connection).  Interleaving halves the exposed latency; the labels are the same.
+template <bool COUNT>
+SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA, const float* treeB, f3 posB, f3 nB, f3 dirB, bool needB,
+                         int& labelA, int& labelB, Counts<COUNT>& cn) {
+    int nodeA = 0, nodeB = 0;
+    bool goA = needA && treeA != nullptr, goB = needB && treeB != nullptr;
+    labelA = 0; labelB = 0;
+    while (goA || goB) {
+        float4 a0, a1, a2, b0, b1, b2;
+        if (goA) { a0 = ldq(treeA, (size_t)nodeA * TREE_QUADS); a1 = ldq(treeA, (size_t)nodeA * TREE_QUADS + 1); a2 = ldq(treeA, (size_t)nodeA * TREE_QUADS + 2); cn.add(C_TREE); }
+        if (goB) { b0 = ldq(treeB, (size_t)nodeB * TREE_QUADS); b1 = ldq(treeB, (size_t)nodeB * TREE_QUADS + 1); b2 = ldq(treeB, (size_t)nodeB * TREE_QUADS + 2); cn.add(C_TREE); }
+        if (goA) {
+            const uint32_t meta = __float_as_uint(a0.w);
+            if (meta & 4u) { labelA = (int)(meta >> 3); goA = false; }
+            else {
+                const uint32_t type = meta & 3u;
+                const f3 p = type == 0 ? posA : (type == 1 ? nA : dirA);
+                const bool bx = p.x > a0.x, by = p.y > a0.y, bz = p.z > a0.z;
+                const float4 qz = bz ? a2 : a1;
+                const float c0 = by ? qz.z : qz.x, c1 = by ? qz.w : qz.y;
+                nodeA = __float_as_int(bx ? c1 : c0);
+            }
+        }
+        if (goB) {
+            const uint32_t meta = __float_as_uint(b0.w);
+            if (meta & 4u) { labelB = (int)(meta >> 3); goB = false; }
+            else {
+                const uint32_t type = meta & 3u;
+                const f3 p = type == 0 ? posB : (type == 1 ? nB : dirB);
+                const bool bx = p.x > b0.x, by = p.y > b0.y, bz = p.z > b0.z;
+                const float4 qz = bz ? b2 : b1;
+                const float c0 = by ? qz.z : qz.x, c1 = by ? qz.w : qz.y;
+                nodeB = __float_as_int(bx ? c1 : c0);
+            }
+        }
+    }
+}
+
 // Gamma(e,l)/Q[l] (optixPathTracer.h:173-189); the product always runs with a full tuple installed
 template <bool COUNT>
 SPC_DEV float gamma_ss(const KParams& p, int e, int l, Counts<COUNT>& cn) {
@@ -661,6 +701,16 @@ SPC_DEV float rmis_weight_eye(const KParams& p, const VCore& last, int last_dept
     const int light_label = tree_label(p.light_tree, last.pos, last.n, inver_dir, cn);
     return gamma_ss(p, last_lastZone, light_label, cn) * (float)SPCBPT_CONNECTION_N;
 }
+// the same two weights with the relabel already done (tree_label2)
+template <bool COUNT>
+SPC_DEV float rmis_weight_eye_l(const KParams& p, int last_depth, int last_lastZone, int light_label, Counts<COUNT>& cn) {
+    if (last_depth == 1) return 0.0f;
+    return gamma_ss(p, last_lastZone, light_label, cn) * (float)SPCBPT_CONNECTION_N;
+}
+template <bool COUNT>
+SPC_DEV float rmis_weight_light_l(const KParams& p, int last_lastZone, float last_lum, int eye_label, Counts<COUNT>& cn) {
+    return gamma_ss(p, eye_label, last_lastZone, cn) * last_lum * (float)SPCBPT_CONNECTION_N;
+}
 // tracing_weight_light (rmis.h:58-79) with Last = light vertex `last`
 template <bool COUNT>
 SPC_DEV float rmis_weight_light(const KParams& p, const VCore& last, int last_lastZone, float last_lum, f3 mid_pos, Counts<COUNT>& cn) {
@@ -702,7 +752,12 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
     // ---- eye side terms shared by both connection kinds
     const float LL_pdf_A = rmis_last_pdf(mat_a, a.c, -connectDir);                 // getLL_pdf(light, eye)
     const f3 fm0 = rmis_flux_multiplier(mat_a, a.c, -connectDir, LA_DIR);           // getFluxMultiplier(eye, -connect_dir)
-    const float wA = rmis_weight_eye(p, a.c, a.depth, a.lastZone, bpos, cn);        // tracing_weight_eye(light, eye)
+    // the two relabels of the connection (light-tree label of the eye vertex seen from b, eye-tree label of the light vertex
+    // seen from a) in one lock-step descent; the first is skipped at depth 1, the second for an emitter vertex, as in rmis.h
+    int light_label, eye_label;
+    tree_label2(p.light_tree, a.c.pos, a.c.n, normalize(bpos - a.c.pos), a.depth != 1,
+                p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), b.depth != 0, light_label, eye_label, cn);
+    const float wA = rmis_weight_eye_l(p, a.depth, a.lastZone, light_label, cn);    // tracing_weight_eye(light, eye)
     const f3 D_A_0 = a.R3 * LL_pdf_A * fm0 + mk3(wA);
     const float weight = sum3(gamma_ss(p, a.sub, b.subspace_id, cn) * lflux * (float)SPCBPT_CONNECTION_N);
     const float pdf_B = rmis_get_pdf(mat_a, a.c, bpos, bn, LA_DIR);                 // getPdf(eye, light, LB)
@@ -723,7 +778,7 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
         const f3 fm1 = rmis_flux_multiplier(mat_b, bc, LB_DIR, connectDir);
         D_A = sum3(D_A_0 * pdf_A * fm1 * lflux / a.singlePdf);
         const float LL_pdf_B = rmis_last_pdf(mat_b, bc, connectDir);               // getLL_pdf(eye, light)
-        const float wB = rmis_weight_light(p, bc, b.last_zone_id, b.last_lum, a.c.pos, cn);
+        const float wB = rmis_weight_light_l(p, b.last_zone_id, b.last_lum, eye_label, cn);
         D_B = (b.rmis_pointer * LL_pdf_B + wB) * pdf_B / b.single_pdf;
     }
     const float w_rmis = weight / (weight + D_A + D_B);

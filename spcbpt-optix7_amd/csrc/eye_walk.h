@@ -36,7 +36,10 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
     mid.c.color = pbr.base;
     mid.c.lnp = fabsf(dot(last.c.n, ray_dir));
     mid.c.mat = g.mat;
-    mid.sub = tree_label(p.eye_tree, g.P, N, inv_dir, cn);
+    // eye-tree label of the new vertex and light-tree relabel of the previous one (tracing_weight_eye, depth >= 3) together
+    int light_label;
+    tree_label2(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, last.c.pos, last.c.n, normalize(g.P - last.c.pos),
+                last.depth + 1 != 1 && last.depth != 1, mid.sub, light_label, cn);
     mid.lastZone = last.sub;
     mid.depth = last.depth + 1;
     mid.singlePdf = w.next_single_pdf * pdf_G / fabsf(dot(last.c.n, ray_dir));
@@ -48,7 +51,7 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
         const Pbr mat_last = load_pbr_colored(S, last.c.mat, last.c.color);
         const f3 in_dir = normalize(mid.c.pos - last.c.pos);
         const float LL_pdf = rmis_last_pdf(mat_last, last.c, in_dir);
-        const float wgt = rmis_weight_eye(p, last.c, last.depth, last.lastZone, mid.c.pos, cn);
+        const float wgt = rmis_weight_eye_l(p, last.depth, last.lastZone, light_label, cn);
         const f3 fm = rmis_flux_multiplier(mat_last, last.c, in_dir, normalize(last.c.lastPos - last.c.pos));
         mid.R3 = (last.R3 * LL_pdf * fm + mk3(wgt)) / last.singlePdf;
     }

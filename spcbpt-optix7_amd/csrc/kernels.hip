@@ -496,7 +496,12 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                         m.last_position[0] = last.position[0]; m.last_position[1] = last.position[1]; m.last_position[2] = last.position[2];
                         m.last_normal_projection = fabsf(dot(last_n, dir));
                         m.material_id = (int16_t)g.mat;
-                        m.subspace_id = (int16_t)tree_label(p.light_tree, g.P, N, inv_dir, cn);
+                        // light-tree label of the new vertex and eye-tree relabel of the previous one (tracing_weight_light) in lock-step
+                        int new_label, eye_label;
+                        const f3 last_pos = ld3(last.position);
+                        tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
+                                    new_label, eye_label, cn);
+                        m.subspace_id = (int16_t)new_label;
                         m.last_zone_id = last.subspace_id;
                         m.depth = (int16_t)(last.depth + 1);
                         m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                             const Pbr mat_last = load_pbr_colored(S, lc.mat, lc.color);
                             const f3 in_dir = normalize(g.P - lc.pos);
                             const float LL_pdf = rmis_last_pdf(mat_last, lc, in_dir);
-                            const float wgt = rmis_weight_light(p, lc, last.last_zone_id, last.last_lum, g.P, cn);
+                            const float wgt = rmis_weight_light_l(p, last.last_zone_id, last.last_lum, eye_label, cn);
                             m.rmis_pointer = (last.rmis_pointer * LL_pdf + wgt) / last.single_pdf;
                         }
                         cn.add(C_VERTEX);

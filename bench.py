@@ -77,7 +77,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--light-paths", type=int, default=100_000)
-    ap.add_argument("--tuple", default="minimal", choices=["minimal", "trained"])
+    ap.add_argument("--tuple", default="trained", choices=["minimal", "trained"],
+                    help="trained (default): the reference's operating mode -- preprocessing() always runs before the first frame "
+                         "(optixPathTracer.cpp:763-766): pretrace, subspace trees of up to 1000 leaves, Q, Adam-trained Gamma; "
+                         "minimal: single-leaf trees, Gamma rows = Q (the cheapest valid tuple, no classification work)")
     ap.add_argument("--scene-route", default="gltf", choices=["gltf", "memory"],
                     help="gltf: write the generated scene as glTF 2.0 and read it back with the C++ reader (default); memory: hand the arrays over directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,13 +133,21 @@ def main():
     r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
     r.resize(args.width, args.height)
     M = args.light_paths
-    # the subspace tuple is computed with the full light pass on every rank (identical result), then the pass is sharded
+    # the subspace tuple is computed with the full light pass, then the pass is sharded.  N > 1: rank 0 trains and
+    # broadcasts (start-up, outside the timed region), so that every rank labels and weights with the same tuple
     r.set_light_trace(M, 52, 1)
-    if args.tuple == "trained":
-        r.preprocess(target_paths=2_000_000, target_q_paths=2_000_000, train=True)
-    else:
-        r.set_subspace()
-    tup = r.get_subspace()
+    t_pre = time.perf_counter()
+    if rank == 0 or dist is None:
+        if args.tuple == "trained":
+            r.preprocess(target_paths=2_000_000, target_q_paths=2_000_000, train=True)
+        else:
+            r.set_subspace()
+    tup = r.get_subspace() if (rank == 0 or dist is None) else None
+    if dist is not None:
+        tup = pkg.dist.broadcast_subspace(tup, 0, device)
+        if rank != 0:
+            r.set_subspace(*tup)
+    t_pre = time.perf_counter() - t_pre
     begin, count = pkg.dist.core_range(M, rank, world)
     r.set_light_trace(M, 52, 1, core_begin=begin, core_count=count)
     rows = pkg.dist.band_rows(args.height, rank, world)
@@ -227,7 +238,7 @@ def main():
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
-                       "frames_in_flight": streams, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

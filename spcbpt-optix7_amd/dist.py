@@ -6,6 +6,7 @@
                (path_id, depth) order, so every rank builds the identical sampler
   eye pass     rank r renders the 8-row bands b with b % N == r
   exchange 2   framebuffer sum over RCCL (bands a rank did not render are zero), only when an image is read out
+  start-up     the subspace tuple (trees, Q, CMF-Gamma) is trained on rank 0 and broadcast (SURVEY.md 8(e) "Preprocessing")
 
 PyTorch is plumbing here (device buffers for the collectives); the kernels run behind the C ABI.
 """
@@ -13,7 +14,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .api import LIGHT_VERTEX_DTYPE
+from .api import LIGHT_VERTEX_DTYPE, NUM_SUBSPACE, TREE_NODE_DTYPE
 
 VERTEX_BYTES = LIGHT_VERTEX_DTYPE.itemsize
 
@@ -71,6 +72,39 @@ def allreduce_image_host(img: np.ndarray, group=None) -> np.ndarray:
     t = torch.from_numpy(np.ascontiguousarray(img))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.numpy()
+
+
+def broadcast_subspace(tup, src: int = 0, device=None, group=None):
+    """One-off start-up exchange: the subspace tuple (eye tree, light tree, Q, CMF-Gamma) of rank `src` on every rank.
+    The tuple is the product of a training run (device reductions in no fixed order), so ranks that trained for themselves
+    would hold slightly different trees and matrices while exchanging light vertices labelled with them; training once and
+    broadcasting keeps the labels, Gamma and Q of all ranks identical.  `device` = the rank's GPU for RCCL, None for gloo."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.zeros(2, dtype=torch.int64, device=dev)
+    if rank == src:
+        et, lt, q, g = tup
+        et = np.ascontiguousarray(et, dtype=TREE_NODE_DTYPE)
+        lt = np.ascontiguousarray(lt, dtype=TREE_NODE_DTYPE)
+        n = torch.tensor([et.shape[0], lt.shape[0]], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src, group=group)
+    ne, nl = (int(v) for v in n.cpu().tolist())
+    sizes = [ne * TREE_NODE_DTYPE.itemsize, nl * TREE_NODE_DTYPE.itemsize, NUM_SUBSPACE * 4, NUM_SUBSPACE * NUM_SUBSPACE * 4]
+    if rank == src:
+        raw = np.concatenate([np.frombuffer(et.tobytes(), np.uint8), np.frombuffer(lt.tobytes(), np.uint8),
+                              np.frombuffer(np.ascontiguousarray(q, np.float32).tobytes(), np.uint8),
+                              np.frombuffer(np.ascontiguousarray(g, np.float32).tobytes(), np.uint8)])
+        buf = torch.from_numpy(raw.copy()).to(dev)
+    else:
+        buf = torch.zeros(sum(sizes), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src, group=group)
+    raw = buf.cpu().numpy().tobytes()
+    o0, o1, o2 = sizes[0], sizes[0] + sizes[1], sizes[0] + sizes[1] + sizes[2]
+    return (np.frombuffer(raw[:o0], dtype=TREE_NODE_DTYPE).copy(), np.frombuffer(raw[o0:o1], dtype=TREE_NODE_DTYPE).copy(),
+            np.frombuffer(raw[o1:o2], dtype=np.float32).copy(),
+            np.frombuffer(raw[o2:], dtype=np.float32).reshape(NUM_SUBSPACE, NUM_SUBSPACE).copy())
 
 
 class FrameExchanger:

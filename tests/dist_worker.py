@@ -28,6 +28,10 @@ def main():
     o.set_light_trace(M, 52, 1)
     tup = minimal_tuple(o, 1)
     o.set_subspace(*tup)
+    # start-up exchange: rank 0's tuple on every rank, bit for bit (the other ranks offer nothing)
+    got = pkg.dist.broadcast_subspace(tup if rank == 0 else None, 0)
+    assert all(a.tobytes() == np.ascontiguousarray(b).tobytes() for a, b in zip(got, tup)), "broadcast tuple differs"
+    assert got[0].dtype == pkg.api.TREE_NODE_DTYPE and got[3].shape == (1000, 1000)
     # single-process reference of the frame
     o.launch("light trace", 3)
     full_lvc = o.lvc_read()

@@ -43,7 +43,8 @@ typedef enum spcbpt_status {
     SPCBPT_ERR_HIP = -3,         /* a HIP call failed; see spcbpt_last_error */
     SPCBPT_ERR_UNKNOWN_ALG = -4, /* name is not one of the four launch names */
     SPCBPT_ERR_STATE = -5,       /* call order violated (e.g. SPCBPT_eye before a sampler exists) */
-    SPCBPT_ERR_CAPACITY = -6     /* a caller-provided buffer is too small */
+    SPCBPT_ERR_CAPACITY = -6,    /* a caller-provided buffer is too small */
+    SPCBPT_ERR_IO = -7           /* a file could not be read / written or is malformed */
 } spcbpt_status;
 
 /* Disney-principled material; field set of MaterialData::Pbr
@@ -356,6 +357,27 @@ int spcbpt_preprocess(spcbpt_ctx* ctx, int target_paths, int target_q_paths, int
 int spcbpt_preprocess_stage(spcbpt_ctx* ctx, int stage, int arg);
 /* Intermediate results for tests / checkpoints: Gamma before the CMF transform (row-major 1000x1000). */
 int spcbpt_get_gamma(spcbpt_ctx* ctx, float* gamma);
+
+/* Checkpoint files of the subspace tuple in the reference's own text formats (row f4): tree_eye.txt, tree_light.txt
+ * (classTree::tree_load, decisionTree/classTree_host.h:15-59), Q.txt (MyThrustOp::load_Q_file,
+ * cuda_thrust/device_thrust.cu:3389-3404) and E.txt = Gamma before the CMF transform (load_Gamma_file, 3347-3380).  The
+ * reference has only the readers, with their call sites commented out (optixPathTracer.cpp:573-581, 597, 603); the
+ * writers emit what those readers parse.  The first three need neither a context nor a GPU.
+ *   spcbpt_checkpoint_read: `gamma` (NUM_SUBSPACE^2) is in/out.  As in load_Gamma_file, the columns of the emitter
+ *   subspaces (light id >= NUM_SUBSPACE - NUM_SUBSPACE_LIGHTSOURCE) keep the caller's current values when
+ *   have_current_gamma != 0; with 0 every entry comes from the file.
+ *   spcbpt_gamma_to_cmf = MyThrustOp::Gamma2CMFGamma (3406-3433).
+ *   spcbpt_checkpoint_save writes the installed trees and Q plus the Gamma of the last preprocessing run (SPCBPT_ERR_STATE
+ *   if the context never preprocessed: a CMF Gamma handed to spcbpt_set_subspace cannot be inverted exactly).
+ *   spcbpt_checkpoint_load reads the four files, applies Gamma2CMFGamma and installs the tuple (spcbpt_set_subspace). */
+int spcbpt_checkpoint_write(const char* dir, const spcbpt_tree_node* eye_tree, int n_eye,
+                            const spcbpt_tree_node* light_tree, int n_light, const float* q, const float* gamma);
+int spcbpt_checkpoint_read(const char* dir, spcbpt_tree_node* eye_tree, int* n_eye, int cap_eye,
+                           spcbpt_tree_node* light_tree, int* n_light, int cap_light, float* q, float* gamma,
+                           int have_current_gamma);
+int spcbpt_gamma_to_cmf(const float* gamma, float* cmf_gamma);
+int spcbpt_checkpoint_save(spcbpt_ctx* ctx, const char* dir);
+int spcbpt_checkpoint_load(spcbpt_ctx* ctx, const char* dir);
 
 /* Read back the installed subspace tuple (checkpoint writer the reference lacks). */
 int spcbpt_get_subspace(spcbpt_ctx* ctx,

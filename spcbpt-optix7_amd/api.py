@@ -257,6 +257,44 @@ class SpcbptError(RuntimeError):
 _lib = None
 
 
+def checkpoint_write(directory: str, eye_tree, light_tree, q, gamma):
+    """Context-free writer of the reference's checkpoint files (spcbpt_checkpoint_write)."""
+    lib = load_library()
+    et = np.ascontiguousarray(eye_tree, dtype=TREE_NODE_DTYPE)
+    lt = np.ascontiguousarray(light_tree, dtype=TREE_NODE_DTYPE)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    g = np.ascontiguousarray(gamma, dtype=np.float32)
+    assert q.size == NUM_SUBSPACE and g.size == NUM_SUBSPACE * NUM_SUBSPACE
+    rc = lib.spcbpt_checkpoint_write(os.fsencode(directory), et.ctypes.data, et.shape[0], lt.ctypes.data, lt.shape[0], q.ctypes.data, g.ctypes.data)
+    if rc:
+        raise SpcbptError(f"checkpoint_write failed ({rc})")
+
+
+def checkpoint_read(directory: str, current_gamma=None, cap=1 << 20):
+    """Context-free reader (tree_load + load_Q_file + load_Gamma_file): returns (eye_tree, light_tree, Q, Gamma).  With
+    `current_gamma` the emitter-subspace columns keep its values, as load_Gamma_file does."""
+    lib = load_library()
+    et = np.zeros(cap, dtype=TREE_NODE_DTYPE)
+    lt = np.zeros(cap, dtype=TREE_NODE_DTYPE)
+    q = np.zeros(NUM_SUBSPACE, dtype=np.float32)
+    g = np.zeros(NUM_SUBSPACE * NUM_SUBSPACE, dtype=np.float32) if current_gamma is None else \
+        np.ascontiguousarray(current_gamma, dtype=np.float32).reshape(-1).copy()
+    ne, nl = C.c_int(), C.c_int()
+    rc = lib.spcbpt_checkpoint_read(os.fsencode(directory), et.ctypes.data, C.byref(ne), cap, lt.ctypes.data, C.byref(nl), cap,
+                                    q.ctypes.data, g.ctypes.data, 0 if current_gamma is None else 1)
+    if rc:
+        raise SpcbptError(f"checkpoint_read failed ({rc})")
+    return et[:ne.value].copy(), lt[:nl.value].copy(), q, g.reshape(NUM_SUBSPACE, NUM_SUBSPACE)
+
+
+def gamma_to_cmf(gamma):
+    lib = load_library()
+    g = np.ascontiguousarray(gamma, dtype=np.float32).reshape(-1)
+    out = np.zeros_like(g)
+    lib.spcbpt_gamma_to_cmf(g.ctypes.data, out.ctypes.data)
+    return out.reshape(NUM_SUBSPACE, NUM_SUBSPACE)
+
+
 def load_library(path: str = LIB_PATH):
     """Loads libspcbpt_hip.so.  Raises if it has not been built — there is no CPU fallback."""
     global _lib
@@ -311,6 +349,11 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_train_records_clear": [vp],
         "spcbpt_preprocess_stage": [vp, i32, i32],
         "spcbpt_get_gamma": [vp, vp],
+        "spcbpt_checkpoint_write": [C.c_char_p, vp, i32, vp, i32, vp, vp],
+        "spcbpt_checkpoint_read": [C.c_char_p, vp, C.POINTER(i32), i32, vp, C.POINTER(i32), i32, vp, vp, i32],
+        "spcbpt_gamma_to_cmf": [vp, vp],
+        "spcbpt_checkpoint_save": [vp, C.c_char_p],
+        "spcbpt_checkpoint_load": [vp, C.c_char_p],
         "spcbpt_gltf_load": [C.c_char_p, C.POINTER(vp), C.c_char_p, i32],
         "spcbpt_scene_file_load": [C.c_char_p, C.c_char_p, C.POINTER(vp)],
         "spcbpt_scene_file_desc": [vp, C.POINTER(SceneDesc)],
@@ -342,6 +385,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
     "spcbpt_get_gamma", "spcbpt_gltf_load", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
     "spcbpt_scene_file_warnings", "spcbpt_scene_file_free",
+    "spcbpt_checkpoint_write", "spcbpt_checkpoint_read", "spcbpt_gamma_to_cmf", "spcbpt_checkpoint_save", "spcbpt_checkpoint_load",
 ]
 
 
@@ -461,6 +505,13 @@ class Renderer:
 
     def train_records_clear(self):
         self._chk(self.lib.spcbpt_train_records_clear(self.h), "train_records_clear")
+
+    def checkpoint_save(self, directory: str):
+        """tree_eye.txt, tree_light.txt, Q.txt, E.txt in the reference's formats (needs a preprocessing run for Gamma)."""
+        self._chk(self.lib.spcbpt_checkpoint_save(self.h, os.fsencode(directory)), "checkpoint_save")
+
+    def checkpoint_load(self, directory: str):
+        self._chk(self.lib.spcbpt_checkpoint_load(self.h, os.fsencode(directory)), "checkpoint_load")
 
     def get_gamma(self):
         g = np.zeros((NUM_SUBSPACE, NUM_SUBSPACE), dtype=np.float32)

@@ -193,4 +193,32 @@ int spcbpt_get_gamma(spcbpt_ctx* c, float* gamma) {
     memcpy(gamma, c->pre->gamma.data(), c->pre->gamma.size() * sizeof(float));
     return SPCBPT_OK;
 }
+
+// Checkpoint files (checkpoint.cpp) on the context's tuple
+int spcbpt_checkpoint_save(spcbpt_ctx* c, const char* dir) {
+    if (!c || !dir) return SPCBPT_ERR_INVALID_ARG;
+    if (!c->have_subspace) { c->error = "checkpoint_save: no subspace tuple installed"; return SPCBPT_ERR_STATE; }
+    if (!c->pre || c->pre->gamma.empty()) { c->error = "checkpoint_save: no Gamma (the context never ran preprocessing stage 3+)"; return SPCBPT_ERR_STATE; }
+    const int rc = spcbpt_checkpoint_write(dir, c->h_eye_tree.data(), (int)c->h_eye_tree.size(), c->h_light_tree.data(),
+                                           (int)c->h_light_tree.size(), c->h_Q.data(), c->pre->gamma.data());
+    if (rc) c->error = std::string("checkpoint_save: cannot write the checkpoint files in ") + dir;
+    return rc;
+}
+int spcbpt_checkpoint_load(spcbpt_ctx* c, const char* dir) {
+    if (!c || !dir) return SPCBPT_ERR_INVALID_ARG;
+    const int cap = 1 << 20;
+    std::vector<spcbpt_tree_node> et(cap), lt(cap);
+    std::vector<float> q(SPCBPT_NUM_SUBSPACE), gamma((size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE, 0.0f), cmf(gamma.size());
+    const bool have = c->pre && !c->pre->gamma.empty();
+    if (have) gamma = c->pre->gamma;
+    int ne = 0, nl = 0;
+    int rc = spcbpt_checkpoint_read(dir, et.data(), &ne, cap, lt.data(), &nl, cap, q.data(), gamma.data(), have ? 1 : 0);
+    if (rc) { c->error = std::string("checkpoint_load: missing or malformed checkpoint files in ") + dir; return rc; }
+    spcbpt_gamma_to_cmf(gamma.data(), cmf.data());
+    rc = c->install_subspace(et.data(), ne, lt.data(), nl, q.data(), cmf.data());
+    if (rc) return rc;
+    if (!c->pre) c->pre = new Preprocessor();
+    c->pre->gamma = gamma;  // what spcbpt_get_gamma / the next save return
+    return SPCBPT_OK;
+}
 }

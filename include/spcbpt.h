@@ -379,6 +379,39 @@ int spcbpt_gamma_to_cmf(const float* gamma, float* cmf_gamma);
 int spcbpt_checkpoint_save(spcbpt_ctx* ctx, const char* dir);
 int spcbpt_checkpoint_load(spcbpt_ctx* ctx, const char* dir);
 
+/* Row f3 -- the interactive loop without a window: the state machine of optixPathTracer.cpp (GLFW callbacks 121-241,
+ * updateState / handleCameraUpdate / handleResize 333-379, initCameraState 661-670, one pass of the render loop 791-822)
+ * over sutil::Trackball and sutil::Camera.  A front end forwards its window events one to one (the arguments are GLFW's:
+ * button 0 left / 1 right, action 1 press / 2 repeat / 0 release, key codes ESCAPE 256, SPACE 32, C 67, P 80, W 87) and
+ * calls spcbpt_viewer_frame once per displayed subframe; tools/spcbpt_viewer.cpp replays an event script.  `ctx` may be
+ * null: the state machine then runs without launching (tests).  Left drag orbits the eye (LookAtFixed), right drag turns
+ * the view (EyeFixed), the wheel zooms, SPACE switches pt <-> SPCBPT_eye and restarts the accumulation, P restarts it on
+ * every frame, W walks forward by 0.5 / render_fps, ESCAPE sets should_close. */
+typedef struct spcbpt_viewer spcbpt_viewer;
+typedef struct spcbpt_viewer_state {
+    float eye[3], lookat[3], up[3];
+    float U[3], V[3], W[3];          /* Camera::UVWFrame at the current window aspect */
+    float fov_y, aspect;
+    int32_t width, height;
+    uint32_t subframe_index;         /* index the NEXT frame will render (0 after a camera / size / algorithm change) */
+    int32_t alg_id;                  /* 0 "pt", 1 "SPCBPT_eye" (render_alg, optixPathTracer.cpp:91) */
+    int32_t should_close, one_frame_render_only, camera_changed;
+    float render_fps;
+} spcbpt_viewer_state;
+int spcbpt_viewer_create(spcbpt_ctx* ctx, const float eye[3], const float lookat[3], const float up[3], float fov_y,
+                         int width, int height, spcbpt_viewer** out);
+void spcbpt_viewer_destroy(spcbpt_viewer* v);
+int spcbpt_viewer_mouse_button(spcbpt_viewer* v, int button, int action, double x, double y);
+int spcbpt_viewer_cursor_pos(spcbpt_viewer* v, double x, double y);
+int spcbpt_viewer_scroll(spcbpt_viewer* v, double xscroll, double yscroll);
+int spcbpt_viewer_window_size(spcbpt_viewer* v, int width, int height);
+int spcbpt_viewer_iconify(spcbpt_viewer* v, int iconified);
+int spcbpt_viewer_key(spcbpt_viewer* v, int key, int action);
+int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps);
+int spcbpt_viewer_frame(spcbpt_viewer* v);
+int spcbpt_viewer_get_state(spcbpt_viewer* v, spcbpt_viewer_state* state);
+const char* spcbpt_viewer_alg_name(int alg_id);
+
 /* Read back the installed subspace tuple (checkpoint writer the reference lacks). */
 int spcbpt_get_subspace(spcbpt_ctx* ctx,
                         spcbpt_tree_node* eye_tree, int* n_eye, int cap_eye,

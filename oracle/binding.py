@@ -61,6 +61,23 @@ def ref_lib():
     return r
 
 
+REF_VIEWER_LIB = os.path.join(_HERE, "_ref", "libref_viewer.so")
+
+
+def ref_viewer_replay(eye, lookat, up, fov_y, aspect, events):
+    """The reference's own sutil::Trackball + sutil::Camera driven by an event list (oracle/ref_viewer.cpp); None when
+    oracle/_ref has not been built (GPU box without the prebuilt files)."""
+    if not os.path.exists(REF_VIEWER_LIB):
+        return None
+    r = C.CDLL(REF_VIEWER_LIB)
+    ev = np.ascontiguousarray(events, np.float64)
+    out = np.zeros((ev.shape[0], 18), np.float32)
+    f = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(C.c_void_p)
+    r.ref_viewer_replay(f(eye), f(lookat), f(up), C.c_float(fov_y), C.c_float(aspect), C.c_void_p(ev.ctypes.data), ev.shape[0],
+                        C.c_void_p(out.ctypes.data))
+    return out
+
+
 class Oracle:
     """CPU restatement driven like the product Renderer."""
 

@@ -257,6 +257,98 @@ class SpcbptError(RuntimeError):
 _lib = None
 
 
+class ViewerState(C.Structure):  # spcbpt_viewer_state
+    _fields_ = [("eye", C.c_float * 3), ("lookat", C.c_float * 3), ("up", C.c_float * 3),
+                ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+                ("fov_y", C.c_float), ("aspect", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("subframe_index", C.c_uint32), ("alg_id", C.c_int32), ("should_close", C.c_int32),
+                ("one_frame_render_only", C.c_int32), ("camera_changed", C.c_int32), ("render_fps", C.c_float)]
+
+
+KEY = {"ESCAPE": 256, "SPACE": 32, "C": 67, "G": 71, "P": 80, "W": 87}   # GLFW key codes the reference's keyCallback tests
+BUTTON = {"left": 0, "right": 1, "middle": 2}
+
+
+class Viewer:
+    """Mirror of the spcbpt_viewer_* entry points (row f3): the reference application's event handling and render loop
+    without a window.  `renderer` may be None (state machine only, no GPU)."""
+
+    def __init__(self, renderer, eye, lookat, up, fov_y, width, height):
+        self.lib = load_library()
+        self.renderer = renderer
+        self.h = C.c_void_p()
+        rc = self.lib.spcbpt_viewer_create(renderer.h if renderer is not None else None, _fp(np.asarray(eye, np.float32)),
+                                           _fp(np.asarray(lookat, np.float32)), _fp(np.asarray(up, np.float32)),
+                                           C.c_float(fov_y), width, height, C.byref(self.h))
+        if rc:
+            raise SpcbptError(f"viewer_create failed ({rc})")
+
+    def close(self):
+        if self.h:
+            self.lib.spcbpt_viewer_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            msg = self.lib.spcbpt_last_error(self.renderer.h) if self.renderer is not None else None
+            raise SpcbptError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def mouse_button(self, button, action, x, y):
+        self._chk(self.lib.spcbpt_viewer_mouse_button(self.h, BUTTON.get(button, button), int(action), float(x), float(y)), "mouse_button")
+
+    def cursor_pos(self, x, y):
+        self._chk(self.lib.spcbpt_viewer_cursor_pos(self.h, float(x), float(y)), "cursor_pos")
+
+    def scroll(self, yscroll):
+        self._chk(self.lib.spcbpt_viewer_scroll(self.h, 0.0, float(yscroll)), "scroll")
+
+    def window_size(self, w, h):
+        self._chk(self.lib.spcbpt_viewer_window_size(self.h, int(w), int(h)), "window_size")
+
+    def iconify(self, on):
+        self._chk(self.lib.spcbpt_viewer_iconify(self.h, int(on)), "iconify")
+
+    def key(self, key, action=1):
+        self._chk(self.lib.spcbpt_viewer_key(self.h, KEY.get(key, key), int(action)), "key")
+
+    def set_fps(self, fps):
+        self._chk(self.lib.spcbpt_viewer_set_fps(self.h, C.c_float(fps)), "set_fps")
+
+    def frame(self):
+        self._chk(self.lib.spcbpt_viewer_frame(self.h), "viewer_frame")
+
+    def state(self):
+        s = ViewerState()
+        self._chk(self.lib.spcbpt_viewer_get_state(self.h, C.byref(s)), "get_state")
+        d = {k: (np.array(getattr(s, k), dtype=np.float32) if k in ("eye", "lookat", "up", "U", "V", "W") else getattr(s, k))
+             for k, _ in ViewerState._fields_}
+        d["alg"] = self.lib.spcbpt_viewer_alg_name(s.alg_id).decode()
+        return d
+
+    def replay(self, events):
+        """events as in oracle/ref_viewer.cpp: rows (type, a, b, c) with 0 press(button, x, y), 1 release(button),
+        2 cursor(x, y), 3 scroll(yscroll), 4 key W at render_fps a.  Returns the camera (eye, lookat, up, U, V, W) after each."""
+        out = np.zeros((len(events), 18), np.float32)
+        for i, (t, a, b, c) in enumerate(np.asarray(events, np.float64)):
+            t = int(t)
+            if t == 0: self.mouse_button(int(a), 1, b, c)
+            elif t == 1: self.mouse_button(int(a), 0, b, c)
+            elif t == 2: self.cursor_pos(b, c)
+            elif t == 3: self.scroll(a)
+            elif t == 4:
+                self.set_fps(a)
+                self.key("W", 1)
+            s = self.state()
+            out[i] = np.concatenate([s["eye"], s["lookat"], s["up"], s["U"], s["V"], s["W"]])
+        return out
+
+
 def checkpoint_write(directory: str, eye_tree, light_tree, q, gamma):
     """Context-free writer of the reference's checkpoint files (spcbpt_checkpoint_write)."""
     lib = load_library()
@@ -352,6 +444,16 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_checkpoint_write": [C.c_char_p, vp, i32, vp, i32, vp, vp],
         "spcbpt_checkpoint_read": [C.c_char_p, vp, C.POINTER(i32), i32, vp, C.POINTER(i32), i32, vp, vp, i32],
         "spcbpt_gamma_to_cmf": [vp, vp],
+        "spcbpt_viewer_create": [vp, f32p, f32p, f32p, C.c_float, i32, i32, C.POINTER(vp)],
+        "spcbpt_viewer_mouse_button": [vp, i32, i32, C.c_double, C.c_double],
+        "spcbpt_viewer_cursor_pos": [vp, C.c_double, C.c_double],
+        "spcbpt_viewer_scroll": [vp, C.c_double, C.c_double],
+        "spcbpt_viewer_window_size": [vp, i32, i32],
+        "spcbpt_viewer_iconify": [vp, i32],
+        "spcbpt_viewer_key": [vp, i32, i32],
+        "spcbpt_viewer_set_fps": [vp, C.c_float],
+        "spcbpt_viewer_frame": [vp],
+        "spcbpt_viewer_get_state": [vp, C.POINTER(ViewerState)],
         "spcbpt_checkpoint_save": [vp, C.c_char_p],
         "spcbpt_checkpoint_load": [vp, C.c_char_p],
         "spcbpt_gltf_load": [C.c_char_p, C.POINTER(vp), C.c_char_p, i32],
@@ -366,6 +468,10 @@ def load_library(path: str = LIB_PATH):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    lib.spcbpt_viewer_destroy.argtypes = [vp]
+    lib.spcbpt_viewer_destroy.restype = None
+    lib.spcbpt_viewer_alg_name.argtypes = [i32]
+    lib.spcbpt_viewer_alg_name.restype = C.c_char_p
     lib.spcbpt_last_error.argtypes = [vp]
     lib.spcbpt_last_error.restype = C.c_char_p
     lib.spcbpt_scene_file_warnings.argtypes = [vp]
@@ -385,6 +491,9 @@ EXPORTED_SYMBOLS = [
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
     "spcbpt_get_gamma", "spcbpt_gltf_load", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
     "spcbpt_scene_file_warnings", "spcbpt_scene_file_free",
+    "spcbpt_viewer_create", "spcbpt_viewer_destroy", "spcbpt_viewer_mouse_button", "spcbpt_viewer_cursor_pos", "spcbpt_viewer_scroll",
+    "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_frame",
+    "spcbpt_viewer_get_state", "spcbpt_viewer_alg_name",
     "spcbpt_checkpoint_write", "spcbpt_checkpoint_read", "spcbpt_gamma_to_cmf", "spcbpt_checkpoint_save", "spcbpt_checkpoint_load",
 ]
 

@@ -262,10 +262,28 @@ def oracle_regression():
                         vc=vc, pc=pc, q=tup[2], gamma_row=tup[3][0])
 
 
+def ref_viewer_vectors():
+    """ref_trackball.npz: camera after every event of the scripts in tests/viewer_scripts.py, from the reference's own
+    sutil/Trackball.cpp + sutil/Camera.cpp (oracle/ref_viewer.cpp -> oracle/_ref/libref_viewer.so)."""
+    from tests.viewer_scripts import scripts
+    data = {}
+    for k, s in enumerate(scripts()):
+        cam = ob.ref_viewer_replay(s["eye"], s["lookat"], s["up"], float(s["fov"]), float(s["aspect"]), s["events"])
+        assert cam is not None, "build oracle/_ref first: make -C oracle ref"
+        data[f"cam{k}"] = cam
+        data[f"events{k}"] = s["events"]
+    np.savez_compressed(os.path.join(HERE, "ref_trackball.npz"), **data)
+    print("ref_trackball.npz:", {k: v.shape for k, v in data.items()})
+
+
 if __name__ == "__main__":
-    ref_vectors()
-    ref_loaders()
-    ref_gltf()
-    survey_kat()
-    oracle_regression()
+    if "--viewer" in sys.argv:      # only the row-f3 vectors
+        ref_viewer_vectors()
+    else:
+        ref_vectors()
+        ref_loaders()
+        ref_gltf()
+        ref_viewer_vectors()
+        survey_kat()
+        oracle_regression()
     print("golden vectors written to", HERE)

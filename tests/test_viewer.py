@@ -1,0 +1,126 @@
+"""Row f3: the windowless viewer (csrc/viewer.cpp, spcbpt_viewer_*).  The camera / trackball arithmetic is pinned BIT-EXACTLY
+against the reference's own sutil/Trackball.cpp + sutil/Camera.cpp (tests/golden/ref_trackball.npz from oracle/_ref, and the
+library itself when it is present); the application glue (callbacks, updateState, render loop) is checked as a state
+machine on the CPU and end to end on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.viewer_scripts import scripts
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _viewer(pkg, s, renderer=None, w=1920, h=1000):
+    return pkg.api.Viewer(renderer, s["eye"], s["lookat"], s["up"], float(s["fov"]), w, h)
+
+
+def test_trackball_and_camera_match_reference_vectors_bit_exactly(hip_lib, pkg):
+    d = np.load(os.path.join(G, "ref_trackball.npz"))
+    for k, s in enumerate(scripts()):
+        assert np.array_equal(d[f"events{k}"], s["events"])
+        # U scales with the window aspect: give the viewer a window of exactly the script's aspect
+        w, h = {0: (1920, 1000), 1: (800, 800), 2: (1920, 1080), 3: (1024, 768)}[k]
+        assert np.float32(w) / np.float32(h) == s["aspect"]
+        got = _viewer(pkg, s, w=w, h=h).replay(s["events"])
+        want = d[f"cam{k}"]
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(axis=1))[0]
+        assert bad.size == 0, (k, bad[:5], got[bad[:1]], want[bad[:1]])
+
+
+def test_against_the_reference_library_when_present(hip_lib, pkg, ob):
+    s = scripts()[1]
+    ref = ob.ref_viewer_replay(s["eye"], s["lookat"], s["up"], float(s["fov"]), float(s["aspect"]), s["events"])
+    if ref is None:
+        pytest.skip("oracle/_ref not built here")
+    got = _viewer(pkg, s, w=800, h=800).replay(s["events"])
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_state_machine_without_a_context(hip_lib, pkg):
+    s = scripts()[0]
+    v = _viewer(pkg, s)
+    st = v.state()
+    assert st["alg"] == "SPCBPT_eye" and st["subframe_index"] == 0 and st["camera_changed"] == 1 and st["render_fps"] == 60.0
+    for k in range(3):
+        v.frame()
+    assert v.state()["subframe_index"] == 3 and v.state()["camera_changed"] == 0
+    # a drag restarts the accumulation at the next frame, and only once
+    v.mouse_button("left", 1, 10, 10); v.cursor_pos(30, 18); v.mouse_button("left", 0, 30, 18)
+    assert v.state()["camera_changed"] == 1 and v.state()["subframe_index"] == 3
+    v.frame()
+    assert v.state()["subframe_index"] == 1
+    v.frame()
+    assert v.state()["subframe_index"] == 2
+    # a cursor move without a button, or with the middle button, is not a camera change
+    before = v.state()
+    v.cursor_pos(300, 300); v.mouse_button("middle", 1, 300, 300); v.cursor_pos(350, 320); v.mouse_button("middle", 0, 350, 320)
+    after = v.state()
+    assert after["camera_changed"] == 0 and np.array_equal(before["eye"], after["eye"])
+    # SPACE cycles pt <-> SPCBPT_eye and restarts; P restarts on every frame until pressed again
+    v.key("SPACE"); assert v.state()["alg"] == "pt"
+    v.frame(); assert v.state()["subframe_index"] == 1
+    v.key("SPACE"); assert v.state()["alg"] == "SPCBPT_eye"
+    v.frame(); v.frame()
+    v.key("P"); v.frame(); v.frame()
+    assert v.state()["one_frame_render_only"] == 1 and v.state()["subframe_index"] == 1
+    v.key("P"); v.frame()
+    assert v.state()["subframe_index"] == 2
+    # key release / repeat only matter for W (outside the PRESS test in the reference)
+    v.key("SPACE", 0); assert v.state()["alg"] == "SPCBPT_eye"
+    e0 = v.state()["eye"].copy()
+    v.set_fps(50.0); v.key("W", 2); v.key("W", 0)
+    st = v.state()
+    d = st["lookat"] - st["eye"]
+    assert np.allclose(st["eye"] - e0, 2 * 0.5 / 50.0 * d / np.linalg.norm(d), atol=1e-6) and st["camera_changed"] == 1
+    # resize: clamped to >= 1, ignored while minimised, changes the aspect of U
+    v.window_size(800, 0); assert (v.state()["width"], v.state()["height"]) == (800, 1)
+    v.iconify(1); v.window_size(640, 480); assert v.state()["width"] == 800
+    v.iconify(0); v.window_size(640, 480)
+    st = v.state()
+    assert (st["width"], st["height"]) == (640, 480) and abs(np.linalg.norm(st["U"]) / np.linalg.norm(st["V"]) - 640 / 480) < 1e-6
+    # wheel: zoom in divides the eye-lookat distance by 1.1
+    d0 = np.linalg.norm(st["eye"] - st["lookat"])
+    v.scroll(1)
+    st = v.state()
+    assert abs(np.linalg.norm(st["eye"] - st["lookat"]) * 1.1 - d0) < 1e-5
+    v.key("ESCAPE"); assert v.state()["should_close"] == 1
+    assert hip_lib.spcbpt_viewer_frame(None) == -1 and hip_lib.spcbpt_viewer_key(None, 32, 1) == -1
+
+
+@pytest.mark.gpu
+def test_viewer_loop_renders_what_the_plain_loop_renders(gpu, pkg):
+    """The viewer's frames are the render loop of optixPathTracer.cpp:791-822: the image after a drag + N frames equals N
+    subframes rendered by hand with the camera the drag produced; switching the algorithm restarts the accumulation."""
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    W = H = 96
+
+    def make():
+        r = pkg.Renderer(scene, 0)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+        r.resize(W, H)
+        r.set_light_trace(3000, 64, 1)
+        r.set_subspace()
+        return r
+
+    a = make()
+    v = pkg.api.Viewer(a, cam["eye"], cam["lookat"], cam["up"], cam["fov"], W, H)
+    v.frame(); v.frame()
+    v.mouse_button("left", 1, 40, 40); v.cursor_pos(65, 52); v.mouse_button("left", 0, 65, 52)
+    v.scroll(1)
+    for _ in range(3):
+        v.frame()
+    st = v.state()
+    assert st["subframe_index"] == 3 and st["alg"] == "SPCBPT_eye"
+    img_v = a.read_accum().copy()
+    b = make()
+    b.set_camera(st["eye"], st["U"], st["V"], st["W"])
+    for f in range(3):
+        b.render_frame("SPCBPT_eye", f, launch_frame=3 + f)   # the viewer's light pass counter kept running: frames 3, 4, 5
+    b.sync()
+    assert np.array_equal(img_v, b.read_accum())
+    v.key("SPACE"); v.frame()
+    b.clear_accum(); b.render_frame("pt", 0); b.sync()
+    assert v.state()["alg"] == "pt" and np.array_equal(a.read_accum(), b.read_accum())

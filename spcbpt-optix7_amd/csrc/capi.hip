@@ -99,20 +99,38 @@ int Context::ensure_spill(size_t threads, bool render) {
     return 0;
 }
 
+// Device layout of a classifier tree (layout.h): 16-B nodes, the eight children of a node in eight consecutive slots.  The
+// caller's tree (classTree::tree_node: arbitrary child indices) is re-laid out breadth-first from the root; a child index
+// that occurs twice is duplicated, so any input that classifies in finitely many steps keeps its labels.
 int Context::upload_tree(const spcbpt_tree_node* t, int n, float*& d_tree, std::vector<spcbpt_tree_node>& host_copy) {
-    host_copy.assign(t, t + n);
-    std::vector<float> packed((size_t)n * 12);
     for (int i = 0; i < n; i++) {
-        float* q = &packed[(size_t)i * 12];
-        q[0] = t[i].mid[0]; q[1] = t[i].mid[1]; q[2] = t[i].mid[2];
-        uint32_t meta = ((uint32_t)t[i].type & 3u) | (t[i].leaf ? 4u : 0u) | ((uint32_t)t[i].label << 3);
-        memcpy(q + 3, &meta, 4);
-        for (int k = 0; k < 8; k++) {
-            int c = t[i].child[k];
-            if (!t[i].leaf && (c < 0 || c >= n)) { error = "tree child index out of range"; return SPCBPT_ERR_INVALID_ARG; }
-            memcpy(q + 4 + k, &c, 4);
+        if (t[i].leaf) {
+            if (t[i].label < 0 || t[i].label >= SPCBPT_NUM_SUBSPACE) { error = "tree label out of range"; return SPCBPT_ERR_INVALID_ARG; }
+        } else {
+            if (t[i].type < 0 || t[i].type > 2) { error = "tree node type out of range"; return SPCBPT_ERR_INVALID_ARG; }
+            for (int k = 0; k < 8; k++)
+                if (t[i].child[k] < 0 || t[i].child[k] >= n) { error = "tree child index out of range"; return SPCBPT_ERR_INVALID_ARG; }
         }
-        if (t[i].leaf && (t[i].label < 0 || t[i].label >= SPCBPT_NUM_SUBSPACE)) { error = "tree label out of range"; return SPCBPT_ERR_INVALID_ARG; }
+    }
+    host_copy.assign(t, t + n);
+    const size_t budget = (size_t)16 * n + 64;      // a tree proper needs exactly n slots; sharing / cycles hit the budget
+    std::vector<float> packed(4);
+    std::vector<int> src(1, 0);                     // slot -> caller's node
+    for (size_t slot = 0; slot < src.size(); slot++) {
+        const spcbpt_tree_node& nd = t[src[slot]];
+        uint32_t meta;
+        if (nd.leaf) {
+            meta = TREE_LEAF_BIT | (uint32_t)nd.label;
+        } else {
+            const size_t base = src.size();
+            if (base + 8 > budget || base + 8 >= (1u << 29)) { error = "tree is not a finite tree (shared or cyclic children)"; return SPCBPT_ERR_INVALID_ARG; }
+            meta = ((uint32_t)nd.type << 29) | (uint32_t)base;
+            for (int k = 0; k < 8; k++) src.push_back(nd.child[k]);
+            packed.resize(src.size() * 4);
+        }
+        float* q = &packed[slot * 4];
+        q[0] = nd.mid[0]; q[1] = nd.mid[1]; q[2] = nd.mid[2];
+        memcpy(q + 3, &meta, 4);
     }
     dev_free(d_tree);
     HIP_TRY(this, dev_alloc(&d_tree, packed.size()));

@@ -566,24 +566,19 @@ SPC_DEV int tree_label(const float* tree, f3 position, f3 normal, f3 dir, Counts
     if (!tree) return 0;
     int node = 0;
     while (true) {
-        // the whole 48-B node in one round trip (the child index used to be a second, dependent load per level)
-        const float4 q0 = ldq(tree, (size_t)node * TREE_QUADS), q1 = ldq(tree, (size_t)node * TREE_QUADS + 1),
-                     q2 = ldq(tree, (size_t)node * TREE_QUADS + 2);
+        const float4 q = ldq(tree, (size_t)node);  // the whole 16-B node in one round trip (layout.h)
         cn.add(C_TREE);
-        const uint32_t meta = __float_as_uint(q0.w);
-        if (meta & 4u) return (int)(meta >> 3);
-        const uint32_t type = meta & 3u;
+        const uint32_t meta = __float_as_uint(q.w);
+        if (meta & TREE_LEAF_BIT) return (int)(meta & ~TREE_LEAF_BIT);
+        const uint32_t type = (meta >> 29) & 3u;
         const f3 p = type == 0 ? position : (type == 1 ? normal : dir);
-        const bool bx = p.x > q0.x, by = p.y > q0.y, bz = p.z > q0.z;
-        const float4 qz = bz ? q2 : q1;                                   // children 4..7 : 0..3
-        const float c0 = by ? qz.z : qz.x, c1 = by ? qz.w : qz.y;          // +2
-        node = __float_as_int(bx ? c1 : c0);                              // +1
+        node = (int)(meta & 0x1fffffffu) + (p.x > q.x ? 1 : 0) + (p.y > q.y ? 2 : 0) + (p.z > q.z ? 4 : 0);
     }
 }
 
-// Two independent classifications descended in lock-step: a descent is a chain of dependent 48-B fetches (one per level, up
-// to 15 levels), and the callers below always need two of them (eye-tree label of a new vertex + light-tree label for its
-// RMIS recursion; the two relabels of a connection).  Interleaving halves the exposed latency; the labels are the same.
+// Two independent classifications descended in lock-step: a descent is a chain of dependent fetches (one per level, up to 15
+// levels), and the callers below always need two of them (eye-tree label of a new vertex + light-tree label for its RMIS
+// recursion; the two relabels of a connection).  Interleaving halves the exposed latency; the labels are the same.
 template <bool COUNT>
 SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA, const float* treeB, f3 posB, f3 nB, f3 dirB, bool needB,
                          int& labelA, int& labelB, Counts<COUNT>& cn) {
@@ -591,31 +586,25 @@ SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA
     bool goA = needA && treeA != nullptr, goB = needB && treeB != nullptr;
     labelA = 0; labelB = 0;
     while (goA || goB) {
-        float4 a0, a1, a2, b0, b1, b2;
-        if (goA) { a0 = ldq(treeA, (size_t)nodeA * TREE_QUADS); a1 = ldq(treeA, (size_t)nodeA * TREE_QUADS + 1); a2 = ldq(treeA, (size_t)nodeA * TREE_QUADS + 2); cn.add(C_TREE); }
-        if (goB) { b0 = ldq(treeB, (size_t)nodeB * TREE_QUADS); b1 = ldq(treeB, (size_t)nodeB * TREE_QUADS + 1); b2 = ldq(treeB, (size_t)nodeB * TREE_QUADS + 2); cn.add(C_TREE); }
+        float4 a, b;
+        if (goA) { a = ldq(treeA, (size_t)nodeA); cn.add(C_TREE); }
+        if (goB) { b = ldq(treeB, (size_t)nodeB); cn.add(C_TREE); }
         if (goA) {
-            const uint32_t meta = __float_as_uint(a0.w);
-            if (meta & 4u) { labelA = (int)(meta >> 3); goA = false; }
+            const uint32_t meta = __float_as_uint(a.w);
+            if (meta & TREE_LEAF_BIT) { labelA = (int)(meta & ~TREE_LEAF_BIT); goA = false; }
             else {
-                const uint32_t type = meta & 3u;
+                const uint32_t type = (meta >> 29) & 3u;
                 const f3 p = type == 0 ? posA : (type == 1 ? nA : dirA);
-                const bool bx = p.x > a0.x, by = p.y > a0.y, bz = p.z > a0.z;
-                const float4 qz = bz ? a2 : a1;
-                const float c0 = by ? qz.z : qz.x, c1 = by ? qz.w : qz.y;
-                nodeA = __float_as_int(bx ? c1 : c0);
+                nodeA = (int)(meta & 0x1fffffffu) + (p.x > a.x ? 1 : 0) + (p.y > a.y ? 2 : 0) + (p.z > a.z ? 4 : 0);
             }
         }
         if (goB) {
-            const uint32_t meta = __float_as_uint(b0.w);
-            if (meta & 4u) { labelB = (int)(meta >> 3); goB = false; }
+            const uint32_t meta = __float_as_uint(b.w);
+            if (meta & TREE_LEAF_BIT) { labelB = (int)(meta & ~TREE_LEAF_BIT); goB = false; }
             else {
-                const uint32_t type = meta & 3u;
+                const uint32_t type = (meta >> 29) & 3u;
                 const f3 p = type == 0 ? posB : (type == 1 ? nB : dirB);
-                const bool bx = p.x > b0.x, by = p.y > b0.y, bz = p.z > b0.z;
-                const float4 qz = bz ? b2 : b1;
-                const float c0 = by ? qz.z : qz.x, c1 = by ? qz.w : qz.y;
-                nodeB = __float_as_int(bx ? c1 : c0);
+                nodeB = (int)(meta & 0x1fffffffu) + (p.x > b.x ? 1 : 0) + (p.y > b.y ? 2 : 0) + (p.z > b.z ? 4 : 0);
             }
         }
     }

@@ -55,9 +55,13 @@ struct DTexture {
     int32_t width, height;
 };
 
-// Subspace-tree node, 48 B = 3 x float4:
-//   q0 = (mid.xyz, as_float(type | leaf << 2 | label << 3))  q1 = child[0..3]  q2 = child[4..7]
-static const int TREE_QUADS = 3;
+// Subspace-tree node, 16 B = 1 x float4: (mid.xyz, meta).  A leaf has meta = TREE_LEAF_BIT | label; an internal node has
+// meta = type << 29 | first child, its eight children sitting in eight consecutive slots (child = first + octant,
+// octant = [p.x > mid.x] + 2 [p.y > mid.y] + 4 [p.z > mid.z] as in classTree::tree_index).  One quad per level instead of the
+// 56-B reference node (three quads): a trained pair of trees is 2.8 MB instead of 8.4 MB, which is the difference between
+// living in the 4 MB L2 of an XCD next to the BVH top and missing it (measured: half of the tree fetches missed L2).
+static const int TREE_QUADS = 1;
+static const uint32_t TREE_LEAF_BIT = 0x80000000u;
 
 typedef spcbpt_light_vertex LightVertex;  // 96 B = 6 x float4, AoS because it is fetched by random gather
 static_assert(sizeof(LightVertex) == 96, "LightVertex");

@@ -23,6 +23,7 @@
 #ifndef SPCBPT_H
 #define SPCBPT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -378,6 +379,11 @@ int spcbpt_checkpoint_read(const char* dir, spcbpt_tree_node* eye_tree, int* n_e
 int spcbpt_gamma_to_cmf(const float* gamma, float* cmf_gamma);
 int spcbpt_checkpoint_save(spcbpt_ctx* ctx, const char* dir);
 int spcbpt_checkpoint_load(spcbpt_ctx* ctx, const char* dir);
+
+/* Texture file -> RGBA8 as the reference's stbi_load(path, &w, &h, &c, STBI_rgb_alpha) delivers it
+ * (OptiXPathTracer/scene_shift.cpp:35-40): baseline / progressive JPEG, PNG, binary PPM, chosen by content.  Two-call
+ * protocol: rgba == NULL returns the size only.  The scene loaders use the same decoder.  Needs no context, no GPU. */
+int spcbpt_image_load(const char* path, int* width, int* height, uint8_t* rgba, size_t capacity_bytes);
 
 /* Row f3 -- the interactive loop without a window: the state machine of optixPathTracer.cpp (GLFW callbacks 121-241,
  * updateState / handleCameraUpdate / handleResize 333-379, initCameraState 661-670, one pass of the render loop 791-822)

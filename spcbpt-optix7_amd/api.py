@@ -349,6 +349,20 @@ class Viewer:
         return out
 
 
+def image_load(path: str):
+    """RGBA8 image (h, w, 4) of a JPEG / PNG / binary PPM file, decoded as the reference's stbi_load(..., STBI_rgb_alpha)."""
+    lib = load_library()
+    w, h = C.c_int(), C.c_int()
+    rc = lib.spcbpt_image_load(os.fsencode(path), C.byref(w), C.byref(h), None, 0)
+    if rc:
+        raise SpcbptError(f"image_load({path}) failed ({rc})")
+    px = np.zeros((h.value, w.value, 4), np.uint8)
+    rc = lib.spcbpt_image_load(os.fsencode(path), C.byref(w), C.byref(h), px.ctypes.data, px.nbytes)
+    if rc:
+        raise SpcbptError(f"image_load({path}) failed ({rc})")
+    return px
+
+
 def checkpoint_write(directory: str, eye_tree, light_tree, q, gamma):
     """Context-free writer of the reference's checkpoint files (spcbpt_checkpoint_write)."""
     lib = load_library()
@@ -454,6 +468,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_viewer_set_fps": [vp, C.c_float],
         "spcbpt_viewer_frame": [vp],
         "spcbpt_viewer_get_state": [vp, C.POINTER(ViewerState)],
+        "spcbpt_image_load": [C.c_char_p, C.POINTER(i32), C.POINTER(i32), vp, C.c_size_t],
         "spcbpt_checkpoint_save": [vp, C.c_char_p],
         "spcbpt_checkpoint_load": [vp, C.c_char_p],
         "spcbpt_gltf_load": [C.c_char_p, C.POINTER(vp), C.c_char_p, i32],
@@ -494,7 +509,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_viewer_create", "spcbpt_viewer_destroy", "spcbpt_viewer_mouse_button", "spcbpt_viewer_cursor_pos", "spcbpt_viewer_scroll",
     "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_frame",
     "spcbpt_viewer_get_state", "spcbpt_viewer_alg_name",
-    "spcbpt_checkpoint_write", "spcbpt_checkpoint_read", "spcbpt_gamma_to_cmf", "spcbpt_checkpoint_save", "spcbpt_checkpoint_load",
+    "spcbpt_image_load", "spcbpt_checkpoint_write", "spcbpt_checkpoint_read", "spcbpt_gamma_to_cmf", "spcbpt_checkpoint_save", "spcbpt_checkpoint_load",
 ]
 
 

@@ -257,7 +257,7 @@ struct Gltf {
         bool ok = false;
         const std::string uri = im ? im->str("uri") : std::string();
         if (!uri.empty() && uri.compare(0, 5, "data:") != 0) {
-            ok = spc_loader::load_ppm(dir + uri, rgba, w, h);
+            ok = spc_loader::load_image(dir + uri, rgba, w, h);
             if (!ok) out->warnings += "image " + uri + " is not a readable binary PPM (PNG/JPEG are not decoded); ";
         } else {
             out->warnings += "embedded images are not decoded; ";

@@ -6,8 +6,8 @@
 //                (q17), the k-th mesh block uses the k-th pushed material, OBJ normals are discarded, missing UVs are zero
 // OBJ reading has the semantics of the reference's vendored old-API tinyobj and PPM decoding those of its stb_image; both are
 // pinned bit-exactly against those loaders (oracle/_ref, tests/golden/ref_loaders.npz, tests/test_scene_file.py).
-// Textures: binary PPM (P6) only — the reference decodes JPEG/PNG through stb_image, which is not rebuilt here; other formats
-// are reported in the warnings string and the material renders with its flat colour.
+// Textures: JPEG, PNG and binary PPM (image_file.cpp, held bit-exactly to the reference's stb_image); a file that cannot be
+// decoded is reported in the warnings string and the material renders with its flat colour.
 // The `.scene` grammar itself is PARITY UNPINNED: sceneLoader.cpp needs the CMake-generated sampleConfig.h (via sutil.h).
 #include <cmath>
 #include <cstdio>
@@ -50,7 +50,7 @@ bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& 
 }  // namespace spc_loader
 
 namespace {
-using spc_loader::load_ppm;
+using spc_loader::load_image;
 
 const int kMaxLine = 2048;
 
@@ -311,7 +311,7 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
                 std::vector<uint8_t> px;
                 int w = 0, h = 0;
                 const std::string tp = root + "/" + fix_slashes(p.tex);
-                if (load_ppm(tp, px, w, h)) {
+                if (load_image(tp, px, w, h)) {
                     s->tex_pixels.push_back(std::move(px));
                     spcbpt_texture t;
                     t.rgba = nullptr; t.width = w; t.height = h;
@@ -320,7 +320,7 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
                     m.albedo_tex = (int)s->textures.size();
                 } else {
                     texture_ids[p.tex] = 0;
-                    s->warnings += "texture " + p.tex + " not loaded (only binary PPM is decoded here); ";
+                    s->warnings += "texture " + p.tex + " not loaded (missing, or not a JPEG / PNG / binary PPM this reader decodes); ";
                 }
             }
         }

@@ -25,4 +25,7 @@ struct spcbpt_scene_file {
 namespace spc_loader {
 // binary PPM (P6, maxval 255) -> RGBA8, pinned against the reference's stb_image (tests/test_scene_file.py)
 bool load_ppm(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h);
+// JPEG / PNG / binary PPM by content -> RGBA8, what stbi_load(..., STBI_rgb_alpha) returns (image_file.cpp; pinned bit-exactly
+// against the reference's stb_image, tests/test_image_file.py)
+bool load_image(const std::string& path, std::vector<uint8_t>& rgba, int& w, int& h);
 }

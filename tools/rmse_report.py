@@ -1,8 +1,11 @@
-"""Equal-spp RMSE (second half of the BASELINE metric).  RMSE on the linear accum buffer of "pt", "SPCBPT_eye" with the
+"""Equal-spp and equal-time RMSE (second half of the BASELINE metric).  RMSE on the linear accum buffer of "pt", "SPCBPT_eye" with the
 minimal tuple and "SPCBPT_eye" with the trained tuple at N spp, against a reference of 32 N spp (16 N of "pt" + 16 N of
 "SPCBPT_eye", trained) whose subframe indices are disjoint from the images under test, so no samples are shared.
 Each frame is launched on a cleared accum buffer at subframe index s (the kernel then leaves new/(s+1) in it) and summed
 on the device in fp32 chunks / fp64 totals, which gives a plain mean for any set of indices.
+Equal time: every algorithm's frame time is measured in the pipelined loop bench.py uses (no sync between frames), "pt" is then
+rendered AGAIN with the number of samples it can afford in the time N samples of the trained SPCBPT take, and its RMSE is
+reported next to the value derived from the equal-spp one (MSE ~ 1 / spp).
   python tools/rmse_report.py <tag> [cornell|bedroom|hallway] [W H spp]   ->  profiles/<tag>_rmse_<scene>.json"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,15 +35,29 @@ def mean_image(alg, first, n):
         torch.cuda.synchronize()
     return (tot / n).cpu().numpy()
 
+def frame_ms(alg, frames=24):
+    for s in range(3):
+        r.render_frame(alg, s, launch_frame=s + 1)
+    r.sync(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for s in range(frames):
+        r.render_frame(alg, s, launch_frame=s + 1)
+    r.sync(); torch.cuda.synchronize()
+    return (time.perf_counter() - t) / frames * 1e3
+
 out = {"tag": tag, "scene": name, "width": W, "height": H, "spp": N, "ref_spp": 32 * N}
 t0 = time.time()
 r.set_subspace()                                   # minimal tuple
 pt = mean_image("pt", 0, N)
 sp_min = mean_image("SPCBPT_eye", 0, N)
+ms_pt, ms_min = frame_ms("pt"), frame_ms("SPCBPT_eye")
 pt_ref = mean_image("pt", 4 * N, 16 * N)
 tp = 400_000 if name == "cornell" else 2_000_000
 t1 = time.time(); r.preprocess(tp, tp, True); out["preprocess_seconds"] = time.time() - t1
 sp_tr = mean_image("SPCBPT_eye", 0, N)
+ms_tr = frame_ms("SPCBPT_eye")
+n_eq = max(1, min(4 * N - 1, int(round(N * ms_tr / ms_pt))))   # samples "pt" affords in the time of N trained-SPCBPT samples
+pt_eq = mean_image("pt", 0, n_eq)
 sp_ref = mean_image("SPCBPT_eye", 32 * N, 16 * N)
 ref = 0.5 * (pt_ref + sp_ref)
 rm = lambda a: float(np.sqrt(((a - ref) ** 2).mean()))
@@ -50,6 +67,13 @@ out.update(rmse_pt=rm(pt), rmse_spcbpt_minimal=rm(sp_min), rmse_spcbpt_trained=r
            mean_pt_ref=float(pt_ref.mean()), mean_spcbpt_ref=float(sp_ref.mean()),
            ref_disagreement_rmse=float(np.sqrt(((pt_ref - sp_ref) ** 2).mean())), seconds=time.time() - t0)
 out["variance_ratio_pt_over_trained"] = (out["rmse_pt"] / out["rmse_spcbpt_trained"]) ** 2
+out["ms_per_frame"] = {"pt": ms_pt, "spcbpt_minimal": ms_min, "spcbpt_trained": ms_tr}
+out["equal_time"] = {"budget_ms": N * ms_tr, "spp": {"pt": n_eq, "spcbpt_trained": N},
+                     "rmse_pt_measured": rm(pt_eq), "relmse_pt_measured": rel(pt_eq),
+                     "rmse_pt_derived": out["rmse_pt"] * (ms_pt / ms_tr) ** 0.5,
+                     "rmse_spcbpt_minimal_derived": out["rmse_spcbpt_minimal"] * (ms_min / ms_tr) ** 0.5,
+                     "rmse_spcbpt_trained": out["rmse_spcbpt_trained"], "relmse_spcbpt_trained": out["relmse_spcbpt_trained"]}
+out["equal_time"]["variance_ratio_pt_over_trained"] = (out["equal_time"]["rmse_pt_measured"] / out["rmse_spcbpt_trained"]) ** 2
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rmse_{name}.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

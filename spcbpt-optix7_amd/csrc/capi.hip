@@ -333,7 +333,11 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         kp.n_tiles = (uint32_t)render_tile_count(kp);
         kp.work_counter = d_work_counter + rk;
         HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
-        if (!blocks_per_cu[counting]) blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
+        if (!blocks_per_cu[counting]) {
+            blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
+            // developer knob (occupancy experiments): fewer resident blocks per CU than the kernel's resources allow
+            if (const char* e = getenv("SPCBPT_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < blocks_per_cu[counting]) blocks_per_cu[counting] = v; }
+        }
     }
     time_begin(name, rstream);
     if (spcbpt_alg) launch_spcbpt(kp, counting, num_cus * blocks_per_cu[counting], rstream);
@@ -746,7 +750,11 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
         HIP_TRY(c, hipMemcpyAsync(c->d_lvc, verts, (size_t)count * sizeof(LightVertex), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     int h[2] = {count, 0};
     HIP_TRY(c, hipMemcpyAsync(c->d_sampler_counts, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    // only the light stream: the copies above must be done before the caller reuses `verts` (and before `h` goes out of
+    // scope).  The render streams are NOT waited for -- the buffer set written here is not the one an eye kernel in flight
+    // reads (launch_light / ensure_lvc_capacity order that), and a device-wide wait here would serialise every frame of a
+    // multi-GPU job with the previous frame's eye kernel.
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->lvc_count = count;
     c->keys_ready = false;
     c->have_sampler = false;

@@ -32,9 +32,9 @@ struct Context {
     // Consecutive render launches alternate between two streams, each with its own work counter, spill area and `result`
     // buffer: frame f+1's eye kernel starts filling the machine while frame f's drains.  Only the film merges (running mean +
     // tone map from `result` into accum/frame) are chained, by ev_merge, so the image is the same as with one stream.
-    // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..4).  More frames in flight pay when one frame does not
+    // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..8).  More frames in flight pay when one frame does not
     // fill the GPU -- a rank of an 8-GPU job renders 1/8 of the image but its frame still ends with the same 50-bounce chain.
-    static const int kMaxRender = 4, kMaxSets = kMaxRender + 1;
+    static const int kMaxRender = 8, kMaxSets = kMaxRender + 1;
     int n_render = 2, n_sets = 3;   // n_sets = n_render + 1: one set per eye kernel in flight + the one the light pass writes
     hipStream_t rstreams[kMaxRender] = {};
     int rk = 0, last_merge_k = -1;

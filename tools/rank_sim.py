@@ -1,9 +1,15 @@
-"""What one rank of an N-GPU job does per frame, on one GPU and without the exchange: 1/N of the light cores, every N-th 8-row
-band.  Shows how the step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS)."""
+"""What one rank of an N-GPU job does per frame, on one GPU: 1/N of the light cores, every N-th 8-row band.  Shows how the
+step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS).
+  python tools/rank_sim.py N streams [steps] [--exchange] [--trained]
+--exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
+all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
+rate when its share of the image is small."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-N = int(sys.argv[1]); streams = int(sys.argv[2]); steps = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]); streams = int(args[1]); steps = int(args[2]) if len(args) > 2 else 32
+exchange, trained = "--exchange" in sys.argv, "--trained" in sys.argv
 os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)
 import __graft_entry__ as g
 p = g.load_package()
@@ -14,15 +20,28 @@ c = scene.camera
 r.set_camera_lookat(c["eye"], c["lookat"], c["up"], c["fov"], W / H)
 r.resize(W, H)
 r.set_light_trace(M, 52, 1)
-r.set_subspace()
+if trained: r.preprocess(2_000_000, 2_000_000, True)
+else: r.set_subspace()
 r.set_light_trace(M, 52, 1, core_begin=0, core_count=M // N)
+ex = None
+if exchange:
+    import torch, torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    ex = p.dist.FrameExchanger(r, 0, 1, dev)
 rows = (0, H, N)
 def step(f):
-    r.launch("light trace", f + 1); r.build_sampler(); r.launch("SPCBPT_eye", f, rows)
+    r.launch("light trace", f + 1)
+    if ex is not None: ex.allgather_lvc()
+    r.build_sampler(); r.launch("SPCBPT_eye", f, rows)
 for f in range(4): step(f)
 r.sync()
 t0 = time.perf_counter()
 for f in range(steps): step(f)
 r.sync()
 dt = (time.perf_counter() - t0) / steps
-print(f"N={N} streams={streams}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+if ex is not None:
+    import torch.distributed as dist
+    dist.destroy_process_group()

@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--render-streams", type=int, default=0,
                     help="frames in flight per GPU (0 = 2 on one GPU, 4 when the frame is sharded: a rank's share of a frame does not fill the GPU)")
     ap.add_argument("--write-image", default="")
+    ap.add_argument("--no-light-ahead", action="store_true", help="sharded job: launch each frame's light pass only when its exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     args = ap.parse_args()
 
@@ -154,8 +155,23 @@ def main():
     ex = pkg.dist.FrameExchanger(r, rank, world, device) if dist is not None else None
     info = r.scene_info()
 
+    # Sharded job: the light pass of the NEXT frame is launched before this frame's shards are gathered, so the host never
+    # waits for a light pass that has only just been queued (spcbpt_set_light_ahead; a light pass is a ~1 ms dependent chain
+    # however few paths a rank traces).  Every step still launches exactly one light pass, one exchange, one sampler build
+    # and one eye pass; the light pass a step launches is consumed by the next step.
+    ahead = ex is not None and not args.no_light_ahead
+    state = {"next_light": 1, "primed": False}
+    if ahead:
+        r.set_light_ahead(True)
+
     def step(f):
-        r.launch("light trace", f + 1)
+        if not ahead:
+            r.launch("light trace", f + 1)
+        else:
+            if not state["primed"]:
+                r.launch("light trace", state["next_light"]); state["next_light"] += 1
+                state["primed"] = True
+            r.launch("light trace", state["next_light"]); state["next_light"] += 1   # consumed by the next step
         if ex is not None:
             ex.allgather_lvc()
         r.build_sampler()
@@ -172,7 +188,10 @@ def main():
         step(f)
     # event counts of ONE launch of the dominant kernel -> algorithmic bytes per launch (untimed)
     r.sync()
-    r.launch("light trace", 999)
+    if not ahead:
+        r.launch("light trace", 999)
+    else:
+        r.launch("light trace", state["next_light"]); state["next_light"] += 1
     if ex is not None:
         ex.allgather_lvc()
     r.build_sampler()
@@ -238,7 +257,7 @@ def main():
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams, "light_pass_ahead": bool(ahead), "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -284,6 +284,12 @@ int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 int spcbpt_stream(spcbpt_ctx* ctx, void** stream);
 int spcbpt_sync(spcbpt_ctx* ctx);
 int spcbpt_sync_light(spcbpt_ctx* ctx);
+/* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain
+ * however few paths a rank traces, and the LVC exchange makes the host wait for it; with on != 0 the host may launch frame
+ * f + 1's "light trace" BEFORE it exchanges and builds frame f's: every light pass queues its buffer set, and
+ * spcbpt_lvc_export / spcbpt_lvc_import / spcbpt_sync_light / spcbpt_build_sampler address the OLDEST queued pass (sync_light
+ * then waits for that pass only, not for the stream).  Off (default): they address the latest light pass. */
+int spcbpt_set_light_ahead(spcbpt_ctx* ctx, int on);
 
 /* Kernel timing measured with HIP events on the context's stream: average
  * milliseconds per launch of `name` since the last reset, and launch count. */

@@ -247,39 +247,51 @@ int Context::launch_light(uint32_t frame) {
     time_end();
     HIP_TRY(this, hipGetLastError());
     keys_ready = true;
+    keys_set = lset;
     lvc_count = -1;  // known on the device only until the next host read
+    set_count_host[lset] = -1;
     have_sampler = false;
+    HIP_TRY(this, hipEventRecord(ev_light[lset], stream));
+    if (!light_ahead) pending.clear();   // default: a sampler build always takes the latest light pass
+    for (auto it = pending.begin(); it != pending.end();) it = (*it == lset) ? pending.erase(it) : it + 1;  // a set that comes round again unbuilt
+    pending.push_back(lset);
     return 0;
 }
 
-int Context::fetch_counts() {
+int Context::fetch_counts_of(int set) {
     int h[2] = {0, 0};
-    HIP_TRY(this, hipMemcpyAsync(h, d_sampler_counts, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(this, hipMemcpyAsync(h, set_counts[set], sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     lvc_count = h[0];
     path_count = h[1];
     return 0;
 }
+int Context::fetch_counts() { return fetch_counts_of(lset); }
 
-// LVC_Process on the device
+// LVC_Process on the device, for the oldest light pass (or imported cache) that has no sampler yet
 int Context::build_sampler() {
     if (!d_lvc) { error = "build_sampler: no light-vertex cache (run \"light trace\" or spcbpt_lvc_import first)"; return SPCBPT_ERR_STATE; }
-    int rc = fetch_counts();  // the radix sort needs its item count on the host: one 8-byte readback per frame
-    if (rc) return rc;
+    const int bset = build_set();
+    select_set(bset);
+    int rc = 0;
+    const bool count_known = set_count_host[bset] >= 0;   // an import told the host; otherwise one 8-byte readback per frame
+    if (count_known) lvc_count = set_count_host[bset];    // (the radix sort needs its item count on the host)
+    else rc = fetch_counts_of(bset);
+    if (rc) { select_set(lset); return rc; }
     const int n = lvc_count;
     time_begin("sampler_build");
-    if (!keys_ready) {
+    if (!(keys_ready && keys_set == bset)) {
         HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
         launch_fill_keys(d_lvc, n, d_keys, d_vals, d_weights, d_sampler_counts, stream);
-        keys_ready = true;
     }
+    keys_ready = false;   // the sort below consumes the keys
     HIP_TRY(this, hipMemsetAsync(d_subspace, 0, SPCBPT_NUM_SUBSPACE * sizeof(DSubspace), stream));
     if (n > 0) {
         size_t tb = 0, tb2 = 0;
         HIP_TRY(this, hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 10, stream));
         HIP_TRY(this, hipcub::DeviceScan::InclusiveSum(nullptr, tb2, d_wsorted, d_prefix, n, stream));
         rc = ensure_temp(std::max(tb, tb2));
-        if (rc) return rc;
+        if (rc) { select_set(lset); return rc; }
         HIP_TRY(this, hipcub::DeviceRadixSort::SortPairs(d_temp, tb, d_keys, d_keys2, d_vals, d_vals2, n, 0, 10, stream));
         launch_subspace_ranges(d_keys2, d_sampler_counts, d_subspace, n, stream);
         launch_gather_weights(d_weights, d_vals2, d_sampler_counts, d_wsorted, n, stream);
@@ -288,13 +300,15 @@ int Context::build_sampler() {
     }
     time_end();
     HIP_TRY(this, hipGetLastError());
-    if (fetch_counts()) return SPCBPT_ERR_HIP;
-    kp.lvc = d_lvc; kp.subspace = d_subspace; kp.cmfs = d_cmfs; kp.jump = reinterpret_cast<const int32_t*>(d_vals2);
-    kp.sampler_counts = d_sampler_counts;
-    eset = lset;
+    // the host copy of (vertex_count, path_count): a second readback, skipped when the count came with an import (a sharded
+    // job must not wait for the light stream here -- the next frame's light pass is already queued on it)
+    if (!count_known && fetch_counts_of(bset)) { select_set(lset); return SPCBPT_ERR_HIP; }
+    eset = bset;
     HIP_TRY(this, hipEventRecord(ev_sampler[eset], stream));
     ev_sampler_set[eset] = true;
     have_sampler = true;
+    if (!pending.empty() && pending.front() == bset) pending.pop_front();
+    select_set(lset);   // the members name the latest light pass's set again
     return 0;
 }
 
@@ -337,10 +351,26 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
             blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
             // developer knob (occupancy experiments): fewer resident blocks per CU than the kernel's resources allow
             if (const char* e = getenv("SPCBPT_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < blocks_per_cu[counting]) blocks_per_cu[counting] = v; }
+            if (const char* e = getenv("SPCBPT_TILES_PER_WAVE")) tiles_per_wave = std::max(1, atoi(e));
+            if (const char* e = getenv("SPCBPT_GRID_PERCENT")) grid_percent = std::max(1, std::min(100, atoi(e)));   // else adaptive
         }
     }
     time_begin(name, rstream);
-    if (spcbpt_alg) launch_spcbpt(kp, counting, num_cus * blocks_per_cu[counting], rstream);
+    if (spcbpt_alg) {
+        // Persistent grid.  With one render stream the kernel takes every resident block slot.  With several it takes 90 % of
+        // them: a persistent block never yields, so a full grid leaves the next frame's light pass (and through the host's
+        // wait for its vertex count, the next eye launch) nothing to run on until whole blocks have drained; with a tenth of the
+        // slots free the light pass runs at once and the two eye kernels share the machine from the start.  Measured on the
+        // bench scene, two streams: 248 -> 259.5 Mpaths/s at 90 %, 259 at 84 %, 257.5 at 75 %; the kernel by itself is 6 %
+        // slower at 90 % (8.5 instead of 8.0 ms).  A policy that looks whether the previous eye kernel is still running does
+        // not work: by the time the host has the vertex count it waited for, that kernel has drained.
+        // SPCBPT_GRID_PERCENT fixes the share; SPCBPT_TILES_PER_WAVE bounds the waves by the tile count (experiments).
+        int max_blocks = num_cus * blocks_per_cu[counting];
+        if (tiles_per_wave > 1) max_blocks = std::max(1, std::min(max_blocks, (int)(kp.n_tiles / (uint32_t)(4 * tiles_per_wave))));
+        const int percent = grid_percent > 0 ? grid_percent : (n_render > 1 ? 90 : 100);
+        if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
+        launch_spcbpt(kp, counting, max_blocks, rstream);
+    }
     else launch_pt(kp, counting, rstream);
     time_end();
     HIP_TRY(this, hipGetLastError());
@@ -463,7 +493,7 @@ Context::~Context() {
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
-    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); dev_free(d_spill); dev_free(d_temp);
+    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); dev_free(d_spill); dev_free(d_temp);
     for (int s = 0; s < kMaxRender; s++) {
         if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
@@ -473,6 +503,7 @@ Context::~Context() {
     for (int s = 0; s < kMaxSets; s++) {
         if (ev_sampler[s]) (void)hipEventDestroy(ev_sampler[s]);
         if (ev_render[s]) (void)hipEventDestroy(ev_render[s]);
+        if (ev_light[s]) (void)hipEventDestroy(ev_light[s]);
     }
 }
 
@@ -523,7 +554,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         const char* nr = getenv("SPCBPT_RENDER_STREAMS");
         c->n_render = nr ? std::max(1, std::min((int)Context::kMaxRender, atoi(nr))) : 2;
         if (ov && std::string(ov) == "0") c->n_render = 1;
-        c->n_sets = c->n_render + 1;
+        c->n_sets = c->n_render + 2;
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
             else CREATE_TRY(hipStreamCreateWithFlags(&c->rstreams[s], hipStreamNonBlocking));
@@ -533,7 +564,10 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         for (int s = 0; s < c->n_sets; s++) {
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_sampler[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&c->ev_light[s], hipEventDisableTiming));
+            c->set_count_host[s] = -1;
         }
+        CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_import_counts), (size_t)Context::kMaxSets * 2 * sizeof(int)));
     }
 
     // ---- scene assembly (scene_shift.cpp:64-154, 184-328)
@@ -737,26 +771,34 @@ int spcbpt_lvc_export(spcbpt_ctx* c, void** dv, void** dc, int* cap) {
     CTX_CHECK(c);
     if (!dv || !dc || !cap) return SPCBPT_ERR_INVALID_ARG;
     if (!c->d_lvc) { c->error = "no LVC allocated"; return SPCBPT_ERR_STATE; }
-    *dv = c->d_lvc; *dc = c->d_sampler_counts; *cap = (int)c->lvc_capacity;
+    const int b = c->build_set();   // the oldest light pass without a sampler: the shard that is exchanged next
+    *dv = c->set_lvc[b]; *dc = c->set_counts[b]; *cap = (int)c->lvc_capacity;
     return SPCBPT_OK;
 }
 
 int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device) {
     CTX_CHECK(c);
     if (!verts || count < 0) { c->error = "bad LVC import"; return SPCBPT_ERR_INVALID_ARG; }
+    if ((size_t)std::max(count, 1) > c->lvc_capacity && c->pending.size() > 1) {
+        c->error = "lvc_import: the cache does not fit and cannot grow while a later light pass is in flight (capacity = num_core * core_padding of spcbpt_set_light_trace)";
+        return SPCBPT_ERR_CAPACITY;
+    }
     int rc = c->ensure_lvc_capacity((size_t)std::max(count, 1));
     if (rc) return rc;
-    if ((const void*)c->d_lvc != verts)
-        HIP_TRY(c, hipMemcpyAsync(c->d_lvc, verts, (size_t)count * sizeof(LightVertex), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    int h[2] = {count, 0};
-    HIP_TRY(c, hipMemcpyAsync(c->d_sampler_counts, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    // only the light stream: the copies above must be done before the caller reuses `verts` (and before `h` goes out of
-    // scope).  The render streams are NOT waited for -- the buffer set written here is not the one an eye kernel in flight
-    // reads (launch_light / ensure_lvc_capacity order that), and a device-wide wait here would serialise every frame of a
-    // multi-GPU job with the previous frame's eye kernel.
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->lvc_count = count;
-    c->keys_ready = false;
+    const int b = c->build_set();
+    if ((const void*)c->set_lvc[b] != verts)
+        HIP_TRY(c, hipMemcpyAsync(c->set_lvc[b], verts, (size_t)count * sizeof(LightVertex), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    int* h = c->h_import_counts + 2 * b;   // pinned: the upload may run after this call returns
+    h[0] = count; h[1] = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->set_counts[b], h, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // Host memory: wait for the light stream, the caller may reuse `verts` at once.  Device memory: no wait at all -- the copy
+    // is ordered on the light stream; the caller keeps `verts` untouched until a light pass launched AFTER this call has been
+    // waited for with spcbpt_sync_light (dist.py alternates two staging buffers, which covers a light pass running one frame
+    // ahead).  The render streams are never waited for: the set written here is not one an eye kernel in flight reads.
+    if (!is_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->set_count_host[b] = count;
+    if (b == c->lset) c->lvc_count = count;
+    if (c->keys_set == b) c->keys_ready = false;
     c->have_sampler = false;
     return SPCBPT_OK;
 }
@@ -780,15 +822,18 @@ int spcbpt_sampler_read(spcbpt_ctx* c, spcbpt_subspace* sub, float* cmfs, int32_
     if (!sub || !vc || !pc) return SPCBPT_ERR_INVALID_ARG;
     if (c->sync_all()) return SPCBPT_ERR_HIP;
     std::vector<DSubspace> h(SPCBPT_NUM_SUBSPACE);
-    HIP_TRY(c, hipMemcpy(h.data(), c->d_subspace, h.size() * sizeof(DSubspace), hipMemcpyDeviceToHost));
+    const int e = c->eset;   // the set of the last sampler build (not necessarily the latest light pass's)
+    HIP_TRY(c, hipMemcpy(h.data(), c->set_subspace[e], h.size() * sizeof(DSubspace), hipMemcpyDeviceToHost));
     for (int i = 0; i < SPCBPT_NUM_SUBSPACE; i++) {
         sub[i].jump_bias = h[i].jump_bias; sub[i].id = i; sub[i].size = h[i].size; sub[i].sum_pmf = h[i].sum_pmf; sub[i].q = 0;
     }
-    *vc = c->lvc_count; *pc = c->path_count;
+    int hc[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(hc, c->set_counts[e], sizeof(hc), hipMemcpyDeviceToHost));
+    *vc = hc[0]; *pc = hc[1];
     if (cmfs && jump) {
-        if (capacity < c->lvc_count) { c->error = "sampler_read: buffer too small"; return SPCBPT_ERR_CAPACITY; }
-        HIP_TRY(c, hipMemcpy(cmfs, c->d_cmfs, (size_t)c->lvc_count * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(jump, c->d_vals2, (size_t)c->lvc_count * 4, hipMemcpyDeviceToHost));
+        if (capacity < hc[0]) { c->error = "sampler_read: buffer too small"; return SPCBPT_ERR_CAPACITY; }
+        HIP_TRY(c, hipMemcpy(cmfs, c->set_cmfs[e], (size_t)hc[0] * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(jump, c->set_vals2[e], (size_t)hc[0] * 4, hipMemcpyDeviceToHost));
     }
     return SPCBPT_OK;
 }
@@ -856,7 +901,26 @@ int spcbpt_reset_counters(spcbpt_ctx* c) {
 int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; return SPCBPT_OK; }
 
 int spcbpt_stream(spcbpt_ctx* c, void** s) { CTX_CHECK(c); if (!s) return SPCBPT_ERR_INVALID_ARG; *s = (void*)c->stream; return SPCBPT_OK; }
-int spcbpt_sync_light(spcbpt_ctx* c) { CTX_CHECK(c); HIP_TRY(c, hipStreamSynchronize(c->stream)); return SPCBPT_OK; }
+// Light passes may run ahead of the exchange / sampler build (a sharded job launches frame f + 1's light pass before it
+// gathers and builds frame f's): with on != 0 every "light trace" launch queues its buffer set, and spcbpt_lvc_export,
+// spcbpt_lvc_import, spcbpt_sync_light and spcbpt_build_sampler address the oldest queued set.  Off (default): they address the
+// latest light pass, as the single-GPU loop expects.  Switching clears the queue.
+int spcbpt_set_light_ahead(spcbpt_ctx* c, int on) {
+    CTX_CHECK(c);
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    c->light_ahead = on != 0;
+    c->pending.clear();
+    return SPCBPT_OK;
+}
+
+// Waits for the OLDEST pending light pass (what spcbpt_lvc_export hands out), not for everything queued on the light stream:
+// a later light pass may already be running ahead.  With nothing pending it waits for the light stream.
+int spcbpt_sync_light(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    if (!c->pending.empty()) HIP_TRY(c, hipEventSynchronize(c->ev_light[c->pending.front()]));
+    else HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SPCBPT_OK;
+}
 int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); if (c->sync_all()) return SPCBPT_ERR_HIP; return SPCBPT_OK; }
 
 int spcbpt_kernel_time(spcbpt_ctx* c, const char* name, double* avg_ms, int* launches) {

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <map>
 #include <string>
 #include <utility>
@@ -35,7 +36,7 @@ struct Context {
     // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..8).  More frames in flight pay when one frame does not
     // fill the GPU -- a rank of an 8-GPU job renders 1/8 of the image but its frame still ends with the same 50-bounce chain.
     static const int kMaxRender = 8, kMaxSets = kMaxRender + 1;
-    int n_render = 2, n_sets = 3;   // n_sets = n_render + 1: one set per eye kernel in flight + the one the light pass writes
+    int n_render = 2, n_sets = 4;   // n_sets = n_render + 2: one set per eye kernel in flight + up to two light passes ahead
     hipStream_t rstreams[kMaxRender] = {};
     int rk = 0, last_merge_k = -1;
     float* d_result[kMaxRender] = {};
@@ -43,7 +44,18 @@ struct Context {
     bool ev_merge_set[kMaxRender] = {};
     hipEvent_t ev_sampler[kMaxSets] = {}, ev_render[kMaxSets] = {};
     bool ev_sampler_set[kMaxSets] = {}, ev_render_set[kMaxSets] = {};
-    int lset = 0, eset = 0;  // buffer set of the light pass / sampler build in progress, and of the sampler eye launches use
+    int lset = 0, eset = 0;  // buffer set of the latest light pass, and of the sampler eye launches use
+    // Light passes whose sampler has not been built yet, oldest first.  The host loop of a single GPU alternates
+    // light pass -> sampler build, so the queue holds one set; a sharded job launches the NEXT frame's light pass before it
+    // exchanges and builds the current one (the light pass is a 1 ms dependent chain however few paths it traces, and the
+    // exchange makes the host wait for it), so export / import / build_sampler always address the OLDEST pending set.
+    std::deque<int> pending;
+    bool light_ahead = false;                // spcbpt_set_light_ahead: keep older unbuilt passes queued (default: only the latest)
+    hipEvent_t ev_light[kMaxSets] = {};      // light pass + compaction of the set done (recorded on `stream`)
+    int set_count_host[kMaxSets];            // vertex count of the set when the host knows it (after an import), else -1
+    int keys_set = -1;                       // the set whose compaction left d_keys / d_vals / d_weights (valid if keys_ready)
+    int* h_import_counts = nullptr;          // pinned [kMaxSets][2]: source of the counts upload of an import (no host wait)
+    int build_set() const { return pending.empty() ? lset : pending.front(); }
     LightVertex* set_lvc[kMaxSets] = {};
     uint32_t* set_vals2[kMaxSets] = {};
     float* set_cmfs[kMaxSets] = {};
@@ -108,6 +120,8 @@ struct Context {
     bool eye_megakernel = true;        // SPCBPT_EYE_PASS=wavefront selects the per-phase kernels of wavefront.hip instead
     int wf_bounces_last = 0;           // bounces launched by the last wavefront frame (diagnostics)
     int num_cus = 0, blocks_per_cu[2] = {0, 0};
+    int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 90 with several render streams, else 100 (launch_render)
+    int tiles_per_wave = 1;            // lower bound of 8x8 tiles per persistent wave (SPCBPT_TILES_PER_WAVE)
     unsigned long long* d_counters = nullptr;
     bool counting = false, timing = false;
     std::vector<TimedSpan> spans;
@@ -127,7 +141,8 @@ struct Context {
     int install_minimal_tuple();
     int set_light_trace(const spcbpt_light_trace_params& p);
     int launch_light(uint32_t frame);
-    int fetch_counts();
+    int fetch_counts();           // counts of the latest light pass's set (lset) -> lvc_count, path_count
+    int fetch_counts_of(int set);
     int build_sampler();
     int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs);
     int finish_frame();

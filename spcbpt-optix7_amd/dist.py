@@ -118,7 +118,8 @@ class FrameExchanger:
         self.torch = torch
         self.counts = torch.zeros(world, dtype=torch.int32, device=device)
         self.gather_buf = None
-        self.cat_buf = None
+        self.cat_bufs = [None, None]   # the import copies out of the staging buffer asynchronously: alternate two of them
+        self.frame = 0
 
     def allgather_lvc(self):
         """After `light trace` on every rank: gathers the shards and installs the global LVC in the context."""
@@ -140,14 +141,19 @@ class FrameExchanger:
         out = self.gather_buf[: self.world * nbytes]
         dist.all_gather_into_tensor(out, shard)
         total = sum(counts)
-        if self.cat_buf is None or self.cat_buf.numel() < total * VERTEX_BYTES:
-            self.cat_buf = torch.empty(max(total, 1) * VERTEX_BYTES * 5 // 4, dtype=torch.uint8, device=self.device)
+        k2 = self.frame & 1
+        self.frame += 1
+        if self.cat_bufs[k2] is None or self.cat_bufs[k2].numel() < total * VERTEX_BYTES:
+            self.cat_bufs[k2] = torch.empty(max(total, 1) * VERTEX_BYTES * 5 // 4, dtype=torch.uint8, device=self.device)
+        cat = self.cat_bufs[k2]
         off = 0
         for k, c in enumerate(counts):
-            self.cat_buf[off: off + c * VERTEX_BYTES].copy_(out[k * nbytes: k * nbytes + c * VERTEX_BYTES])
+            cat[off: off + c * VERTEX_BYTES].copy_(out[k * nbytes: k * nbytes + c * VERTEX_BYTES])
             off += c * VERTEX_BYTES
         torch.cuda.current_stream(self.device).synchronize()   # torch's stream only (a device-wide sync would wait for the eye kernel)
-        r.lvc_import_device(self.cat_buf.data_ptr(), total)
+        # queued on the context's light stream, no host wait: `cat` stays untouched until the frame after next (see
+        # spcbpt_lvc_import), and the sampler build that follows takes its item count from this call
+        r.lvc_import_device(cat.data_ptr(), total)
         return total
 
     def reduce_framebuffer(self):

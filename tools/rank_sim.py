@@ -1,6 +1,6 @@
 """What one rank of an N-GPU job does per frame, on one GPU: 1/N of the light cores, every N-th 8-row band.  Shows how the
 step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS).
-  python tools/rank_sim.py N streams [steps] [--exchange] [--trained]
+  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead] [--trained]
 --exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
 all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
 rate when its share of the image is small."""
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]); streams = int(args[1]); steps = int(args[2]) if len(args) > 2 else 32
-exchange, trained = "--exchange" in sys.argv, "--trained" in sys.argv
+exchange, trained, ahead = "--exchange" in sys.argv, "--trained" in sys.argv, "--ahead" in sys.argv
 os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)
 import __graft_entry__ as g
 p = g.load_package()
@@ -31,8 +31,11 @@ if exchange:
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     ex = p.dist.FrameExchanger(r, 0, 1, dev)
 rows = (0, H, N)
+if ahead:
+    r.set_light_ahead(True)
+    r.launch("light trace", 1)
 def step(f):
-    r.launch("light trace", f + 1)
+    r.launch("light trace", f + 2 if ahead else f + 1)
     if ex is not None: ex.allgather_lvc()
     r.build_sampler(); r.launch("SPCBPT_eye", f, rows)
 for f in range(4): step(f)
@@ -41,7 +44,7 @@ t0 = time.perf_counter()
 for f in range(steps): step(f)
 r.sync()
 dt = (time.perf_counter() - t0) / steps
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead' if ahead else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--render-streams", type=int, default=0,
                     help="frames in flight per GPU (0 = 2 on one GPU, 4 when the frame is sharded: a rank's share of a frame does not fill the GPU)")
     ap.add_argument("--write-image", default="")
-    ap.add_argument("--no-light-ahead", action="store_true", help="sharded job: launch each frame's light pass only when its exchange is due (the host then waits for it)")
+    ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     args = ap.parse_args()
 
@@ -155,11 +155,11 @@ def main():
     ex = pkg.dist.FrameExchanger(r, rank, world, device) if dist is not None else None
     info = r.scene_info()
 
-    # Sharded job: the light pass of the NEXT frame is launched before this frame's shards are gathered, so the host never
-    # waits for a light pass that has only just been queued (spcbpt_set_light_ahead; a light pass is a ~1 ms dependent chain
-    # however few paths a rank traces).  Every step still launches exactly one light pass, one exchange, one sampler build
+    # The light pass of the NEXT frame is launched before this frame's shards are gathered and its sampler is built, so the
+    # host never waits for a light pass that has only just been queued (spcbpt_set_light_ahead; a light pass is a ~1 ms
+    # dependent chain however few paths a rank traces, and it shares the GPU with the previous frame's eye kernel).  Every step still launches exactly one light pass, one exchange, one sampler build
     # and one eye pass; the light pass a step launches is consumed by the next step.
-    ahead = ex is not None and not args.no_light_ahead
+    ahead = not args.no_light_ahead
     state = {"next_light": 1, "primed": False}
     if ahead:
         r.set_light_ahead(True)

@@ -189,6 +189,8 @@ int Context::ensure_lvc_capacity(size_t n) {
         dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
         HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
     }
+    for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; }   // the sets are empty again
+    pending.clear();
     select_set(lset);
     HIP_TRY(this, dev_alloc(&d_keys, n)); HIP_TRY(this, dev_alloc(&d_keys2, n));
     HIP_TRY(this, dev_alloc(&d_vals, n));
@@ -251,7 +253,11 @@ int Context::launch_light(uint32_t frame) {
     lvc_count = -1;  // known on the device only until the next host read
     set_count_host[lset] = -1;
     have_sampler = false;
+    // (vertex_count, path_count) to pinned host memory, inside the event: the sampler build reads them after waiting for
+    // THIS pass only, not for whatever else has been queued on the stream since
+    HIP_TRY(this, hipMemcpyAsync(h_light_counts + 2 * lset, d_sampler_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(this, hipEventRecord(ev_light[lset], stream));
+    light_counts_valid[lset] = true;
     if (!light_ahead) pending.clear();   // default: a sampler build always takes the latest light pass
     for (auto it = pending.begin(); it != pending.end();) it = (*it == lset) ? pending.erase(it) : it + 1;  // a set that comes round again unbuilt
     pending.push_back(lset);
@@ -274,9 +280,15 @@ int Context::build_sampler() {
     const int bset = build_set();
     select_set(bset);
     int rc = 0;
-    const bool count_known = set_count_host[bset] >= 0;   // an import told the host; otherwise one 8-byte readback per frame
-    if (count_known) lvc_count = set_count_host[bset];    // (the radix sort needs its item count on the host)
-    else rc = fetch_counts_of(bset);
+    // the radix sort needs its item count on the host: an import told it, or the light pass left it in pinned memory (wait for
+    // that pass's event), or -- a cache written some other way -- one 8-byte readback
+    bool count_known = set_count_host[bset] >= 0;
+    if (count_known) lvc_count = set_count_host[bset];
+    else if (light_counts_valid[bset]) {
+        HIP_TRY(this, hipEventSynchronize(ev_light[bset]));
+        lvc_count = h_light_counts[2 * bset]; path_count = h_light_counts[2 * bset + 1];
+        count_known = true;
+    } else rc = fetch_counts_of(bset);
     if (rc) { select_set(lset); return rc; }
     const int n = lvc_count;
     time_begin("sampler_build");
@@ -493,7 +505,7 @@ Context::~Context() {
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
-    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); dev_free(d_spill); dev_free(d_temp);
+    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts); dev_free(d_spill); dev_free(d_temp);
     for (int s = 0; s < kMaxRender; s++) {
         if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
@@ -568,6 +580,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
             c->set_count_host[s] = -1;
         }
         CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_import_counts), (size_t)Context::kMaxSets * 2 * sizeof(int)));
+        CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_light_counts), (size_t)Context::kMaxSets * 2 * sizeof(int)));
     }
 
     // ---- scene assembly (scene_shift.cpp:64-154, 184-328)
@@ -797,6 +810,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     // ahead).  The render streams are never waited for: the set written here is not one an eye kernel in flight reads.
     if (!is_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->set_count_host[b] = count;
+    c->light_counts_valid[b] = false;
     if (b == c->lset) c->lvc_count = count;
     if (c->keys_set == b) c->keys_ready = false;
     c->have_sampler = false;

@@ -53,8 +53,11 @@ struct Context {
     bool light_ahead = false;                // spcbpt_set_light_ahead: keep older unbuilt passes queued (default: only the latest)
     hipEvent_t ev_light[kMaxSets] = {};      // light pass + compaction of the set done (recorded on `stream`)
     int set_count_host[kMaxSets];            // vertex count of the set when the host knows it (after an import), else -1
+    bool light_counts_valid[kMaxSets] = {};  // h_light_counts of the set describe its current contents
     int keys_set = -1;                       // the set whose compaction left d_keys / d_vals / d_weights (valid if keys_ready)
     int* h_import_counts = nullptr;          // pinned [kMaxSets][2]: source of the counts upload of an import (no host wait)
+    int* h_light_counts = nullptr;           // pinned [kMaxSets][2]: (vertex_count, path_count) of a light pass, written on `stream`
+                                             // before ev_light -- the host reads them after waiting for that event only
     int build_set() const { return pending.empty() ? lset : pending.front(); }
     LightVertex* set_lvc[kMaxSets] = {};
     uint32_t* set_vals2[kMaxSets] = {};

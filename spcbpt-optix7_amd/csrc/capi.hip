@@ -152,8 +152,24 @@ int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_t
     if (!d_gamma) HIP_TRY(this, dev_alloc(&d_gamma, (size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE));
     HIP_TRY(this, hipMemcpyAsync(d_Q, h_Q.data(), h_Q.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(d_gamma, h_gamma.data(), h_gamma.size() * 4, hipMemcpyHostToDevice, stream));
+    {   // two-level copy for first-stage sampling (device_lib.h: sample_first_stage)
+        std::vector<float> two((size_t)SPCBPT_NUM_SUBSPACE * CMF2_ROW, 2.0f);
+        for (int e = 0; e < SPCBPT_NUM_SUBSPACE; e++) {
+            float* row = &two[(size_t)e * CMF2_ROW];
+            memcpy(row + CMF2_COARSE, &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE], SPCBPT_NUM_SUBSPACE * sizeof(float));
+            for (int k = 0; k < CMF2_COARSE; k++) row[k] = row[CMF2_COARSE + 32 * k + 31];
+        }
+        if (!d_gamma2) HIP_TRY(this, dev_alloc(&d_gamma2, two.size()));
+        HIP_TRY(this, hipMemcpy(d_gamma2, two.data(), two.size() * sizeof(float), hipMemcpyHostToDevice));
+        gamma_monotone = true;   // counting equals bisecting only on a non-decreasing row that ends above every random number
+        for (int e = 0; e < SPCBPT_NUM_SUBSPACE && gamma_monotone; e++) {
+            const float* row = &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE];
+            for (int l = 1; l < SPCBPT_NUM_SUBSPACE; l++) if (!(row[l] >= row[l - 1])) { gamma_monotone = false; break; }
+            if (!(row[SPCBPT_NUM_SUBSPACE - 1] >= 1.0f)) gamma_monotone = false;
+        }
+    }
     HIP_TRY(this, hipStreamSynchronize(stream));
-    kp.eye_tree = d_eye_tree; kp.light_tree = d_light_tree; kp.Q = d_Q; kp.cmf_gamma = d_gamma;
+    kp.eye_tree = d_eye_tree; kp.light_tree = d_light_tree; kp.Q = d_Q; kp.cmf_gamma = d_gamma; kp.cmf_gamma2 = gamma_monotone ? d_gamma2 : nullptr;
     have_subspace = true;
     return 0;
 }
@@ -501,7 +517,7 @@ Context::~Context() {
     free_preprocess();
     dev_free(d_nodes); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
-    dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma);
+    dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }

@@ -634,6 +634,43 @@ SPC_DEV int binary_sample(const float* cmf, int size, uint32_t& seed, float& pmf
     return l;
 }
 
+// sampleFirstStage (cuProg.h:290-301) = binary_sample over the 1000-entry CMF row of the eye subspace: ten DEPENDENT probes.
+// For a non-decreasing CMF the bisection returns the first bin with u < cmf[bin], i.e. the number of entries <= u, which two
+// counting passes over 32 values each find in two round trips (coarse: every 32nd entry; fine: the 32 entries of that
+// segment; 8 independent 16-B loads per pass), plus one for the two CMF values of the pmf.  Same bin, same pmf, same random
+// number; the probe counter (algorithmic bytes) is charged what the bisection would have probed.
+template <bool COUNT>
+SPC_DEV int sample_first_stage(const KParams& p, int eye_subspace, uint32_t& seed, float& pmf, Counts<COUNT>& cn) {
+    // a caller-supplied matrix with a decreasing row (not a CMF) keeps the bisection, whose answer is then its own definition
+    if (!p.cmf_gamma2) return binary_sample(p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, seed, pmf, cn);
+    const float u = rnd(seed);
+    const float4* R = reinterpret_cast<const float4*>(p.cmf_gamma2 + (size_t)eye_subspace * CMF2_ROW);
+    float4 q[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = R[i];
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) k += (q[i].x <= u ? 1 : 0) + (q[i].y <= u ? 1 : 0) + (q[i].z <= u ? 1 : 0) + (q[i].w <= u ? 1 : 0);
+    const float4* F = R + (CMF2_COARSE / 4) + (size_t)k * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = F[i];
+    int l = 32 * k;
+#pragma unroll
+    for (int i = 0; i < 8; i++) l += (q[i].x <= u ? 1 : 0) + (q[i].y <= u ? 1 : 0) + (q[i].z <= u ? 1 : 0) + (q[i].w <= u ? 1 : 0);
+    const float* row = p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE;
+    const float hi = row[l], lo = l == 0 ? 0.0f : row[l - 1];
+    pmf = l == 0 ? hi : hi - lo;
+    if (COUNT) {  // the probes of the reference's bisection on its way to bin l
+        int mid = SPCBPT_NUM_SUBSPACE / 2 - 1, a = 0, b = SPCBPT_NUM_SUBSPACE;
+        while (b - a > 1) {
+            cn.add(C_CMF);
+            if (l <= mid) b = mid + 1; else a = mid + 1;
+            mid = (a + b) / 2 - 1;
+        }
+    }
+    return l;
+}
+
 // ---- recursive MIS (rmis.h) ------------------------------------------------------
 // The fields of a path vertex the RMIS recursions read, shared by eye and light vertices.
 struct VCore {

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                         float pmf1, pmf2;
                         float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
-                        const int l = binary_sample(p.cmf_gamma + (size_t)cur.sub * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, w.seed, pmf1, cn);
+                        const int l = sample_first_stage(p, cur.sub, w.seed, pmf1, cn);
                         const DSubspace ss = p.subspace[l];
                         if (ss.size != 0) {
                             const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);

@@ -66,6 +66,10 @@ static const uint32_t TREE_LEAF_BIT = 0x80000000u;
 typedef spcbpt_light_vertex LightVertex;  // 96 B = 6 x float4, AoS because it is fetched by random gather
 static_assert(sizeof(LightVertex) == 96, "LightVertex");
 
+// First-stage sampling table: per eye subspace 32 coarse entries (every 32nd CMF value) followed by the row padded to 1024
+// entries (padding 2.0 > any random number), all 16-B aligned.
+static const int CMF2_COARSE = 32, CMF2_FINE = 1024, CMF2_ROW = CMF2_COARSE + CMF2_FINE;
+
 struct DSubspace {  // 16 B
     int32_t jump_bias;
     int32_t size;
@@ -108,6 +112,7 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     const float* light_tree;
     const float* Q;
     const float* cmf_gamma;
+    const float* cmf_gamma2;  // two-level copy of cmf_gamma for first-stage sampling (CMF2_ROW floats per row, see device_lib.h)
     // sampler (SubspaceSampler)
     const LightVertex* lvc;
     const DSubspace* subspace;

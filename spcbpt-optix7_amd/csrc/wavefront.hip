@@ -177,7 +177,7 @@ __global__ __launch_bounds__(WBLOCK) void k_wf_shade(const KParams p, const WfSt
                 // shadow-ray records sit at fixed positions (connection-major: it * count + item), no compaction needed
                 for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                     float pmf1, pmf2 = 0.0f;
-                    const int l = binary_sample(p.cmf_gamma + (size_t)mid.sub * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, w.seed, pmf1, cn);
+                    const int l = sample_first_stage(p, mid.sub, w.seed, pmf1, cn);
                     const DSubspace ss = p.subspace[l];
                     const size_t k = (size_t)it * count + item;
                     if (ss.size != 0) {

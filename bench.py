@@ -117,7 +117,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        # the two small all-gathers of a frame queue behind persistent eye kernels for block slots: high-priority RCCL stream
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
 
     streams = args.render_streams if args.render_streams > 0 else (4 if world > 1 else 2)
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create

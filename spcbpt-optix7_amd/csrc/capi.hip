@@ -576,7 +576,15 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     } while (0)
     // non-blocking streams: a host that drives collectives on the legacy default stream (torch) must not be serialised with
     // the render stream; every hand-over in this file is an explicit event or synchronize
-    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // Priorities: the light pass, the sampler build and the exchange copies are small, latency-critical kernels that the host
+    // (or the next eye launch) waits for, while several persistent eye kernels queue for every block slot that frees up; the
+    // light stream therefore gets the highest priority and the render streams the lowest (SPCBPT_STREAM_PRIORITY=0: all equal).
+    int prio_least = 0, prio_greatest = 0;
+    CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    const char* sp = getenv("SPCBPT_STREAM_PRIORITY");
+    const bool use_prio = !(sp && std::string(sp) == "0") && prio_least != prio_greatest;
+    if (use_prio) CREATE_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest));
+    else CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         const char* ov = getenv("SPCBPT_OVERLAP");
         const char* nr = getenv("SPCBPT_RENDER_STREAMS");
@@ -585,6 +593,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         c->n_sets = c->n_render + 2;
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
+            else if (use_prio) CREATE_TRY(hipStreamCreateWithPriority(&c->rstreams[s], hipStreamNonBlocking, prio_least));
             else CREATE_TRY(hipStreamCreateWithFlags(&c->rstreams[s], hipStreamNonBlocking));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_merge[s], hipEventDisableTiming));
         }

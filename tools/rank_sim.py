@@ -28,7 +28,7 @@ if exchange:
     import torch, torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
     dev = torch.device("cuda", 0)
-    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
     ex = p.dist.FrameExchanger(r, 0, 1, dev)
 rows = (0, H, N)
 if ahead:
@@ -41,9 +41,20 @@ def step(f):
 for f in range(4): step(f)
 r.sync()
 t0 = time.perf_counter()
-for f in range(steps): step(f)
+host = {"light": 0.0, "exchange": 0.0, "build": 0.0, "eye": 0.0}
+def timed_step(f):
+    a = time.perf_counter(); r.launch("light trace", f + 2 if ahead else f + 1)
+    b = time.perf_counter()
+    if ex is not None: ex.allgather_lvc()
+    c2 = time.perf_counter(); r.build_sampler()
+    d = time.perf_counter(); r.launch("SPCBPT_eye", f, rows)
+    e = time.perf_counter()
+    host["light"] += b - a; host["exchange"] += c2 - b; host["build"] += d - c2; host["eye"] += e - d
+for f in range(steps): timed_step(f)
+t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
+print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
 print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead' if ahead else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist

@@ -60,6 +60,7 @@ void Context::time_end() {
 }
 int Context::sync_all() {
     HIP_TRY(this, hipStreamSynchronize(stream));
+    if (lstream_b) HIP_TRY(this, hipStreamSynchronize(lstream_b));
     for (int k = 0; k < n_render; k++)
         if (rstreams[k] && rstreams[k] != stream) HIP_TRY(this, hipStreamSynchronize(rstreams[k]));
     return 0;
@@ -226,6 +227,28 @@ int Context::ensure_temp(size_t bytes) {
     return 0;
 }
 
+int Context::ensure_lane_b() {
+    if (!lstream_b) {
+        int least = 0, greatest = 0;
+        HIP_TRY(this, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(this, hipStreamCreateWithPriority(&lstream_b, hipStreamNonBlocking, greatest));
+    }
+    const size_t slots = (size_t)lt.core_count * lt.core_padding;
+    if (slots > b_scratch_capacity) { dev_free(b_scratch); HIP_TRY(this, dev_alloc(&b_scratch, slots)); b_scratch_capacity = slots; }
+    if ((size_t)lt.core_count + 1 > b_counts_capacity) {
+        dev_free(b_core_counts); dev_free(b_core_offsets);
+        HIP_TRY(this, dev_alloc(&b_core_counts, (size_t)lt.core_count + 1));
+        HIP_TRY(this, dev_alloc(&b_core_offsets, (size_t)lt.core_count + 1));
+        b_counts_capacity = (size_t)lt.core_count + 1;
+    }
+    if (lvc_capacity > b_keys_capacity) {
+        dev_free(b_keys); dev_free(b_vals); dev_free(b_weights);
+        HIP_TRY(this, dev_alloc(&b_keys, lvc_capacity)); HIP_TRY(this, dev_alloc(&b_vals, lvc_capacity)); HIP_TRY(this, dev_alloc(&b_weights, lvc_capacity));
+        b_keys_capacity = lvc_capacity;
+    }
+    return 0;
+}
+
 // "light trace": k_light_trace into the padded scratch, then compaction into the deterministic (core, slot) order
 int Context::launch_light(uint32_t frame) {
     if (!have_subspace) { error = "light trace needs a subspace tuple (spcbpt_set_subspace)"; return SPCBPT_ERR_STATE; }
@@ -234,46 +257,76 @@ int Context::launch_light(uint32_t frame) {
         int rc = set_light_trace(d);
         if (rc) return rc;
     }
+    // lane: passes running ahead alternate between the light stream and a second one (context.h); everything else uses lane 0
+    int lane = 0;
+    if (light_ahead && !counting && getenv("SPCBPT_LIGHT_LANES") == nullptr) { light_toggle ^= 1; lane = light_toggle; }
+    if (lane) { int rcb = ensure_lane_b(); if (rcb) return rcb; }
+    hipStream_t ls = lane ? lstream_b : stream;
+    LightVertex* scratch = lane ? b_scratch : d_scratch;
+    int* core_counts = lane ? b_core_counts : d_core_counts;
+    int* core_offsets = lane ? b_core_offsets : d_core_offsets;
+    uint32_t* keys = lane ? b_keys : d_keys;
+    uint32_t* vals = lane ? b_vals : d_vals;
+    float* weights = lane ? b_weights : d_weights;
     kp.num_core = lt.num_core; kp.core_padding = lt.core_padding; kp.m_per_core = lt.m_per_core;
     kp.core_begin = lt.core_begin; kp.core_count = lt.core_count; kp.launch_frame = frame;
     kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
-    kp.lvc_scratch = d_scratch; kp.core_counts = d_core_counts;
-    int rc = ensure_spill(((size_t)lt.core_count + 255) / 256 * 256);
-    if (rc) return rc;
+    kp.lvc_scratch = scratch; kp.core_counts = core_counts;
+    int rc = 0;
+    {   // traversal-stack spill area of this lane's light kernel
+        const int entries = std::max(0, 3 * bvh_depth - kStackLds);
+        kp.spill_entries = entries;
+        const size_t need = (((size_t)lt.core_count + 255) / 256 * 256) * (size_t)entries;
+        uint32_t*& buf = lane ? b_spill : d_spill;
+        size_t& cap = lane ? b_spill_capacity : spill_capacity;
+        if (entries == 0) kp.spill = nullptr;
+        else {
+            if (need > cap) { dev_free(buf); HIP_TRY(this, dev_alloc(&buf, need)); cap = need; }
+            kp.spill = buf;
+        }
+    }
     kp.counters = counting ? d_counters : nullptr;
     // write the set the eye pass is NOT reading; it was last read by the render launch before the previous one
     lset = (lset + 1) % n_sets;
     select_set(lset);
-    if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_render[lset], 0));
-    HIP_TRY(this, hipMemsetAsync(d_core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), stream));
-    HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), stream));
+    if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[lset], 0));
+    HIP_TRY(this, hipMemsetAsync(core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), ls));
+    HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), ls));
     kp.path_counter = d_sampler_counts + 1;
-    time_begin("light_trace");
-    launch_light_trace(kp, counting, stream);
+    time_begin("light_trace", ls);
+    launch_light_trace(kp, counting, ls);
     time_end();
     HIP_TRY(this, hipGetLastError());
     // compaction: exclusive scan of per-core counts (+1 sentinel gives the total) -> offsets
-    time_begin("lvc_compact");
+    time_begin("lvc_compact", ls);
     size_t tb = 0;
-    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_core_counts, d_core_offsets, lt.core_count + 1, stream));
-    rc = ensure_temp(tb);
-    if (rc) return rc;
-    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(d_temp, tb, d_core_counts, d_core_offsets, lt.core_count + 1, stream));
-    HIP_TRY(this, hipMemcpyAsync(d_sampler_counts, d_core_offsets + lt.core_count, sizeof(int), hipMemcpyDeviceToDevice, stream));
-    launch_lvc_compact(d_scratch, d_core_counts, d_core_offsets, lt.core_count, lt.core_padding, d_lvc, d_keys, d_vals, d_weights,
-                       d_sampler_counts, stream);
+    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, core_counts, core_offsets, lt.core_count + 1, ls));
+    unsigned char* temp = nullptr;
+    if (lane) {
+        if (tb > b_temp_capacity) { dev_free(b_temp); HIP_TRY(this, dev_alloc(&b_temp, tb)); b_temp_capacity = tb; }
+        temp = b_temp;
+    } else {
+        rc = ensure_temp(tb);
+        if (rc) return rc;
+        temp = d_temp;
+    }
+    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(temp, tb, core_counts, core_offsets, lt.core_count + 1, ls));
+    HIP_TRY(this, hipMemcpyAsync(d_sampler_counts, core_offsets + lt.core_count, sizeof(int), hipMemcpyDeviceToDevice, ls));
+    launch_lvc_compact(scratch, core_counts, core_offsets, lt.core_count, lt.core_padding, d_lvc, keys, vals, weights,
+                       d_sampler_counts, ls);
     time_end();
     HIP_TRY(this, hipGetLastError());
-    keys_ready = true;
-    keys_set = lset;
+    if (lane == 0) { keys_ready = true; keys_set = lset; }
+    else if (keys_set == lset) keys_ready = false;   // the set was rewritten by the other lane: lane 0's keys no longer describe it
     lvc_count = -1;  // known on the device only until the next host read
     set_count_host[lset] = -1;
     have_sampler = false;
     // (vertex_count, path_count) to pinned host memory, inside the event: the sampler build reads them after waiting for
     // THIS pass only, not for whatever else has been queued on the stream since
-    HIP_TRY(this, hipMemcpyAsync(h_light_counts + 2 * lset, d_sampler_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(this, hipEventRecord(ev_light[lset], stream));
+    HIP_TRY(this, hipMemcpyAsync(h_light_counts + 2 * lset, d_sampler_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(this, hipEventRecord(ev_light[lset], ls));
     light_counts_valid[lset] = true;
+    light_lane_of_set[lset] = lane;
     if (!light_ahead) pending.clear();   // default: a sampler build always takes the latest light pass
     for (auto it = pending.begin(); it != pending.end();) it = (*it == lset) ? pending.erase(it) : it + 1;  // a set that comes round again unbuilt
     pending.push_back(lset);
@@ -296,6 +349,7 @@ int Context::build_sampler() {
     const int bset = build_set();
     select_set(bset);
     int rc = 0;
+    if (light_lane_of_set[bset] != 0 && light_counts_valid[bset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_light[bset], 0));   // traced on the second lane
     // the radix sort needs its item count on the host: an import told it, or the light pass left it in pinned memory (wait for
     // that pass's event), or -- a cache written some other way -- one 8-byte readback
     bool count_known = set_count_host[bset] >= 0;
@@ -521,7 +575,9 @@ Context::~Context() {
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
-    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts); dev_free(d_spill); dev_free(d_temp);
+    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
+    dev_free(b_scratch); dev_free(b_core_counts); dev_free(b_core_offsets); dev_free(b_keys); dev_free(b_vals); dev_free(b_weights); dev_free(b_temp); dev_free(b_spill);
+    if (lstream_b) (void)hipStreamDestroy(lstream_b); dev_free(d_spill); dev_free(d_temp);
     for (int s = 0; s < kMaxRender; s++) {
         if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
@@ -590,7 +646,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         const char* nr = getenv("SPCBPT_RENDER_STREAMS");
         c->n_render = nr ? std::max(1, std::min((int)Context::kMaxRender, atoi(nr))) : 2;
         if (ov && std::string(ov) == "0") c->n_render = 1;
-        c->n_sets = c->n_render + 2;
+        c->n_sets = std::min((int)Context::kMaxSets, c->n_render + 4);   // eye kernels in flight + up to three light passes ahead + the one being built
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
             else if (use_prio) CREATE_TRY(hipStreamCreateWithPriority(&c->rstreams[s], hipStreamNonBlocking, prio_least));
@@ -824,6 +880,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     int rc = c->ensure_lvc_capacity((size_t)std::max(count, 1));
     if (rc) return rc;
     const int b = c->build_set();
+    if (c->light_lane_of_set[b] != 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_light[b], 0));   // the pass that filled this set ran on the second lane
     if ((const void*)c->set_lvc[b] != verts)
         HIP_TRY(c, hipMemcpyAsync(c->set_lvc[b], verts, (size_t)count * sizeof(LightVertex), is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     int* h = c->h_import_counts + 2 * b;   // pinned: the upload may run after this call returns
@@ -836,6 +893,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     if (!is_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->set_count_host[b] = count;
     c->light_counts_valid[b] = false;
+    c->light_lane_of_set[b] = 0;   // from here on the set's contents are ordered on `stream`
     if (b == c->lset) c->lvc_count = count;
     if (c->keys_set == b) c->keys_ready = false;
     c->have_sampler = false;

@@ -36,7 +36,7 @@ struct Context {
     // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..8).  More frames in flight pay when one frame does not
     // fill the GPU -- a rank of an 8-GPU job renders 1/8 of the image but its frame still ends with the same 50-bounce chain.
     static const int kMaxRender = 8, kMaxSets = kMaxRender + 1;
-    int n_render = 2, n_sets = 4;   // n_sets = n_render + 2: one set per eye kernel in flight + up to two light passes ahead
+    int n_render = 2, n_sets = 6;   // n_sets = n_render + 4: one set per eye kernel in flight + the light passes ahead of them
     hipStream_t rstreams[kMaxRender] = {};
     int rk = 0, last_merge_k = -1;
     float* d_result[kMaxRender] = {};
@@ -59,6 +59,19 @@ struct Context {
     int* h_light_counts = nullptr;           // pinned [kMaxSets][2]: (vertex_count, path_count) of a light pass, written on `stream`
                                              // before ev_light -- the host reads them after waiting for that event only
     int build_set() const { return pending.empty() ? lset : pending.front(); }
+    // Second light lane.  On one in-order stream light pass, compaction, import copy and sampler build of consecutive frames
+    // form a chain of ~1.3 ms per frame -- more than a rank's share of the eye pass costs when the frame is sharded eight ways.
+    // With light passes running ahead, every other pass (kernel + compaction) therefore goes to a second stream with its own
+    // scratch, counts, key and temp buffers; imports and sampler builds stay on `stream` and wait for the pass's event.
+    hipStream_t lstream_b = nullptr;
+    int light_toggle = 0;
+    int light_lane_of_set[kMaxSets] = {};    // which lane's stream last wrote the set (its ev_light orders it)
+    LightVertex* b_scratch = nullptr; size_t b_scratch_capacity = 0;
+    int *b_core_counts = nullptr, *b_core_offsets = nullptr; size_t b_counts_capacity = 0;
+    uint32_t *b_keys = nullptr, *b_vals = nullptr; float* b_weights = nullptr; size_t b_keys_capacity = 0;
+    unsigned char* b_temp = nullptr; size_t b_temp_capacity = 0;
+    uint32_t* b_spill = nullptr; size_t b_spill_capacity = 0;
+    int ensure_lane_b();
     LightVertex* set_lvc[kMaxSets] = {};
     uint32_t* set_vals2[kMaxSets] = {};
     float* set_cmfs[kMaxSets] = {};

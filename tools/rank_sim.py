@@ -1,6 +1,6 @@
 """What one rank of an N-GPU job does per frame, on one GPU: 1/N of the light cores, every N-th 8-row band.  Shows how the
 step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS).
-  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead] [--trained]
+  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead | --ahead=D] [--trained]
 --exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
 all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
 rate when its share of the image is small."""
@@ -9,7 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]); streams = int(args[1]); steps = int(args[2]) if len(args) > 2 else 32
-exchange, trained, ahead = "--exchange" in sys.argv, "--trained" in sys.argv, "--ahead" in sys.argv
+exchange, trained = "--exchange" in sys.argv, "--trained" in sys.argv
+depth = max([int(a[len("--ahead="):]) for a in sys.argv if a.startswith("--ahead=")] + [1 if "--ahead" in sys.argv else 0])   # light passes ahead
+ahead = depth > 0
 os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)
 import __graft_entry__ as g
 p = g.load_package()
@@ -33,9 +35,9 @@ if exchange:
 rows = (0, H, N)
 if ahead:
     r.set_light_ahead(True)
-    r.launch("light trace", 1)
+    for k in range(depth): r.launch("light trace", 1 + k)
 def step(f):
-    r.launch("light trace", f + 2 if ahead else f + 1)
+    r.launch("light trace", f + 1 + depth)
     if ex is not None: ex.allgather_lvc()
     r.build_sampler(); r.launch("SPCBPT_eye", f, rows)
 for f in range(4): step(f)
@@ -43,7 +45,7 @@ r.sync()
 t0 = time.perf_counter()
 host = {"light": 0.0, "exchange": 0.0, "build": 0.0, "eye": 0.0}
 def timed_step(f):
-    a = time.perf_counter(); r.launch("light trace", f + 2 if ahead else f + 1)
+    a = time.perf_counter(); r.launch("light trace", f + 1 + depth)
     b = time.perf_counter()
     if ex is not None: ex.allgather_lvc()
     c2 = time.perf_counter(); r.build_sampler()
@@ -55,7 +57,7 @@ t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
 print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead' if ahead else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead=' + str(depth) if ahead else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

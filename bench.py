@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--render-streams", type=int, default=0,
                     help="frames in flight per GPU (0 = 2 on one GPU, 4 when the frame is sharded: a rank's share of a frame does not fill the GPU)")
     ap.add_argument("--write-image", default="")
+    ap.add_argument("--eye-batch", type=int, default=0,
+                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 1 on one GPU, 4 when the frame is sharded: a rank's share "
+                         "of a frame is about one tile per resident wave, several frames in one tile queue regenerate like one large frame")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -121,8 +124,10 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
 
-    streams = args.render_streams if args.render_streams > 0 else (4 if world > 1 else 2)
+    batch = args.eye_batch if args.eye_batch > 0 else (4 if world > 1 else 1)
+    streams = args.render_streams if args.render_streams > 0 else (2 if batch > 1 else (4 if world > 1 else 2))
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
+    os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets
     scene = make_scene(pkg, args.scene, args.tris)
     if args.scene_route == "gltf":
         # BASELINE config 2: "bedroom-class glTF scene" -- the generated scene goes to disk as glTF 2.0 (binary buffers + PPM
@@ -177,7 +182,19 @@ def main():
         if ex is not None:
             ex.allgather_lvc()
         r.build_sampler()
-        r.launch("SPCBPT_eye", f, rows)
+        if batch == 1:
+            r.launch("SPCBPT_eye", f, rows)
+        else:                                  # one persistent eye kernel per `batch` frames (tile queue spans the frames)
+            queued.append(f)
+            if len(queued) == batch:
+                flush()
+
+    queued = []
+
+    def flush():
+        if queued:
+            r.launch_eye_batch(queued, rows)
+            queued.clear()
 
     def barrier():
         if dist is not None:
@@ -188,6 +205,7 @@ def main():
     r.clear_accum()
     for f in range(args.warmup):
         step(f)
+    flush()
     # event counts of ONE launch of the dominant kernel -> algorithmic bytes per launch (untimed)
     r.sync()
     if not ahead:
@@ -211,8 +229,12 @@ def main():
     r.reset_kernel_time()
     for f in range(min(8, max(2, args.steps))):
         step(1000 + f)
-        r.sync()
+        if batch == 1 or not queued:      # batched: a sync after each launch = after every `batch` steps
+            r.sync()
+    flush()
+    r.sync()
     k_ms, k_n = r.kernel_time("spcbpt_render")
+    bytes_per_launch *= batch             # a batched launch renders `batch` frames (the last one of this pass may hold fewer)
     lt_ms, _ = r.kernel_time("light_trace")
     sb_ms, _ = r.kernel_time("sampler_build")
     cp_ms, _ = r.kernel_time("lvc_compact")
@@ -223,6 +245,7 @@ def main():
     t0 = time.perf_counter()
     for f in range(args.steps):
         step(f)
+    flush()
     if ex is not None:
         ex.reduce_framebuffer()
     barrier()
@@ -259,7 +282,7 @@ def main():
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams, "light_pass_ahead": bool(ahead), "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_pass_ahead": bool(ahead), "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -284,6 +284,15 @@ int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 int spcbpt_stream(spcbpt_ctx* ctx, void** stream);
 int spcbpt_sync(spcbpt_ctx* ctx);
 int spcbpt_sync_light(spcbpt_ctx* ctx);
+/* Batched eye launch (no reference counterpart): renders the samplers of the last n_frames spcbpt_build_sampler calls -- one
+ * frame each, oldest first, subframe index subframes[k] -- with ONE persistent kernel whose tile queue spans the frames, and
+ * merges them into the film in that order.  The result is that of n_frames spcbpt_launch("SPCBPT_eye") calls; the point is the
+ * drain phase of the megakernel, which is paid once per launch: a rank's eighth of a sharded frame is about one 8x8 tile per
+ * resident wave, i.e. nothing but drain.  n_frames <= 8 and <= the number of samplers built since and still intact
+ * (SPCBPT_ERR_STATE otherwise).  SPCBPT_EYE_BATCH = F in the environment at spcbpt_create sizes the ring of sampler buffer
+ * sets for batches of F, so that batches in flight, light passes ahead and builds never wait for a set. */
+int spcbpt_launch_eye_batch(spcbpt_ctx* ctx, int n_frames, const uint32_t* subframes, int row_begin, int row_end, int row_step);
+
 /* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain
  * however few paths a rank traces, and the LVC exchange makes the host wait for it; with on != 0 the host may launch frame
  * f + 1's "light trace" BEFORE it exchanges and builds frame f's: every light pass queues its buffer set, and

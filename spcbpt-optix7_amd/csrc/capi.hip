@@ -327,6 +327,7 @@ int Context::launch_light(uint32_t frame) {
     HIP_TRY(this, hipEventRecord(ev_light[lset], ls));
     light_counts_valid[lset] = true;
     light_lane_of_set[lset] = lane;
+    for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == lset) ? built_sets.erase(it) : it + 1;   // its sampler is gone
     if (!light_ahead) pending.clear();   // default: a sampler build always takes the latest light pass
     for (auto it = pending.begin(); it != pending.end();) it = (*it == lset) ? pending.erase(it) : it + 1;  // a set that comes round again unbuilt
     pending.push_back(lset);
@@ -389,6 +390,9 @@ int Context::build_sampler() {
     HIP_TRY(this, hipEventRecord(ev_sampler[eset], stream));
     ev_sampler_set[eset] = true;
     have_sampler = true;
+    for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == bset) ? built_sets.erase(it) : it + 1;
+    built_sets.push_back(bset);
+    while ((int)built_sets.size() > kMaxBatchFrames) built_sets.pop_front();
     if (!pending.empty() && pending.front() == bset) pending.pop_front();
     select_set(lset);   // the members name the latest light pass's set again
     return 0;
@@ -461,6 +465,76 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         ev_render_set[eset] = true;
     }
     return finish_frame();
+}
+
+int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, int rs) {
+    if (!d_accum) { error = "render before spcbpt_resize"; return SPCBPT_ERR_STATE; }
+    if (!have_camera) { error = "render before spcbpt_set_camera"; return SPCBPT_ERR_STATE; }
+    if (!have_subspace) { error = "SPCBPT_eye needs a subspace tuple and a built sampler"; return SPCBPT_ERR_STATE; }
+    if (n < 1 || n > kMaxBatchFrames || !subframes) { error = "launch_eye_batch: 1..8 frames"; return SPCBPT_ERR_INVALID_ARG; }
+    if (n > (int)built_sets.size()) { error = "launch_eye_batch: fewer samplers have been built (and are still intact) than frames were asked for"; return SPCBPT_ERR_STATE; }
+    // (SPCBPT_EYE_BATCH at spcbpt_create only sizes the ring of buffer sets so that batches, light passes ahead and builds do not
+    // wait for each other; correctness rests on the per-set events and on `built_sets` naming intact samplers)
+    if (!eye_megakernel || counting) { error = "launch_eye_batch: megakernel eye pass without counters only"; return SPCBPT_ERR_STATE; }
+    if (kp.width >= 65536u || kp.height >= 65536u) { error = "launch_eye_batch: image too large"; return SPCBPT_ERR_INVALID_ARG; }
+    if (rs < 1) rs = 1;
+    if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }
+    kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
+    kp.counters = nullptr;
+    rk = (rk + 1) % n_render;
+    rstream = rstreams[rk];
+    const size_t px = (size_t)kp.width * kp.height;
+    if (!h_frames) HIP_TRY(this, hipHostMalloc(reinterpret_cast<void**>(&h_frames), sizeof(FrameDesc) * kMaxRender * kDescRing * kMaxBatchFrames));
+    if (!d_frames[rk]) HIP_TRY(this, hipMalloc(reinterpret_cast<void**>(&d_frames[rk]), sizeof(FrameDesc) * kMaxBatchFrames));
+    // the descriptors travel through a small ring of pinned slots: the host must not wait for the previous batch of this stream
+    // (it would stop launching the light passes of the batches after it), only for the upload that used this slot 4 batches ago
+    const int gen = desc_gen[rk]++ % kDescRing;
+    FrameDesc* hf = h_frames + ((size_t)rk * kDescRing + gen) * kMaxBatchFrames;
+    if (ev_desc[rk][gen]) HIP_TRY(this, hipEventSynchronize(ev_desc[rk][gen]));
+    else HIP_TRY(this, hipEventCreateWithFlags(&ev_desc[rk][gen], hipEventDisableTiming));
+    int sets[kMaxBatchFrames];
+    for (int k = 0; k < n; k++) {
+        const int e = built_sets[built_sets.size() - (size_t)n + (size_t)k];   // oldest of the last n first
+        sets[k] = e;
+        if (!d_result_b[rk][k]) HIP_TRY(this, dev_alloc(&d_result_b[rk][k], px * 4));
+        hf[k].lvc = set_lvc[e]; hf[k].subspace = set_subspace[e]; hf[k].cmfs = set_cmfs[e];
+        hf[k].jump = reinterpret_cast<const int32_t*>(set_vals2[e]); hf[k].sampler_counts = set_counts[e];
+        hf[k].result = d_result_b[rk][k]; hf[k].subframe = subframes[k];
+        if (rstream != stream && ev_sampler_set[e]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[e], 0));
+    }
+    HIP_TRY(this, hipMemcpyAsync(d_frames[rk], hf, sizeof(FrameDesc) * (size_t)n, hipMemcpyHostToDevice, rstream));
+    HIP_TRY(this, hipEventRecord(ev_desc[rk][gen], rstream));
+    int rc = ensure_spill((size_t)render_thread_count(kp), true);
+    if (rc) return rc;
+    kp.n_tiles = (uint32_t)render_tile_count(kp);
+    kp.frames = d_frames[rk]; kp.n_frames = (uint32_t)n;
+    kp.work_counter = d_work_counter + rk;
+    kp.result = nullptr; kp.subframe = subframes[0];
+    HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
+    if (!blocks_per_cu[0]) blocks_per_cu[0] = spcbpt_blocks_per_cu(false);
+    int max_blocks = num_cus * blocks_per_cu[0];
+    // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile
+    const int percent = grid_percent > 0 ? grid_percent : 90;
+    if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
+    time_begin("spcbpt_render", rstream);
+    launch_spcbpt_batch(kp, max_blocks, rstream);
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    for (int k = 0; k < n; k++) { HIP_TRY(this, hipEventRecord(ev_render[sets[k]], rstream)); ev_render_set[sets[k]] = true; }
+    eset = sets[n - 1];
+    // the frames' merges, in frame order, after the previous launch's merge
+    if (last_merge_k >= 0 && last_merge_k != rk && rstreams[last_merge_k] != rstream) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_merge[last_merge_k], 0));
+    for (int k = 0; k < n; k++) {
+        kp.subframe = subframes[k];
+        kp.result = d_result_b[rk][k];
+        launch_film_merge(kp, rstream);
+        HIP_TRY(this, hipGetLastError());
+    }
+    kp.frames = nullptr; kp.n_frames = 0;
+    HIP_TRY(this, hipEventRecord(ev_merge[rk], rstream));
+    ev_merge_set[rk] = true;
+    last_merge_k = rk;
+    return 0;
 }
 
 // merge this launch's `result` into accum / frame, after the previous launch's merge (the only cross-frame ordering)
@@ -576,6 +650,9 @@ Context::~Context() {
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
     dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
+    for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
+    if (h_frames) (void)hipHostFree(h_frames);
+    for (int s2 = 0; s2 < kMaxRender; s2++) for (int g2 = 0; g2 < kDescRing; g2++) if (ev_desc[s2][g2]) (void)hipEventDestroy(ev_desc[s2][g2]);
     dev_free(b_scratch); dev_free(b_core_counts); dev_free(b_core_offsets); dev_free(b_keys); dev_free(b_vals); dev_free(b_weights); dev_free(b_temp); dev_free(b_spill);
     if (lstream_b) (void)hipStreamDestroy(lstream_b); dev_free(d_spill); dev_free(d_temp);
     for (int s = 0; s < kMaxRender; s++) {
@@ -646,7 +723,9 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         const char* nr = getenv("SPCBPT_RENDER_STREAMS");
         c->n_render = nr ? std::max(1, std::min((int)Context::kMaxRender, atoi(nr))) : 2;
         if (ov && std::string(ov) == "0") c->n_render = 1;
-        c->n_sets = std::min((int)Context::kMaxSets, c->n_render + 4);   // eye kernels in flight + up to three light passes ahead + the one being built
+        if (const char* eb = getenv("SPCBPT_EYE_BATCH")) c->eye_batch = std::max(1, std::min((int)kMaxBatchFrames, atoi(eb)));
+        // sets: one per frame of every eye launch in flight + the light passes ahead of them + the one being built
+        c->n_sets = std::min((int)Context::kMaxSets, c->eye_batch > 1 ? c->eye_batch * (c->n_render + 1) + 3 : c->n_render + 4);
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
             else if (use_prio) CREATE_TRY(hipStreamCreateWithPriority(&c->rstreams[s], hipStreamNonBlocking, prio_least));
@@ -820,6 +899,8 @@ int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
     dev_free(c->d_accum); dev_free(c->d_frame);
     HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
     HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
+    for (int s = 0; s < Context::kMaxRender; s++)
+        for (int k = 0; k < kMaxBatchFrames; k++) { dev_free(c->d_result_b[s][k]); c->d_result_b[s][k] = nullptr; }   // re-allocated at the new size on demand
     for (int s = 0; s < c->n_render; s++) {
         dev_free(c->d_result[s]);
         HIP_TRY(c, dev_alloc(&c->d_result[s], (size_t)w * h * 4));
@@ -854,6 +935,11 @@ int spcbpt_launch(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r
     if (alg == "pretrace") return c->launch_pretrace(frame);
     c->error = "unknown algorithm '" + alg + "' (expected \"pt\", \"light trace\", \"SPCBPT_eye\" or \"pretrace\")";
     return SPCBPT_ERR_UNKNOWN_ALG;
+}
+
+int spcbpt_launch_eye_batch(spcbpt_ctx* c, int n_frames, const uint32_t* subframes, int r0, int r1, int rs) {
+    CTX_CHECK(c);
+    return c->launch_eye_batch(n_frames, subframes, r0, r1, rs);
 }
 
 int spcbpt_build_sampler(spcbpt_ctx* c) {

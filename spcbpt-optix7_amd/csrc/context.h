@@ -35,7 +35,7 @@ struct Context {
     // tone map from `result` into accum/frame) are chained, by ev_merge, so the image is the same as with one stream.
     // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..8).  More frames in flight pay when one frame does not
     // fill the GPU -- a rank of an 8-GPU job renders 1/8 of the image but its frame still ends with the same 50-bounce chain.
-    static const int kMaxRender = 8, kMaxSets = kMaxRender + 1;
+    static const int kMaxRender = 8, kMaxSets = 20;
     int n_render = 2, n_sets = 6;   // n_sets = n_render + 4: one set per eye kernel in flight + the light passes ahead of them
     hipStream_t rstreams[kMaxRender] = {};
     int rk = 0, last_merge_k = -1;
@@ -163,6 +163,18 @@ struct Context {
     int fetch_counts_of(int set);
     int build_sampler();
     int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs);
+    // Batched eye launch (spcbpt_launch_eye_batch): the last n built samplers, one per frame, rendered by ONE persistent kernel
+    // whose tile queue spans the frames (kernels.hip: BATCH).  A rank's share of a sharded frame is a few thousand tiles --
+    // about one per resident wave, i.e. all drain phase; four frames in one queue regenerate like one frame four times the size.
+    std::deque<int> built_sets;                                  // sets of the most recent sampler builds, oldest first
+    int eye_batch = 1;                                           // frames per batched launch the context is sized for (SPCBPT_EYE_BATCH)
+    float* d_result_b[kMaxRender][kMaxBatchFrames] = {};         // per render stream and frame slot: radiance of that frame
+    FrameDesc* d_frames[kMaxRender] = {};                        // device copies of the batch descriptors
+    static const int kDescRing = 4;
+    FrameDesc* h_frames = nullptr;                               // pinned [kMaxRender][kDescRing][kMaxBatchFrames]: descriptor uploads in flight
+    hipEvent_t ev_desc[kMaxRender][kDescRing] = {};              // upload out of that pinned slot done
+    int desc_gen[kMaxRender] = {};
+    int launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, int rs);
     int finish_frame();
     // preprocess.hip
     Preprocessor* pre = nullptr;

@@ -843,6 +843,9 @@ SPC_DEV uint32_t quant8(float x) {
     x = clampf(x, 0.0f, 1.0f);
     return min((uint32_t)(x * 256.0f), 255u);
 }
+SPC_DEV void film_store(float* buf, uint32_t width, uint32_t x, uint32_t y, f3 result) {  // radiance of one frame's sample
+    reinterpret_cast<float4*>(buf)[(size_t)y * width + x] = make_float4(result.x, result.y, result.z, 1.0f);
+}
 SPC_DEV void film_write(const KParams& p, uint32_t x, uint32_t y, f3 result) {
     const size_t idx = (size_t)y * p.width + x;
     if (p.result) {  // deferred: k_film_merge applies the running mean and the tone map in frame order
@@ -865,13 +868,14 @@ SPC_DEV void film_write(const KParams& p, uint32_t x, uint32_t y, f3 result) {
                        (quant8(to_srgb(clampf(t.z, 0.f, 1.f))) << 16) | (255u << 24);
     }
 }
-SPC_DEV f3 camera_ray(const KParams& p, uint32_t x, uint32_t y, uint32_t& seed) {  // raygen.cu:332-343
-    seed = tea4(y * p.width + x, p.subframe);
+SPC_DEV f3 camera_ray(const KParams& p, uint32_t x, uint32_t y, uint32_t& seed, uint32_t subframe) {  // raygen.cu:332-343
+    seed = tea4(y * p.width + x, subframe);
     float jx = 0.5f, jy = 0.5f;
-    if (p.subframe != 0) { jx = rnd(seed); jy = rnd(seed); }
+    if (subframe != 0) { jx = rnd(seed); jy = rnd(seed); }
     const float dx = 2.0f * (((float)x + jx) / (float)p.width) - 1.0f;
     const float dy = 2.0f * (((float)y + jy) / (float)p.height) - 1.0f;
     return normalize(dx * ld3(p.U) + dy * ld3(p.V) + ld3(p.W));
 }
+SPC_DEV f3 camera_ray(const KParams& p, uint32_t x, uint32_t y, uint32_t& seed) { return camera_ray(p, x, y, seed, p.subframe); }
 
 }  // namespace spc

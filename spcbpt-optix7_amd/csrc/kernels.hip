@@ -44,7 +44,11 @@ SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
 // their last paths with ever fewer live lanes -- measured with the wave clocks of the counting build, the average wave has
 // left after 83 % of the kernel span.  Ordering the queue by the longest path each tile held in the previous frame did not
 // shorten that (long paths are decided by Russian roulette, not by the pixel).
-template <bool COUNT>
+// BATCH: the tiles of p.n_frames frames (same camera and bands, each with its own sampler tables, subframe index and result
+// buffer: p.frames) share one queue, so a wave keeps regenerating across frame boundaries and the drain phase is paid once per
+// batch instead of once per frame -- what a rank's small share of a sharded frame needs.  Every pixel-sample is computed exactly
+// as in a launch of its own frame; BATCH = false compiles to the single-frame kernel unchanged.
+template <bool COUNT, bool BATCH>
 __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     __shared__ float4 s_ray[(BLOCK / 64) * POOL_RAYS];
@@ -69,8 +73,9 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
     cn.clear();
     TravStack<BLOCK, STACK_LDS> st;
     st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
-    const int path_count = p.sampler_counts[1];
-    const uint32_t n_tiles = p.n_tiles;
+    const int path_count = BATCH ? 0 : p.sampler_counts[1];
+    const uint32_t n_tiles = BATCH ? p.n_tiles * p.n_frames : p.n_tiles;   // queue length
+    uint32_t fid = 0, pool_fid = 0, pend_fid = 0;   // frame of the lane's path / of the wave's current tile / of the parked pixel
 
     bool alive = false, exhausted = false;
     uint32_t pool_tile = 0;
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                 if (lane == (uint32_t)__ffsll((long long)idle) - 1u) t = atomicAdd(p.work_counter, 1u);
                 t = __shfl(t, __ffsll((long long)idle) - 1, 64);
                 if (t >= n_tiles) { exhausted = true; break; }
-                pool_tile = t;
+                pool_tile = BATCH ? t % p.n_tiles : t;
+                pool_fid = BATCH ? t / p.n_tiles : 0u;
                 pool_left = 64;
             }
             const int n_idle = __popcll(idle);
@@ -118,12 +124,13 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                 const uint32_t slot = (uint32_t)(64 - pool_left + my_rank);
                 uint32_t nx, ny;
                 if (tile_pixel(p, pool_tile, slot, nx, ny)) {
-                    if (alive) { pend_valid = true; pend_xy = x | (y << 16); pend_result = result; }
+                    if (alive) { pend_valid = true; pend_xy = x | (y << 16); pend_result = result; pend_fid = fid; }
                     x = nx; y = ny;
+                    fid = pool_fid;
                     alive = true;
                     has_ray = true;
                     fresh = true;
-                    w.dir = camera_ray(p, x, y, w.seed);
+                    w.dir = camera_ray(p, x, y, w.seed, BATCH ? p.frames[fid].subframe : p.subframe);
                     w.origin = ld3(p.eye);
                     w.done = false;
                     w.next_flux = mk3(0.0f);
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     col[9 * BLOCK] = __float_as_uint(cur.flux.x); col[10 * BLOCK] = __float_as_uint(cur.flux.y); col[11 * BLOCK] = __float_as_uint(cur.flux.z);
                     col[12 * BLOCK] = __float_as_uint(cur.R3.x); col[13 * BLOCK] = __float_as_uint(cur.R3.y); col[14 * BLOCK] = __float_as_uint(cur.R3.z);
                     col[15 * BLOCK] = __float_as_uint(cur.pdf); col[16 * BLOCK] = __float_as_uint(cur.singlePdf);
-                    col[17 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20);
+                    col[17 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | (fid << 28);
                     col[18 * BLOCK] = (uint32_t)cur.c.mat;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -198,10 +205,11 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     a.R3 = mk3(__uint_as_float(col[12 * BLOCK]), __uint_as_float(col[13 * BLOCK]), __uint_as_float(col[14 * BLOCK]));
                     a.pdf = __uint_as_float(col[15 * BLOCK]); a.singlePdf = __uint_as_float(col[16 * BLOCK]);
                     const uint32_t ids = col[17 * BLOCK];
-                    a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)(ids >> 20);
+                    a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)((ids >> 20) & 255u);
+                    const LightVertex* job_lvc = BATCH ? p.frames[ids >> 28].lvc : p.lvc;
                     a.c.mat = (int)col[18 * BLOCK];
                     LightVertex b;
-                    const float4* src = reinterpret_cast<const float4*>(p.lvc + w_slot[slot]);
+                    const float4* src = reinterpret_cast<const float4*>(job_lvc + w_slot[slot]);
                     float4* dst = reinterpret_cast<float4*>(&b);
 #pragma unroll
                     for (int q = 0; q < 6; q++) dst[q] = src[q];
@@ -228,7 +236,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             }
         }
         if (pend_valid) {
-            film_write(p, pend_xy & 0xffffu, pend_xy >> 16, pend_result);
+            if (BATCH) film_store(p.frames[pend_fid].result, p.width, pend_xy & 0xffffu, pend_xy >> 16, pend_result);
+            else film_write(p, pend_xy & 0xffffu, pend_xy >> 16, pend_result);
             pend_valid = false;
         }
         if (fresh) {  // init_EyeSubpath (raygen.cu:216-231)
@@ -261,23 +270,30 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419).  Only the
                     // position quad of the light vertex is fetched here (visibilityTest, cuProg.h:463-487); the connection
                     // itself does not consume random numbers, so drawing all three first leaves the RNG stream unchanged.
+                    const LightVertex* f_lvc = p.lvc; const DSubspace* f_subspace = p.subspace; const float* f_cmfs = p.cmfs;
+                    const int32_t* f_jump = p.jump;
+                    int f_path_count = path_count;
+                    if (BATCH) {   // the sampler tables of this path's frame
+                        const FrameDesc& D = p.frames[fid];
+                        f_lvc = D.lvc; f_subspace = D.subspace; f_cmfs = D.cmfs; f_jump = D.jump; f_path_count = D.sampler_counts[1];
+                    }
 #pragma unroll
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                         float pmf1, pmf2;
                         float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
                         const int l = sample_first_stage(p, cur.sub, w.seed, pmf1, cn);
-                        const DSubspace ss = p.subspace[l];
+                        const DSubspace ss = f_subspace[l];
                         if (ss.size != 0) {
-                            const int k = binary_sample(p.cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
-                            const int lslot = p.jump[ss.jump_bias + k];
+                            const int k = binary_sample(f_cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
+                            const int lslot = f_jump[ss.jump_bias + k];
                             w_slot[it * 64 + lane] = lslot;
                             cn.add(C_CONN);
-                            const float4 bq0 = reinterpret_cast<const float4*>(p.lvc + lslot)[0];
-                            const float4 bq1 = reinterpret_cast<const float4*>(p.lvc + lslot)[1];
+                            const float4 bq0 = reinterpret_cast<const float4*>(f_lvc + lslot)[0];
+                            const float4 bq1 = reinterpret_cast<const float4*>(f_lvc + lslot)[1];
                             const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
                             const float len = sqrtf(dot(bias, bias));
                             const f3 sdir = bias / len;
-                            w_pmf[it * 64 + lane] = (float)path_count * pmf2 * pmf1;
+                            w_pmf[it * 64 + lane] = (float)f_path_count * pmf2 * pmf1;
                             // a pair that faces away on either side has a BSDF factor of exactly zero (bsdf_eval / the one-sided
                             // emitter term of connect_vertices): its shadow ray cannot change the pixel and is not traced
                             if (!null_connection(cur.c.pos, cur.c.n, mk3(bq0.x, bq0.y, bq0.z), mk3(bq1.x, bq1.y, bq1.z)))
@@ -297,7 +313,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
             for (int it = 0; it < SPCBPT_CONNECTION_N; it++) w_ray[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, -1.0f);
         }
         if (alive && finished) {
-            film_write(p, x, y, result);
+            if (BATCH) film_store(p.frames[fid].result, p.width, x, y, result);
+            else film_write(p, x, y, result);
             alive = false;
         }
         SPC_PHASE(C_T_SHADE);
@@ -882,13 +899,21 @@ void launch_spcbpt(const KParams& p, bool count, int max_blocks, hipStream_t s) 
     if (tiles <= 0) return;
     int blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    if (count) hipLaunchKernelGGL(k_spcbpt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL(k_spcbpt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (count) hipLaunchKernelGGL((k_spcbpt<true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_spcbpt<false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+}
+// p.frames / p.n_frames describe the batch; p.n_tiles is the tile count of ONE frame
+void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
+    const long long tiles = (long long)p.n_tiles * p.n_frames;
+    if (tiles <= 0) return;
+    long long blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((k_spcbpt<false, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
 }
 int spcbpt_blocks_per_cu(bool count) {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true>, BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false>, BLOCK, 0);
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false>, BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false>, BLOCK, 0);
     return e == hipSuccess && n > 0 ? n : 1;
 }
 int render_tile_count(const KParams& p) {

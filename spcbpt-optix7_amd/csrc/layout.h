@@ -98,6 +98,19 @@ struct DeviceScene {
     int32_t n_mats;
 };
 
+// One frame of a batched eye launch (k_spcbpt<*, BATCH = true>): what differs between the frames that share a tile queue.
+struct FrameDesc {  // 64 B
+    const spcbpt_light_vertex* lvc;
+    const struct DSubspace* subspace;
+    const float* cmfs;
+    const int32_t* jump;
+    const int32_t* sampler_counts;
+    float* result;       // float4 per pixel: the radiance of this frame's samples (merged in frame order afterwards)
+    uint32_t subframe;
+    uint32_t pad[3];
+};
+static const int kMaxBatchFrames = 8;   // fid travels in 4 bits next to the pixel coordinates
+
 struct KParams {  // passed by value as the kernel argument block (the MyParams analogue)
     DeviceScene scene;
     float eye[3], U[3], V[3], W[3];
@@ -128,6 +141,8 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     // instrumentation / traversal scratch
     uint32_t* work_counter;        // tile queue head of the persistent megakernel (zeroed before each launch)
     uint32_t n_tiles;              // 8x8 pixel tiles in the selected bands
+    const FrameDesc* frames;       // batched launch: n_frames frames share the queue (tile t belongs to frame t / n_tiles)
+    uint32_t n_frames;
     unsigned long long* counters;  // C_COUNT slots or null
     uint32_t* spill;               // per-thread traversal stack overflow area
     int32_t spill_entries;         // entries per thread in `spill`

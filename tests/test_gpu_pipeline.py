@@ -90,3 +90,59 @@ def test_default_order_still_builds_the_latest_pass(gpu, pkg):
         r.launch("light trace", f + 1); r.build_sampler(); r.launch("SPCBPT_eye", f)
     r.sync()
     assert np.array_equal(r.read_accum(), want)
+
+
+def test_batched_eye_launch_equals_frame_by_frame(gpu, pkg):
+    """spcbpt_launch_eye_batch: several frames' tiles in one persistent kernel's queue.  Every pixel-sample is computed as in a
+    launch of its own frame, and the merges run in frame order: the film must match bit for bit, with full images, with
+    interleaved bands (a rank's share) and with a batch that is smaller than the one the context was sized for."""
+    import os
+    want, _ = _plain(pkg)                       # FRAMES = 5 frames, launch frames 1..5
+    os.environ["SPCBPT_EYE_BATCH"] = "4"
+    try:
+        r = _renderer(pkg)
+    finally:
+        del os.environ["SPCBPT_EYE_BATCH"]
+    done = []
+    for f in range(FRAMES):
+        r.launch("light trace", f + 1)
+        r.build_sampler()
+        done.append(f)
+        if len(done) == 3 or f == FRAMES - 1:   # batches of 3 and 2
+            r.launch_eye_batch(done)
+            done = []
+    r.sync()
+    assert np.array_equal(r.read_accum(), want)
+    # bands of a rank (every 3rd band from band 1) against the same bands rendered frame by frame
+    rows = (8, H, 3)
+    a = _renderer(pkg)
+    for f in range(4):
+        a.launch("light trace", f + 1); a.build_sampler(); a.launch("SPCBPT_eye", f, rows)
+    a.sync()
+    r.clear_accum()
+    for f in range(4):
+        r.launch("light trace", f + 1); r.build_sampler()
+    r.launch_eye_batch([0, 1, 2, 3], rows)
+    r.sync()
+    assert np.array_equal(r.read_accum(), a.read_accum())
+    # a context that was not sized for batches still renders them (its sets are guarded by events, not by the sizing)
+    a.clear_accum()
+    for f in range(2):
+        a.launch("light trace", f + 1); a.build_sampler()
+    a.launch_eye_batch([0, 1], rows)
+    b = _renderer(pkg)
+    for f in range(2):
+        b.launch("light trace", f + 1); b.build_sampler(); b.launch("SPCBPT_eye", f, rows)
+    a.sync(); b.sync()
+    assert np.array_equal(a.read_accum(), b.read_accum())
+    # errors: more frames than intact samplers, more than 8, a batch before any build
+    c = _renderer(pkg)
+    with pytest.raises(pkg.SpcbptError):
+        c.launch_eye_batch([0])
+    c.launch("light trace", 1); c.build_sampler()
+    with pytest.raises(pkg.SpcbptError):
+        c.launch_eye_batch([0, 1])
+    with pytest.raises(pkg.SpcbptError):
+        c.launch_eye_batch(list(range(9)))
+    c.launch_eye_batch([0])
+    c.sync()

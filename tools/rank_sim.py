@@ -1,6 +1,6 @@
 """What one rank of an N-GPU job does per frame, on one GPU: 1/N of the light cores, every N-th 8-row band.  Shows how the
 step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS).
-  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead | --ahead=D] [--trained]
+  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead | --ahead=D] [--batch=F] [--trained]
 --exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
 all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
 rate when its share of the image is small."""
@@ -12,6 +12,8 @@ N = int(args[0]); streams = int(args[1]); steps = int(args[2]) if len(args) > 2 
 exchange, trained = "--exchange" in sys.argv, "--trained" in sys.argv
 depth = max([int(a[len("--ahead="):]) for a in sys.argv if a.startswith("--ahead=")] + [1 if "--ahead" in sys.argv else 0])   # light passes ahead
 ahead = depth > 0
+batch = max([int(a[len("--batch="):]) for a in sys.argv if a.startswith("--batch=")] + [1])   # frames per eye launch
+if batch > 1: os.environ["SPCBPT_EYE_BATCH"] = str(batch)
 os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)
 import __graft_entry__ as g
 p = g.load_package()
@@ -36,10 +38,16 @@ rows = (0, H, N)
 if ahead:
     r.set_light_ahead(True)
     for k in range(depth): r.launch("light trace", 1 + k)
+queued = []
+def eye(f):
+    if batch == 1: r.launch("SPCBPT_eye", f, rows); return
+    queued.append(f)
+    if len(queued) == batch:
+        r.launch_eye_batch(queued, rows); queued.clear()
 def step(f):
     r.launch("light trace", f + 1 + depth)
     if ex is not None: ex.allgather_lvc()
-    r.build_sampler(); r.launch("SPCBPT_eye", f, rows)
+    r.build_sampler(); eye(f)
 for f in range(4): step(f)
 r.sync()
 t0 = time.perf_counter()
@@ -49,7 +57,7 @@ def timed_step(f):
     b = time.perf_counter()
     if ex is not None: ex.allgather_lvc()
     c2 = time.perf_counter(); r.build_sampler()
-    d = time.perf_counter(); r.launch("SPCBPT_eye", f, rows)
+    d = time.perf_counter(); eye(f)
     e = time.perf_counter()
     host["light"] += b - a; host["exchange"] += c2 - b; host["build"] += d - c2; host["eye"] += e - d
 for f in range(steps): timed_step(f)
@@ -57,7 +65,7 @@ t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
 print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead=' + str(depth) if ahead else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -269,7 +269,9 @@ def main():
     if rank == 0:
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
+        # the PMC passes behind that file profile the single-GPU default run (one whole frame per launch); a rank's share or a
+        # batched launch moves other amounts, and no counter run exists for those: null there
+        if os.path.exists(tfile) and world == 1 and batch == 1 and ex is None:
             try:
                 traffic = json.load(open(tfile)).get("spcbpt_render_hbm_bytes_per_launch")
             except Exception:

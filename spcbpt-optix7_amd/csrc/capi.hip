@@ -980,6 +980,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     c->set_count_host[b] = count;
     c->light_counts_valid[b] = false;
     c->light_lane_of_set[b] = 0;   // from here on the set's contents are ordered on `stream`
+    for (auto it = c->built_sets.begin(); it != c->built_sets.end();) it = (*it == b) ? c->built_sets.erase(it) : it + 1;   // a sampler built from the old contents is gone
     if (b == c->lset) c->lvc_count = count;
     if (c->keys_set == b) c->keys_ready = false;
     c->have_sampler = false;

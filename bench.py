@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--eye-batch", type=int, default=0,
                     help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 1 on one GPU, 4 when the frame is sharded: a rank's share "
                          "of a frame is about one tile per resident wave, several frames in one tile queue regenerate like one large frame")
+    ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     args = ap.parse_args()
@@ -167,6 +168,7 @@ def main():
     # dependent chain however few paths a rank traces, and it shares the GPU with the previous frame's eye kernel).  Every step still launches exactly one light pass, one exchange, one sampler build
     # and one eye pass; the light pass a step launches is consumed by the next step.
     ahead = not args.no_light_ahead
+    depth = args.light_ahead if args.light_ahead > 0 else (batch if batch > 1 else 1)
     state = {"next_light": 1, "primed": False}
     if ahead:
         r.set_light_ahead(True)
@@ -176,7 +178,8 @@ def main():
             r.launch("light trace", f + 1)
         else:
             if not state["primed"]:
-                r.launch("light trace", state["next_light"]); state["next_light"] += 1
+                for _ in range(depth):
+                    r.launch("light trace", state["next_light"]); state["next_light"] += 1
                 state["primed"] = True
             r.launch("light trace", state["next_light"]); state["next_light"] += 1   # consumed by the next step
         if ex is not None:
@@ -284,7 +287,7 @@ def main():
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_pass_ahead": bool(ahead), "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": depth if ahead else 0, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

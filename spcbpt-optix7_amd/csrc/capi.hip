@@ -725,7 +725,8 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         if (ov && std::string(ov) == "0") c->n_render = 1;
         if (const char* eb = getenv("SPCBPT_EYE_BATCH")) c->eye_batch = std::max(1, std::min((int)kMaxBatchFrames, atoi(eb)));
         // sets: one per frame of every eye launch in flight + the light passes ahead of them + the one being built
-        c->n_sets = std::min((int)Context::kMaxSets, c->eye_batch > 1 ? c->eye_batch * (c->n_render + 1) + 3 : c->n_render + 4);
+        c->n_sets = std::min((int)Context::kMaxSets, c->eye_batch > 1 ? c->eye_batch * (c->n_render + 2) + 3 : c->n_render + 4);   // batches in flight + one being built + a batch of light passes ahead
+        if (const char* ns = getenv("SPCBPT_SETS")) c->n_sets = std::max(3, std::min((int)Context::kMaxSets, atoi(ns)));   // developer knob
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
             else if (use_prio) CREATE_TRY(hipStreamCreateWithPriority(&c->rstreams[s], hipStreamNonBlocking, prio_least));

@@ -146,3 +146,77 @@ def test_batched_eye_launch_equals_frame_by_frame(gpu, pkg):
         c.launch_eye_batch(list(range(9)))
     c.launch_eye_batch([0])
     c.sync()
+
+
+def test_two_ranks_on_one_gpu_with_the_sharded_host_loop(gpu, pkg):
+    """The sharded job's host loop as bench.py runs it for world > 1 -- light passes launched ahead, export of the oldest pending
+    shard, gather, import without host waits, sampler build, several frames per eye launch on interleaved bands -- with two
+    contexts on one GPU standing in for two ranks (the all-gather is a device-side concatenation in rank order).  The sum of the
+    two films must equal the film of one context rendering whole frames the plain way, bit for bit."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    M, NF, WORLD, BATCH = 3000, 6, 2, 2
+    VB = pkg.dist.VERTEX_BYTES
+
+    def make(batch):
+        if batch > 1:
+            os.environ["SPCBPT_EYE_BATCH"] = str(batch)
+        try:
+            r = pkg.Renderer(scene, 0)
+        finally:
+            os.environ.pop("SPCBPT_EYE_BATCH", None)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+        r.resize(W, H)
+        r.set_light_trace(M, 64, 1)
+        r.set_subspace()
+        return r
+
+    single = make(1)
+    tup = single.get_subspace()
+    for f in range(NF):
+        single.launch("light trace", f + 1); single.build_sampler(); single.launch("SPCBPT_eye", f)
+    single.sync()
+    want = single.read_accum().copy()
+
+    ranks = []
+    for k in range(WORLD):
+        r = make(BATCH)
+        r.set_subspace(*tup)                                   # the broadcast tuple
+        b, c = pkg.dist.core_range(M, k, WORLD)
+        r.set_light_trace(M, 64, 1, core_begin=b, core_count=c)
+        r.set_light_ahead(True)
+        r.launch("light trace", 1)                             # the pass running ahead
+        ranks.append(r)
+    stage = [[None, None] for _ in range(WORLD)]
+    queued = []
+    for f in range(NF):
+        shards = []
+        for r in ranks:
+            r.launch("light trace", f + 2)
+            dv, dc, cap = r.lvc_export()
+            r.sync_light()
+            n = int(pkg.dist.device_view(dc, 8, dev).view(torch.int32)[0].item())
+            shards.append(pkg.dist.device_view(dv, n * VB, dev))
+        gathered = torch.cat(shards)                           # rank order = global (path, depth) order
+        total = gathered.numel() // VB
+        torch.cuda.current_stream(dev).synchronize()
+        for k, r in enumerate(ranks):
+            stage[k][f & 1] = gathered.clone()
+            torch.cuda.current_stream(dev).synchronize()
+            r.lvc_import_device(stage[k][f & 1].data_ptr(), total)
+            r.build_sampler()
+        queued.append(f)
+        if len(queued) == BATCH:
+            for k, r in enumerate(ranks):
+                r.launch_eye_batch(queued, pkg.dist.band_rows(H, k, WORLD))
+            queued = []
+    for r in ranks:
+        r.sync()
+    films = [r.read_accum() for r in ranks]
+    rows0 = pkg.dist.rows_of_rank(H, 0, WORLD)
+    rows1 = pkg.dist.rows_of_rank(H, 1, WORLD)
+    assert (films[0][rows1] == 0).all() and (films[1][rows0] == 0).all()      # a rank writes its own bands only
+    assert np.array_equal(films[0] + films[1], want)

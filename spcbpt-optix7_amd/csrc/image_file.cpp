@@ -44,6 +44,7 @@ struct Inflater {
     const uint8_t* p; const uint8_t* end;
     uint32_t bits = 0; int nbits = 0;
     bool bad = false;
+    size_t max_out = (size_t)1 << 31;   // the caller knows how many bytes the image needs: a stream that inflates to more is refused
     int bit() {
         if (nbits == 0) { if (p >= end) { bad = true; return 0; } bits = *p++; nbits = 8; }
         const int b = bits & 1; bits >>= 1; nbits--; return b;
@@ -126,6 +127,7 @@ struct Inflater {
                 }
                 while (!bad) {
                     const int sym = decode(lc);
+                    if (out.size() > max_out) return false;
                     if (sym < 256) out.push_back((uint8_t)sym);
                     else if (sym == 256) break;
                     else {
@@ -186,6 +188,7 @@ bool decode_png(const Bytes& file, Bytes& rgba, int& W, int& H) {
     Bytes raw;
     Inflater inf;
     inf.p = idat.data(); inf.end = idat.data() + idat.size();
+    inf.max_out = ((size_t)w * channels * depth / 8 + 9) * ((size_t)h + 7 * (interlace ? 1 : 0)) + 1024;   // every pass row: filter byte + samples
     if (!inf.run(raw)) return false;
     // samples of the whole image as 16-bit values (channel-interleaved), filled pass by pass
     std::vector<uint16_t> samp((size_t)w * h * channels);

@@ -173,7 +173,7 @@ def main():
     if ahead:
         r.set_light_ahead(True)
 
-    def step(f):
+    def step(f, isolate=False):
         if not ahead:
             r.launch("light trace", f + 1)
         else:
@@ -185,6 +185,8 @@ def main():
         if ex is not None:
             ex.allgather_lvc()
         r.build_sampler()
+        if isolate and (batch == 1 or len(queued) == batch - 1):
+            r.sync()                           # roofline pass: the light pass launched above must not share the GPU with the eye kernel
         if batch == 1:
             r.launch("SPCBPT_eye", f, rows)
         else:                                  # one persistent eye kernel per `batch` frames (tile queue spans the frames)
@@ -231,7 +233,7 @@ def main():
     r.enable_kernel_timing(True)
     r.reset_kernel_time()
     for f in range(min(8, max(2, args.steps))):
-        step(1000 + f)
+        step(1000 + f, isolate=True)
         if batch == 1 or not queued:      # batched: a sync after each launch = after every `batch` steps
             r.sync()
     flush()
@@ -295,7 +297,7 @@ def main():
             "kernels_ms": {"spcbpt_render": round(k_ms, 4), "light_trace": round(lt_ms, 4), "lvc_compact": round(cp_ms, 4),
                            "sampler_build": round(sb_ms, 4),
                            "spcbpt_render_span_in_timed_region": round(k_ms_overlapped, 4),
-                           "note": "HIP-event durations from a pass with one frame in flight (sync after each frame); in the timed "
+                           "note": "HIP-event durations from a pass with nothing else on the GPU (sync before and after each eye launch); in the timed "
                                    "region frames overlap (light pass of f+1 and eye kernel of f+1 under the drain of f), so the "
                                    "span of a kernel there includes sharing the GPU and ms_per_step is shorter than kernel_ms"},
             "events_per_eye_path": {k: round(v / max(c_eye["eye_paths"], 1), 3) for k, v in c_eye.items()

@@ -443,17 +443,18 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     }
     time_begin(name, rstream);
     if (spcbpt_alg) {
-        // Persistent grid.  With one render stream the kernel takes every resident block slot.  With several it takes 90 % of
+        // Persistent grid.  With one render stream the kernel takes every resident block slot.  With several it takes 94 % of
         // them: a persistent block never yields, so a full grid leaves the next frame's light pass (and through the host's
         // wait for its vertex count, the next eye launch) nothing to run on until whole blocks have drained; with a tenth of the
         // slots free the light pass runs at once and the two eye kernels share the machine from the start.  Measured on the
-        // bench scene, two streams: 248 -> 259.5 Mpaths/s at 90 %, 259 at 84 %, 257.5 at 75 %; the kernel by itself is 6 %
-        // slower at 90 % (8.5 instead of 8.0 ms).  A policy that looks whether the previous eye kernel is still running does
+        // bench scene, two streams, before the light pass ran ahead: 248 -> 259.5 Mpaths/s at 90 %, 259 at 84 %, 257.5 at 75 %; with
+        // the final host loop 259.4 at 100 %, 254 at 97 %, 263.5 at 94 %, 264 at 90 % -- and the kernel by itself takes 7.95 /
+        // 8.15 / 8.19 / 8.43 ms at those shares, so 94 % it is.  A policy that looks whether the previous eye kernel is still running does
         // not work: by the time the host has the vertex count it waited for, that kernel has drained.
         // SPCBPT_GRID_PERCENT fixes the share; SPCBPT_TILES_PER_WAVE bounds the waves by the tile count (experiments).
         int max_blocks = num_cus * blocks_per_cu[counting];
         if (tiles_per_wave > 1) max_blocks = std::max(1, std::min(max_blocks, (int)(kp.n_tiles / (uint32_t)(4 * tiles_per_wave))));
-        const int percent = grid_percent > 0 ? grid_percent : (n_render > 1 ? 90 : 100);
+        const int percent = grid_percent > 0 ? grid_percent : (n_render > 1 ? 94 : 100);
         if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
         launch_spcbpt(kp, counting, max_blocks, rstream);
     }
@@ -514,7 +515,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     if (!blocks_per_cu[0]) blocks_per_cu[0] = spcbpt_blocks_per_cu(false);
     int max_blocks = num_cus * blocks_per_cu[0];
     // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile
-    const int percent = grid_percent > 0 ? grid_percent : 90;
+    const int percent = grid_percent > 0 ? grid_percent : 94;
     if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
     time_begin("spcbpt_render", rstream);
     launch_spcbpt_batch(kp, max_blocks, rstream);

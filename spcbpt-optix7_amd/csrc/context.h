@@ -138,7 +138,7 @@ struct Context {
     bool eye_megakernel = true;        // SPCBPT_EYE_PASS=wavefront selects the per-phase kernels of wavefront.hip instead
     int wf_bounces_last = 0;           // bounces launched by the last wavefront frame (diagnostics)
     int num_cus = 0, blocks_per_cu[2] = {0, 0};
-    int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 90 with several render streams, else 100 (launch_render)
+    int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 94 with several render streams, else 100 (launch_render)
     int tiles_per_wave = 1;            // lower bound of 8x8 tiles per persistent wave (SPCBPT_TILES_PER_WAVE)
     unsigned long long* d_counters = nullptr;
     bool counting = false, timing = false;

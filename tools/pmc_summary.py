@@ -17,9 +17,9 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))   # the newest run
 summary = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*_ours.csv"))):
     agg = collections.defaultdict(list)
@@ -39,7 +39,7 @@ notes = ("FETCH_SIZE / WRITE_SIZE are in KB per launch, collected in separate --
          "uncalibrated for other patterns; this kernel issues scattered 16-B/lane gathers, so hbm bytes are reported as a "
          "range [FETCH_SIZE, 2*FETCH_SIZE] + WRITE_SIZE; Infinity-Cache hits are included in these memory-side counters.")
 out = {"tag": tag, "notes": notes, "kernels": summary}
-key = "spc::k_spcbpt<false>"
+key = next((k for k in ("spc::k_spcbpt<false, false>", "spc::k_spcbpt<false>") if k in summary), "")   # single-frame, non-counting
 if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[key]:
     f = summary[key]["FETCH_SIZE"]["avg_per_launch"] * 1024.0
     w = summary[key]["WRITE_SIZE"]["avg_per_launch"] * 1024.0

@@ -14,7 +14,7 @@ for set in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE GRBM_TA_BUSY" "TCP_TOTAL_
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "k_spcbpt<false>" in r["Kernel_Name"]:
+    if "k_spcbpt<false, false>" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print(k, "%.4g" % (sum(v) / len(v)))

@@ -13,7 +13,7 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    for tag in ("k_spcbpt<false>", "k_spcbpt<true>"):
+    for tag in ("k_spcbpt<false, false>", "k_spcbpt<true, false>"):
         if tag in r["Kernel_Name"]:
             agg[(r["Counter_Name"], tag)].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):

@@ -11,7 +11,7 @@ python3 - "$f" <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if "k_spcbpt<false>" in r["Kernel_Name"]:
+    if "k_spcbpt<false, false>" in r["Kernel_Name"]:
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in agg.items():
     print(k, "%.4g" % (sum(v) / len(v)), "n", len(v))

@@ -293,8 +293,12 @@ int Context::launch_light(uint32_t frame) {
     HIP_TRY(this, hipMemsetAsync(core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), ls));
     HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), ls));
     kp.path_counter = d_sampler_counts + 1;
+    // persistent grid of the light pass: at most light_blocks blocks pull cores from a queue (kernels.hip)
+    kp.work_counter = d_work_counter + kMaxRender + lane;
+    HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
+    if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus / 2); }
     time_begin("light_trace", ls);
-    launch_light_trace(kp, counting, ls);
+    launch_light_trace(kp, counting, light_blocks, ls);
     time_end();
     HIP_TRY(this, hipGetLastError());
     // compaction: exclusive scan of per-core counts (+1 sentinel gives the total) -> offsets
@@ -841,7 +845,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         const char* mode = getenv("SPCBPT_EYE_PASS");
         c->eye_megakernel = !(mode && std::string(mode) == "wavefront");
     }
-    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)Context::kMaxRender));
+    CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)Context::kMaxRender + 2));   // tile queues of the render streams + core queues of the two light lanes
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
     CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
     memset(&c->kp, 0, sizeof(c->kp));

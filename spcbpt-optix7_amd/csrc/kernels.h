@@ -13,7 +13,7 @@ int spcbpt_blocks_per_cu(bool count);
 int render_tile_count(const KParams& p);
 void launch_pt(const KParams& p, bool count, hipStream_t s);
 void launch_film_merge(const KParams& p, hipStream_t s);
-void launch_light_trace(const KParams& p, bool count, hipStream_t s);
+void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s);
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
                         LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);

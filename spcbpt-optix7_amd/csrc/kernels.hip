@@ -428,45 +428,89 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Light pass: one core per lane, each core walks m_per_core light paths and fills its own padded slot range, exactly the
-// launch geometry of LightTraceParams; the MI355X default is num_core = M, m_per_core = 1 (one path per lane).
+// Light pass.  A core walks m_per_core light paths and fills its own padded slot range, exactly the launch geometry of
+// LightTraceParams; the MI355X default is num_core = M, m_per_core = 1 (one path per core).  Persistent waves with per-lane
+// regeneration, like the eye pass: a lane whose core is finished takes the next core of a global queue at once (one atomic
+// per wave and refill), and every iteration of the wave advances all live paths by one segment.  Light paths end after 2.6
+// vertices on average but may run for 50, so one core per lane for the whole launch kept a wave resident for its longest
+// path with 1-2 live lanes; regenerating waves do the same work with a quarter of the resident blocks, which matters because
+// the pass shares the GPU with persistent eye kernels that never yield a block slot.  What a core computes and where it
+// stores it does not depend on the lane that runs it: seeds come from the global core index, slots from the core's range.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    const int local_core = blockIdx.x * BLOCK + threadIdx.x;
+    const DeviceScene& S = p.scene;
+    const uint32_t lane = threadIdx.x & 63;
     Counts<COUNT> cn;
     cn.clear();
+    TravStack<BLOCK, STACK_LDS> st;
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
     int paths_started = 0;
-    if (local_core < p.core_count) {
-        const DeviceScene& S = p.scene;
-        const int core = p.core_begin + local_core;
-        int origins = 0;
-        TravStack<BLOCK, STACK_LDS> st;
-        st.init(s_stack, p.spill, p.spill_entries, (size_t)local_core);
-        uint32_t seed = tea4((uint32_t)core, p.launch_frame);  // light sampling stream
-        // payload.seed: BSDF stream; the reference starts it equal to `seed`
-        uint32_t pseed = p.lt_decorrelate ? tea4((uint32_t)core ^ 0x80000000u, p.launch_frame) : seed;
-        LightVertex* slots = p.lvc_scratch + (size_t)local_core * p.core_padding;
-        int nverts = 0, npaths = 0;
-        auto store = [&](const LightVertex& v) {
-            float4* dst = reinterpret_cast<float4*>(slots + nverts);
-            const float4* src = reinterpret_cast<const float4*>(&v);
+    // per-core state
+    bool has_core = false, exhausted = false;
+    int local_core = 0, nverts = 0, npaths = 0, origins = 0;
+    uint32_t seed = 0, pseed = 0;
+    LightVertex* slots = nullptr;
+    // per-path state
+    bool in_path = false;
+    f3 origin = mk3(0.0f), dir = mk3(0.0f), next_flux = mk3(0.0f);
+    float next_single_pdf = 0.0f;
+    int depth = 0;
+    uint32_t path_id = 0;
+    LightVertex last;
+    uint32_t pool_base = 0;
+    int pool_left = 0;
+    auto store = [&](const LightVertex& v) {
+        float4* dst = reinterpret_cast<float4*>(slots + nverts);
+        const float4* src = reinterpret_cast<const float4*>(&v);
 #pragma unroll
-            for (int q = 0; q < 6; q++) dst[q] = src[q];
-            nverts++;
-            cn.add(C_LVCW);
-        };
-        while (true) {
+        for (int q = 0; q < 6; q++) dst[q] = src[q];
+        nverts++;
+        cn.add(C_LVCW);
+    };
+    while (true) {
+        // ---- regeneration: cores of the queue to lanes without one
+        unsigned long long idle = __ballot(!has_core);
+        while (idle != 0ull && !exhausted) {
+            if (pool_left == 0) {
+                uint32_t t = 0;
+                if (lane == (uint32_t)__ffsll((long long)idle) - 1u) t = atomicAdd(p.work_counter, 64u);
+                t = __shfl(t, __ffsll((long long)idle) - 1, 64);
+                if (t >= (uint32_t)p.core_count) { exhausted = true; break; }
+                pool_base = t;
+                pool_left = min(64, p.core_count - (int)t);
+            }
+            const int n_idle = __popcll(idle);
+            const int take = n_idle < pool_left ? n_idle : pool_left;
+            const int my_rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (!has_core && my_rank < take) {
+                local_core = (int)pool_base + my_rank;
+                has_core = true;
+                const int core = p.core_begin + local_core;
+                seed = tea4((uint32_t)core, p.launch_frame);  // light sampling stream
+                // payload.seed: BSDF stream; the reference starts it equal to `seed`
+                pseed = p.lt_decorrelate ? tea4((uint32_t)core ^ 0x80000000u, p.launch_frame) : seed;
+                slots = p.lvc_scratch + (size_t)local_core * p.core_padding;
+                nverts = 0; npaths = 0; origins = 0;
+                in_path = false;
+            }
+            pool_base += (uint32_t)take;
+            pool_left -= take;
+            idle = __ballot(!has_core);
+        }
+        if (!__any(has_core)) break;   // queue exhausted and every core of the wave finished
+        // ---- a core without a running path starts its next one: light sample + origin vertex (raygen.cu:620-668)
+        if (has_core && !in_path) {
             const int lid = pick_light(S, seed);
             const DLight& L = S.lights[lid];
             const float r1 = rnd(seed), r2 = rnd(seed);
             const LightSampleD ls = light_reverse_sample(S, L, r1, r2);
             const float d1 = rnd(seed), d2 = rnd(seed);  // traceMode
             const Onb onb(ls.normal);
-            f3 dir = onb.to_world(cosine_sample_hemisphere(d1, d2));
+            dir = onb.to_world(cosine_sample_hemisphere(d1, d2));
             const float dir_pdf = fabsf(dot(dir, ls.normal)) * kInvPi;
-            f3 origin = ls.position;
-            const uint32_t path_id = (uint32_t)core * (uint32_t)p.m_per_core + (uint32_t)npaths;
+            origin = ls.position;
+            path_id = (uint32_t)(p.core_begin + local_core) * (uint32_t)p.m_per_core + (uint32_t)npaths;
             cn.add(C_LIGHT);
             // origin vertex (init_vertex_from_lightSample raygen.cu:172-195)
             LightVertex v;
@@ -479,91 +523,103 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
             v.path_id = path_id; v.pad = 0;
             store(v);
             origins++;
-            if (!(nverts < p.core_padding)) break;
-            // walk (hit_program.cu:341-438)
-            f3 next_flux = mk3(0.0f);
-            float next_single_pdf = dir_pdf;
-            bool done = false, full = false;
-            int depth = 0;
-            LightVertex last = v;
-            while (true) {
-                HitRec h;
-                cn.add(C_CLOSEST);
-                if (!traverse<false, COUNT>(S, st, origin, dir, kEps, 1e16f, h, cn)) { done = true; }
-                else {
-                    const Geom g = local_geometry(S, h);
-                    if (g.emitter) { done = true; }  // __closesthit__lightSource_subpath
-                    else {
-                        Pbr pbr = load_pbr(S, g.mat);
-                        color_tex_sample(S, g, pbr, cn);
-                        f3 N = g.N;
-                        if (dot(N, dir) > 0.f) N = -N;
-                        const f3 inv_dir = -dir;
-                        const f3 new_dir = bsdf_sample(pbr, N, inv_dir, pseed);
-                        const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
-                        if (!(pdf > 0.0f)) done = true;
-                        const f3 last_n = ld3(last.normal), last_flux = ld3(last.flux);
-                        const float pdf_G = fabsf(dot(N, dir) * dot(last_n, dir)) / (h.t * h.t);
-                        const f3 flux = last.depth == 0 ? last_flux * pdf_G : next_flux * last_flux * pdf_G;
-                        LightVertex m;
-                        m.position[0] = g.P.x; m.position[1] = g.P.y; m.position[2] = g.P.z;
-                        m.normal[0] = N.x; m.normal[1] = N.y; m.normal[2] = N.z;
-                        m.flux[0] = flux.x; m.flux[1] = flux.y; m.flux[2] = flux.z;
-                        m.color[0] = pbr.base.x; m.color[1] = pbr.base.y; m.color[2] = pbr.base.z;
-                        m.last_position[0] = last.position[0]; m.last_position[1] = last.position[1]; m.last_position[2] = last.position[2];
-                        m.last_normal_projection = fabsf(dot(last_n, dir));
-                        m.material_id = (int16_t)g.mat;
-                        // light-tree label of the new vertex and eye-tree relabel of the previous one (tracing_weight_light) in lock-step
-                        int new_label, eye_label;
-                        const f3 last_pos = ld3(last.position);
-                        tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
-                                    new_label, eye_label, cn);
-                        m.subspace_id = (int16_t)new_label;
-                        m.last_zone_id = last.subspace_id;
-                        m.depth = (int16_t)(last.depth + 1);
-                        m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
-                        m.pdf = last.pdf * m.single_pdf;
-                        m.last_lum = sum3(last_flux / last.pdf);
-                        m.path_id = path_id; m.pad = 0;
-                        if (last.depth == 0) {
-                            m.rmis_pointer = last.rmis_pointer / last.single_pdf;  // tracing_init_light
-                        } else {  // tracing_update_light (rmis.h:80-94)
-                            const VCore lc = core_of(last);
-                            const Pbr mat_last = load_pbr_colored(S, lc.mat, lc.color);
-                            const f3 in_dir = normalize(g.P - lc.pos);
-                            const float LL_pdf = rmis_last_pdf(mat_last, lc, in_dir);
-                            const float wgt = rmis_weight_light_l(p, last.last_zone_id, last.last_lum, eye_label, cn);
-                            m.rmis_pointer = (last.rmis_pointer * LL_pdf + wgt) / last.single_pdf;
-                        }
-                        cn.add(C_VERTEX);
-                        next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
-                        next_single_pdf = pdf;
-                        origin = g.P;
-                        dir = new_dir;
-                        const float r = rnd(pseed);
-                        const float rr = rr_of(pbr.base);
-                        if (r > rr) done = true;
-                        else next_single_pdf *= rr;
-                        store(m);
-                        last = m;
-                        if (!(nverts < p.core_padding)) { full = true; break; }
-                    }
-                }
-                if (done || depth > 50) break;
-                depth += 1;
-            }
-            if (full) break;
-            npaths++;
-            if (npaths >= p.m_per_core) break;
-            if (!(nverts < p.core_padding)) break;
+            last = v;
+            next_flux = mk3(0.0f);
+            next_single_pdf = dir_pdf;
+            depth = 0;
+            in_path = nverts < p.core_padding;   // a full slot range ends the core right after the origin vertex
+            if (!in_path) { p.core_counts[local_core] = nverts; paths_started += origins; has_core = false; }
         }
-        p.core_counts[local_core] = nverts;
-        paths_started = origins;
+        // ---- one segment of every running path (hit_program.cu:341-438)
+        const bool tracing = has_core && in_path;
+        HitRec h;
+        h.tri = -1;
+        if (tracing) {
+            cn.add(C_CLOSEST);
+            traverse<false, COUNT>(S, st, origin, dir, kEps, 1e16f, h, cn);
+        }
+        if (tracing) {
+            bool done = false, full = false;
+            if (h.tri < 0) { done = true; }
+            else {
+                const Geom g = local_geometry(S, h);
+                if (g.emitter) { done = true; }  // __closesthit__lightSource_subpath
+                else {
+                    Pbr pbr = load_pbr(S, g.mat);
+                    color_tex_sample(S, g, pbr, cn);
+                    f3 N = g.N;
+                    if (dot(N, dir) > 0.f) N = -N;
+                    const f3 inv_dir = -dir;
+                    const f3 new_dir = bsdf_sample(pbr, N, inv_dir, pseed);
+                    const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
+                    if (!(pdf > 0.0f)) done = true;
+                    const f3 last_n = ld3(last.normal), last_flux = ld3(last.flux);
+                    const float pdf_G = fabsf(dot(N, dir) * dot(last_n, dir)) / (h.t * h.t);
+                    const f3 flux = last.depth == 0 ? last_flux * pdf_G : next_flux * last_flux * pdf_G;
+                    LightVertex m;
+                    m.position[0] = g.P.x; m.position[1] = g.P.y; m.position[2] = g.P.z;
+                    m.normal[0] = N.x; m.normal[1] = N.y; m.normal[2] = N.z;
+                    m.flux[0] = flux.x; m.flux[1] = flux.y; m.flux[2] = flux.z;
+                    m.color[0] = pbr.base.x; m.color[1] = pbr.base.y; m.color[2] = pbr.base.z;
+                    m.last_position[0] = last.position[0]; m.last_position[1] = last.position[1]; m.last_position[2] = last.position[2];
+                    m.last_normal_projection = fabsf(dot(last_n, dir));
+                    m.material_id = (int16_t)g.mat;
+                    // light-tree label of the new vertex and eye-tree relabel of the previous one (tracing_weight_light) in lock-step
+                    int new_label, eye_label;
+                    const f3 last_pos = ld3(last.position);
+                    tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
+                                new_label, eye_label, cn);
+                    m.subspace_id = (int16_t)new_label;
+                    m.last_zone_id = last.subspace_id;
+                    m.depth = (int16_t)(last.depth + 1);
+                    m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
+                    m.pdf = last.pdf * m.single_pdf;
+                    m.last_lum = sum3(last_flux / last.pdf);
+                    m.path_id = path_id; m.pad = 0;
+                    if (last.depth == 0) {
+                        m.rmis_pointer = last.rmis_pointer / last.single_pdf;  // tracing_init_light
+                    } else {  // tracing_update_light (rmis.h:80-94)
+                        const VCore lc = core_of(last);
+                        const Pbr mat_last = load_pbr_colored(S, lc.mat, lc.color);
+                        const f3 in_dir = normalize(g.P - lc.pos);
+                        const float LL_pdf = rmis_last_pdf(mat_last, lc, in_dir);
+                        const float wgt = rmis_weight_light_l(p, last.last_zone_id, last.last_lum, eye_label, cn);
+                        m.rmis_pointer = (last.rmis_pointer * LL_pdf + wgt) / last.single_pdf;
+                    }
+                    cn.add(C_VERTEX);
+                    next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
+                    next_single_pdf = pdf;
+                    origin = g.P;
+                    dir = new_dir;
+                    const float r = rnd(pseed);
+                    const float rr = rr_of(pbr.base);
+                    if (r > rr) done = true;
+                    else next_single_pdf *= rr;
+                    store(m);
+                    last = m;
+                    if (!(nverts < p.core_padding)) full = true;
+                }
+            }
+            // the walk loop's exit tests (raygen.cu:646-676): slot range full -> the core ends; path done or too deep -> next path
+            bool path_over = full;
+            if (!full) {
+                if (done || depth > 50) path_over = true;
+                else depth += 1;
+            }
+            if (path_over) {
+                in_path = false;
+                bool core_over = full;
+                if (!full) {
+                    npaths++;
+                    if (npaths >= p.m_per_core || !(nverts < p.core_padding)) core_over = true;
+                }
+                if (core_over) { p.core_counts[local_core] = nverts; paths_started += origins; has_core = false; }
+            }
+        }
     }
-    // path_count of the sampler (#depth-0 vertices, device_thrust.cu:324-326): one atomic per wave, spread over the
-    // kernel's run time (a same-address atomic costs ~11 ns; per-wave atomics in the compaction kernel cost 0.9 ms)
+    // path_count of the sampler (#depth-0 vertices, device_thrust.cu:324-326): one atomic per wave
     for (int o = 32; o > 0; o >>= 1) paths_started += __shfl_down(paths_started, o, 64);
-    if ((threadIdx.x & 63) == 0 && paths_started) atomicAdd(p.path_counter, paths_started);
+    if (lane == 0 && paths_started) atomicAdd(p.path_counter, paths_started);
     cn.flush(p.counters);
 }
 
@@ -945,9 +1001,10 @@ void launch_pt(const KParams& p, bool count, hipStream_t s) {
     if (count) hipLaunchKernelGGL(k_pt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL(k_pt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
 }
-void launch_light_trace(const KParams& p, bool count, hipStream_t s) {
-    const int blocks = (p.core_count + BLOCK - 1) / BLOCK;
+void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s) {
+    int blocks = (p.core_count + BLOCK - 1) / BLOCK;   // p.work_counter (the core queue head) must have been zeroed on `s`
     if (blocks <= 0) return;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     if (count) hipLaunchKernelGGL(k_light_trace<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL(k_light_trace<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
 }

@@ -89,8 +89,9 @@ def main():
                     help="frames in flight per GPU (0 = 2 on one GPU, 4 when the frame is sharded: a rank's share of a frame does not fill the GPU)")
     ap.add_argument("--write-image", default="")
     ap.add_argument("--eye-batch", type=int, default=0,
-                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 1 on one GPU, 4 when the frame is sharded: a rank's share "
-                         "of a frame is about one tile per resident wave, several frames in one tile queue regenerate like one large frame")
+                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 4: several frames in one tile queue pay the drain phase of the "
+                         "persistent kernel once (and a rank's share of a sharded frame is about one tile per resident wave: all drain); "
+                         "1 = one launch per frame")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
@@ -125,8 +126,8 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
 
-    batch = args.eye_batch if args.eye_batch > 0 else (4 if world > 1 else 1)
-    streams = args.render_streams if args.render_streams > 0 else (2 if batch > 1 else (4 if world > 1 else 2))
+    batch = args.eye_batch if args.eye_batch > 0 else 4
+    streams = args.render_streams if args.render_streams > 0 else 2
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets
     scene = make_scene(pkg, args.scene, args.tris)
@@ -276,9 +277,11 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         # the PMC passes behind that file profile the single-GPU default run (one whole frame per launch); a rank's share or a
         # batched launch moves other amounts, and no counter run exists for those: null there
-        if os.path.exists(tfile) and world == 1 and batch == 1 and ex is None:
+        if os.path.exists(tfile) and world == 1 and ex is None:
             try:
-                traffic = json.load(open(tfile)).get("spcbpt_render_hbm_bytes_per_launch")
+                t = json.load(open(tfile))
+                if int(t.get("frames_per_launch", 1)) == batch:
+                    traffic = t.get("spcbpt_render_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

@@ -39,13 +39,15 @@ notes = ("FETCH_SIZE / WRITE_SIZE are in KB per launch, collected in separate --
          "uncalibrated for other patterns; this kernel issues scattered 16-B/lane gathers, so hbm bytes are reported as a "
          "range [FETCH_SIZE, 2*FETCH_SIZE] + WRITE_SIZE; Infinity-Cache hits are included in these memory-side counters.")
 out = {"tag": tag, "notes": notes, "kernels": summary}
-key = next((k for k in ("spc::k_spcbpt<false, false>", "spc::k_spcbpt<false>") if k in summary), "")   # single-frame, non-counting
+# the dominant kernel of the run: the batched instantiation when the run used it, else the single-frame one (non-counting)
+key = next((k for k in ("spc::k_spcbpt<false, true>", "spc::k_spcbpt<false, false>", "spc::k_spcbpt<false>") if k in summary and "FETCH_SIZE" in summary[k]), "")
+frames_per_launch = int(os.environ.get("FRAMES_PER_LAUNCH", "4" if key.endswith("<false, true>") else "1"))
 if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[key]:
     f = summary[key]["FETCH_SIZE"]["avg_per_launch"] * 1024.0
     w = summary[key]["WRITE_SIZE"]["avg_per_launch"] * 1024.0
     out["spcbpt_render_hbm_bytes_per_launch_low"] = f + w
     out["spcbpt_render_hbm_bytes_per_launch_high"] = 2 * f + w
-    json.dump({"tag": tag, "spcbpt_render_hbm_bytes_per_launch": 2 * f + w,
+    json.dump({"tag": tag, "kernel": key, "frames_per_launch": frames_per_launch, "spcbpt_render_hbm_bytes_per_launch": 2 * f + w,
                "definition": "2*FETCH_SIZE + WRITE_SIZE (KB*1024) per k_spcbpt<false> launch, gfx950 FETCH_SIZE half-count correction applied; "
                              "uncorrected lower bound = FETCH_SIZE + WRITE_SIZE = %.4g" % (f + w)},
               open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
+os.environ.setdefault("SPCBPT_EYE_BATCH", "4")   # the timing loop below batches eye launches like bench.py
 import __graft_entry__ as g
 p = g.load_package()
 tag = sys.argv[1]
@@ -36,12 +37,29 @@ def mean_image(alg, first, n):
     return (tot / n).cpu().numpy()
 
 def frame_ms(alg, frames=24):
-    for s in range(3):
-        r.render_frame(alg, s, launch_frame=s + 1)
+    """ms per frame in the host loop bench.py runs: "pt" frame by frame; "SPCBPT_eye" with the light pass launched a batch ahead
+    and 4 frames per eye launch"""
+    def loop(n):
+        if alg != "SPCBPT_eye":
+            for s in range(n): r.render_frame(alg, s)
+            return
+        r.set_light_ahead(True)
+        nxt = 1
+        for _ in range(4):
+            r.launch("light trace", nxt); nxt += 1
+        queued = []
+        for s in range(n):
+            r.launch("light trace", nxt); nxt += 1
+            r.build_sampler()
+            queued.append(s)
+            if len(queued) == 4 or s == n - 1:
+                r.launch_eye_batch(queued); queued = []
+        r.sync()
+        r.set_light_ahead(False)
+    loop(4)
     r.sync(); torch.cuda.synchronize()
     t = time.perf_counter()
-    for s in range(frames):
-        r.render_frame(alg, s, launch_frame=s + 1)
+    loop(frames)
     r.sync(); torch.cuda.synchronize()
     return (time.perf_counter() - t) / frames * 1e3
 

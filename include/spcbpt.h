@@ -299,6 +299,10 @@ int spcbpt_launch_eye_batch(spcbpt_ctx* ctx, int n_frames, const uint32_t* subfr
  * spcbpt_lvc_export / spcbpt_lvc_import / spcbpt_sync_light / spcbpt_build_sampler address the OLDEST queued pass (sync_light
  * then waits for that pass only, not for the stream).  Off (default): they address the latest light pass. */
 int spcbpt_set_light_ahead(spcbpt_ctx* ctx, int on);
+/* spcbpt_lvc_import(..., is_device = 1) reads its source asynchronously (on the light stream, possibly behind light passes launched
+ * ahead).  A host that alternates TWO staging buffers calls this before it overwrites one of them: it returns when the import
+ * before the previous one -- the last reader of that buffer -- has copied. */
+int spcbpt_lvc_import_wait(spcbpt_ctx* ctx);
 
 /* Kernel timing measured with HIP events on the context's stream: average
  * milliseconds per launch of `name` since the last reset, and launch count. */

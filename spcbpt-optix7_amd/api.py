@@ -444,6 +444,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_sync": [vp],
         "spcbpt_sync_light": [vp],
         "spcbpt_set_light_ahead": [vp, i32],
+        "spcbpt_lvc_import_wait": [vp],
         "spcbpt_kernel_time": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i32)],
         "spcbpt_reset_kernel_time": [vp],
         "spcbpt_enable_kernel_timing": [vp, i32],
@@ -502,7 +503,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
-    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_kernel_time",
+    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -703,6 +704,10 @@ class Renderer:
     def set_light_ahead(self, on: bool):
         """Light passes may be launched one frame ahead of their exchange / sampler build (see spcbpt_set_light_ahead)."""
         self._chk(self.lib.spcbpt_set_light_ahead(self.h, int(on)), "set_light_ahead")
+
+    def lvc_import_wait(self):
+        """Before overwriting one of two alternating device staging buffers of lvc_import_device (spcbpt_lvc_import_wait)."""
+        self._chk(self.lib.spcbpt_lvc_import_wait(self.h), "lvc_import_wait")
 
     def sync_light(self):
         self._chk(self.lib.spcbpt_sync_light(self.h), "sync_light")

@@ -657,6 +657,7 @@ Context::~Context() {
     dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
     for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
     if (h_frames) (void)hipHostFree(h_frames);
+    for (int g2 = 0; g2 < 2; g2++) if (ev_import[g2]) (void)hipEventDestroy(ev_import[g2]);
     for (int s2 = 0; s2 < kMaxRender; s2++) for (int g2 = 0; g2 < kDescRing; g2++) if (ev_desc[s2][g2]) (void)hipEventDestroy(ev_desc[s2][g2]);
     dev_free(b_scratch); dev_free(b_core_counts); dev_free(b_core_offsets); dev_free(b_keys); dev_free(b_vals); dev_free(b_weights); dev_free(b_temp); dev_free(b_spill);
     if (lstream_b) (void)hipStreamDestroy(lstream_b); dev_free(d_spill); dev_free(d_temp);
@@ -983,6 +984,12 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     // waited for with spcbpt_sync_light (dist.py alternates two staging buffers, which covers a light pass running one frame
     // ahead).  The render streams are never waited for: the set written here is not one an eye kernel in flight reads.
     if (!is_device) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    else {   // spcbpt_lvc_import_wait: when may the staging buffer of the import before the previous one be written again
+        hipEvent_t& ev = c->ev_import[c->import_gen & 1];
+        if (!ev) HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(ev, c->stream));
+        c->import_gen++;
+    }
     c->set_count_host[b] = count;
     c->light_counts_valid[b] = false;
     c->light_lane_of_set[b] = 0;   // from here on the set's contents are ordered on `stream`
@@ -1100,6 +1107,15 @@ int spcbpt_set_light_ahead(spcbpt_ctx* c, int on) {
     if (c->sync_all()) return SPCBPT_ERR_HIP;
     c->light_ahead = on != 0;
     c->pending.clear();
+    return SPCBPT_OK;
+}
+
+// A host that alternates two device staging buffers for spcbpt_lvc_import calls this before it overwrites one: it returns when
+// the import copy that read that buffer (the import before the previous one) has run.  The copies are queued on the light
+// stream behind whatever light passes were launched ahead, so no other wait of the exchange sequence implies this.
+int spcbpt_lvc_import_wait(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    if (c->import_gen >= 2 && c->ev_import[c->import_gen & 1]) HIP_TRY(c, hipEventSynchronize(c->ev_import[c->import_gen & 1]));
     return SPCBPT_OK;
 }
 

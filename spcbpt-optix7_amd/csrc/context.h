@@ -55,6 +55,8 @@ struct Context {
     int set_count_host[kMaxSets];            // vertex count of the set when the host knows it (after an import), else -1
     bool light_counts_valid[kMaxSets] = {};  // h_light_counts of the set describe its current contents
     int keys_set = -1;                       // the set whose compaction left d_keys / d_vals / d_weights (valid if keys_ready)
+    hipEvent_t ev_import[2] = {};            // device-to-device import copies done (alternating: the caller alternates two staging buffers)
+    long long import_gen = 0;
     int* h_import_counts = nullptr;          // pinned [kMaxSets][2]: source of the counts upload of an import (no host wait)
     int* h_light_counts = nullptr;           // pinned [kMaxSets][2]: (vertex_count, path_count) of a light pass, written on `stream`
                                              // before ev_light -- the host reads them after waiting for that event only

@@ -143,6 +143,8 @@ class FrameExchanger:
         total = sum(counts)
         k2 = self.frame & 1
         self.frame += 1
+        r.lvc_import_wait()   # the import two frames ago read staging buffer k2 asynchronously: it must have copied before the
+                              # buffer is rewritten (or re-allocated) below
         if self.cat_bufs[k2] is None or self.cat_bufs[k2].numel() < total * VERTEX_BYTES:
             self.cat_bufs[k2] = torch.empty(max(total, 1) * VERTEX_BYTES * 5 // 4, dtype=torch.uint8, device=self.device)
         cat = self.cat_bufs[k2]

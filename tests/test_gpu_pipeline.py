@@ -70,6 +70,7 @@ def test_ahead_with_export_and_device_import(gpu, pkg):
         n = int(pkg.dist.device_view(dc, 8, dev).view(torch.int32)[0].item())
         assert n == len(lvcs[f])
         shard = pkg.dist.device_view(dv, n * pkg.dist.VERTEX_BYTES, dev)
+        r.lvc_import_wait()                                                 # the import that read stage[f & 1] has copied
         stage[f & 1] = shard.clone()
         torch.cuda.current_stream(dev).synchronize()
         r.lvc_import_device(stage[f & 1].data_ptr(), n)
@@ -204,6 +205,7 @@ def test_two_ranks_on_one_gpu_with_the_sharded_host_loop(gpu, pkg):
         total = gathered.numel() // VB
         torch.cuda.current_stream(dev).synchronize()
         for k, r in enumerate(ranks):
+            r.lvc_import_wait()
             stage[k][f & 1] = gathered.clone()
             torch.cuda.current_stream(dev).synchronize()
             r.lvc_import_device(stage[k][f & 1].data_ptr(), total)

@@ -36,6 +36,7 @@ def allgather(self):
     out = self.gather_buf[: self.world * nbytes]
     dist.all_gather_into_tensor(out, shard); t = tick("gather shards", t)
     total = sum(counts); k2 = self.frame & 1; self.frame += 1
+    r.lvc_import_wait()
     if self.cat_bufs[k2] is None or self.cat_bufs[k2].numel() < total * VB:
         self.cat_bufs[k2] = torch.empty(max(total, 1) * VB * 5 // 4, dtype=torch.uint8, device=dev)
     cat = self.cat_bufs[k2]; off = 0

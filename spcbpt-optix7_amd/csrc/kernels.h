@@ -32,8 +32,8 @@ void launch_wf_bounce(const KParams& p, const WfState& wf, int bounce, bool coun
 void launch_wf_film(const KParams& p, const WfState& wf, hipStream_t s);
 
 #ifndef SPC_STACK_LDS
-#define SPC_STACK_LDS 20
+#define SPC_STACK_LDS 16
 #endif
-static const int kStackLds = SPC_STACK_LDS;  // LDS traversal-stack entries per lane (20 KB per block); with the 16.4 KB shadow-ray pool of k_spcbpt four blocks fit a CU
+static const int kStackLds = SPC_STACK_LDS;  // LDS traversal-stack entries per lane (16 KB per block): with the ray pool and the connection tables of k_spcbpt a block takes 40 464 B and four blocks fit the 160 KB of a CU; deeper stacks spill to HBM (TravStack)
 
 }  // namespace spc

@@ -15,12 +15,22 @@ namespace spc {
 
 static constexpr int BLOCK = 256;
 static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
-static_assert(STACK_LDS >= 19, "the pooled connections publish 19 dwords per eye vertex through the traversal-stack LDS");
+static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye vertex through the traversal-stack LDS");
 #ifndef SPC_WAVES
-// minimum waves per SIMD requested from the register allocator for the megakernel.  Measured on MI355X (bedroom 1080p, ms per
-// frame) with the pooled if-if traversal: 2 (241 VGPR, no scratch) -> 12.86, 3 (168 VGPR, 252 B scratch) -> 10.72,
-// 4 (128 VGPR, 452 B) -> 11.01, 5 (96 VGPR, 688 B) -> 14.16.  (Before the pooled traversal 4 was the optimum.)
-#define SPC_WAVES 3
+// minimum waves per SIMD requested from the register allocator for the other kernels of this file.  4 like the eye kernel, and for
+// its sake: with three 128-VGPR eye blocks resident on a CU, 128 registers per lane are what is left -- a light-pass block that
+// wants 154 would only fit on CUs holding two eye blocks or fewer and starve next to a persistent eye kernel (measured: the step
+// got SLOWER with the faster eye kernel until the light pass was compiled to fit)
+#define SPC_WAVES 4
+#endif
+#ifndef SPC_EYE_WAVES
+// ... and for the eye megakernel.  Measured on MI355X (bedroom 1080p, ms per frame).  With the pooled if-if traversal, one frame
+// per launch: 2 (241 VGPR, no scratch) -> 12.86, 3 (168 VGPR, 252 B scratch) -> 10.72, 4 (128 VGPR, 452 B) -> 11.01,
+// 5 (96 VGPR, 688 B) -> 14.16.  With pooled connections, immediate regeneration and batched launches the balance moved: the
+// kernel is bound by the latency of dependent gathers (its throughput is 1 : 1.71 : 2.20 at 1, 2, 3 resident blocks per CU),
+// and 4 (128 VGPR, 372 B scratch) gives 25.9 instead of 28.4 ms per 4-frame launch -- provided the block fits 4 times into
+// the 160 KB of LDS, hence the 16-entry stack and the three eye-vertex dwords that travel by ds_bpermute instead (below).
+#define SPC_EYE_WAVES 4
 #endif
 
 // pixel of this lane: 8x8 tile per wave, 4 tiles (in x) per block, bands of 8 rows selected by (row_begin, row_step)
@@ -49,7 +59,7 @@ SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
 // batch instead of once per frame -- what a rank's small share of a sharded frame needs.  Every pixel-sample is computed exactly
 // as in a launch of its own frame; BATCH = false compiles to the single-frame kernel unchanged.
 template <bool COUNT, bool BATCH>
-__global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
+__global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     __shared__ float4 s_ray[(BLOCK / 64) * POOL_RAYS];
     __shared__ float4 s_org[BLOCK];
@@ -184,16 +194,20 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     col[3 * BLOCK] = __float_as_uint(cur.c.color.x); col[4 * BLOCK] = __float_as_uint(cur.c.color.y); col[5 * BLOCK] = __float_as_uint(cur.c.color.z);
                     col[6 * BLOCK] = __float_as_uint(cur.c.lastPos.x); col[7 * BLOCK] = __float_as_uint(cur.c.lastPos.y); col[8 * BLOCK] = __float_as_uint(cur.c.lastPos.z);
                     col[9 * BLOCK] = __float_as_uint(cur.flux.x); col[10 * BLOCK] = __float_as_uint(cur.flux.y); col[11 * BLOCK] = __float_as_uint(cur.flux.z);
-                    col[12 * BLOCK] = __float_as_uint(cur.R3.x); col[13 * BLOCK] = __float_as_uint(cur.R3.y); col[14 * BLOCK] = __float_as_uint(cur.R3.z);
-                    col[15 * BLOCK] = __float_as_uint(cur.pdf); col[16 * BLOCK] = __float_as_uint(cur.singlePdf);
-                    col[17 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | (fid << 28);
-                    col[18 * BLOCK] = (uint32_t)cur.c.mat;
+                    col[12 * BLOCK] = __float_as_uint(cur.pdf); col[13 * BLOCK] = __float_as_uint(cur.singlePdf);
+                    col[14 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | (fid << 28);
+                    col[15 * BLOCK] = (uint32_t)cur.c.mat;
+                    // (RMIS_pointer_3 does not fit the 16 stack entries four resident blocks leave: it travels by ds_bpermute below)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (uint32_t j = lane; j < n_jobs; j += 64u) {
-                    const uint32_t slot = w_job[j], owner = slot & 63u;
+                for (uint32_t base = 0; base < n_jobs; base += 64u) {   // wave-uniform: the shuffles below need every lane
+                    const uint32_t j = base + lane;
+                    const bool job = j < n_jobs;
+                    const uint32_t slot = job ? w_job[j] : 0u, owner = slot & 63u;
+                    const f3 ownerR3 = mk3(__shfl(cur.R3.x, (int)owner, 64), __shfl(cur.R3.y, (int)owner, 64), __shfl(cur.R3.z, (int)owner, 64));
+                    if (!job) continue;
                     const uint32_t* col = w_stack + owner;
                     const float4 po = w_org[owner];
                     EyeVertex a;
@@ -202,12 +216,12 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_spcbpt(const KParams p) {
                     a.c.color = mk3(__uint_as_float(col[3 * BLOCK]), __uint_as_float(col[4 * BLOCK]), __uint_as_float(col[5 * BLOCK]));
                     a.c.lastPos = mk3(__uint_as_float(col[6 * BLOCK]), __uint_as_float(col[7 * BLOCK]), __uint_as_float(col[8 * BLOCK]));
                     a.flux = mk3(__uint_as_float(col[9 * BLOCK]), __uint_as_float(col[10 * BLOCK]), __uint_as_float(col[11 * BLOCK]));
-                    a.R3 = mk3(__uint_as_float(col[12 * BLOCK]), __uint_as_float(col[13 * BLOCK]), __uint_as_float(col[14 * BLOCK]));
-                    a.pdf = __uint_as_float(col[15 * BLOCK]); a.singlePdf = __uint_as_float(col[16 * BLOCK]);
-                    const uint32_t ids = col[17 * BLOCK];
+                    a.R3 = ownerR3;
+                    a.pdf = __uint_as_float(col[12 * BLOCK]); a.singlePdf = __uint_as_float(col[13 * BLOCK]);
+                    const uint32_t ids = col[14 * BLOCK];
                     a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)((ids >> 20) & 255u);
                     const LightVertex* job_lvc = BATCH ? p.frames[ids >> 28].lvc : p.lvc;
-                    a.c.mat = (int)col[18 * BLOCK];
+                    a.c.mat = (int)col[15 * BLOCK];
                     LightVertex b;
                     const float4* src = reinterpret_cast<const float4*>(job_lvc + w_slot[slot]);
                     float4* dst = reinterpret_cast<float4*>(&b);

@@ -296,7 +296,7 @@ int Context::launch_light(uint32_t frame) {
     // persistent grid of the light pass: at most light_blocks blocks pull cores from a queue (kernels.hip)
     kp.work_counter = d_work_counter + kMaxRender + lane;
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
-    if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus / 2); }
+    if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
     time_begin("light_trace", ls);
     launch_light_trace(kp, counting, light_blocks, ls);
     time_end();

@@ -141,7 +141,7 @@ struct Context {
     int wf_bounces_last = 0;           // bounces launched by the last wavefront frame (diagnostics)
     int num_cus = 0, blocks_per_cu[2] = {0, 0};
     int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 94 with several render streams, else 100 (launch_render)
-    int light_blocks = -1;             // persistent grid of the light pass (SPCBPT_LIGHT_BLOCKS; default: half a block per CU)
+    int light_blocks = -1;             // persistent grid of the light pass (SPCBPT_LIGHT_BLOCKS; default: one block per CU)
     int tiles_per_wave = 1;            // lower bound of 8x8 tiles per persistent wave (SPCBPT_TILES_PER_WAVE)
     unsigned long long* d_counters = nullptr;
     bool counting = false, timing = false;

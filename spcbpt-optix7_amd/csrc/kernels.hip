@@ -195,7 +195,8 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     col[6 * BLOCK] = __float_as_uint(cur.c.lastPos.x); col[7 * BLOCK] = __float_as_uint(cur.c.lastPos.y); col[8 * BLOCK] = __float_as_uint(cur.c.lastPos.z);
                     col[9 * BLOCK] = __float_as_uint(cur.flux.x); col[10 * BLOCK] = __float_as_uint(cur.flux.y); col[11 * BLOCK] = __float_as_uint(cur.flux.z);
                     col[12 * BLOCK] = __float_as_uint(cur.pdf); col[13 * BLOCK] = __float_as_uint(cur.singlePdf);
-                    col[14 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | (fid << 28);
+                    // the frame of the VERTEX: a lane that parked its pixel has already taken a tile of possibly another frame
+                    col[14 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | ((pend_valid ? pend_fid : fid) << 28);
                     col[15 * BLOCK] = (uint32_t)cur.c.mat;
                     // (RMIS_pointer_3 does not fit the 16 stack entries four resident blocks leave: it travels by ds_bpermute below)
                 }

@@ -222,3 +222,42 @@ def test_two_ranks_on_one_gpu_with_the_sharded_host_loop(gpu, pkg):
     rows1 = pkg.dist.rows_of_rank(H, 1, WORLD)
     assert (films[0][rows1] == 0).all() and (films[1][rows0] == 0).all()      # a rank writes its own bands only
     assert np.array_equal(films[0] + films[1], want)
+
+
+def test_batched_eye_launch_where_waves_cross_frame_boundaries(gpu, pkg):
+    """At 96 x 96 a frame is 144 tiles and a wave hardly ever holds paths of two frames at once; at 448 x 448 with four frames in
+    the queue (12 544 tiles for ~3 900 resident waves) most waves regenerate across a frame boundary while a lane still owes the
+    connections of a vertex of the previous frame (the parked pixel): those connections must read the sampler tables of THEIR
+    frame.  (A first version published the lane's new frame id with the old vertex; only a run at bench scale showed it.)"""
+    import os
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    S, NF = 448, 4
+
+    def make(batch):
+        if batch > 1:
+            os.environ["SPCBPT_EYE_BATCH"] = str(batch)
+        try:
+            r = pkg.Renderer(scene, 0)
+        finally:
+            os.environ.pop("SPCBPT_EYE_BATCH", None)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+        r.resize(S, S)
+        r.set_light_trace(20000, 64, 1)
+        r.set_subspace()
+        return r
+
+    a = make(1)
+    for f in range(NF):
+        a.launch("light trace", f + 1); a.build_sampler(); a.launch("SPCBPT_eye", f)
+    a.sync()
+    want = a.read_accum().copy()
+    b = make(NF)
+    for rep in range(2):                      # twice: the result must not depend on how the waves happened to be scheduled
+        b.clear_accum()
+        for f in range(NF):
+            b.launch("light trace", f + 1); b.build_sampler()
+        b.launch_eye_batch(list(range(NF)))
+        b.sync()
+        got = b.read_accum()
+        assert np.array_equal(got, want), (rep, int((np.abs(got - want).max(axis=2) > 0).sum()))

@@ -72,9 +72,13 @@ def test_emitter_quads_are_single_sided_for_path_rays_only(gpu, pkg, ob):
         assert vis[0] == 0               # but it occludes a shadow ray
 
 
-def test_light_vertex_cache_matches_oracle(gpu, pkg, ob):
+@pytest.mark.parametrize("lt", [(3000, 64, 2), (60, 48, 40)])
+def test_light_vertex_cache_matches_oracle(gpu, pkg, ob, lt):
+    """(3000, 64, 2): two paths per core, ranges never fill.  (60, 48, 40): the reference's kind of geometry -- many paths per
+    core, and most cores end because their padded slot range is full (raygen.cu:652, 676), in the middle of a path or right
+    after an origin vertex; the persistent light kernel must cut every core at the same vertex as the per-core loop."""
     scene = pkg.scenes.cornell_box()
-    r, o = _pair(pkg, ob, scene, 8, 8, lt=(3000, 64, 2))
+    r, o = _pair(pkg, ob, scene, 8, 8, lt=lt)
     tup = minimal_tuple(o, 2)
     r.set_subspace(*tup); o.set_subspace(*tup)
     r.launch("light trace", 7); o.launch("light trace", 7)

@@ -273,6 +273,14 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
  * resampling (part of [2], summed over the lanes that sample); [10..13] 100 MHz wall clock of the megakernel's waves: earliest
  * start, latest end, sum of ends, number of waves (how long the last waves run alone). */
 int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[14]);
+/* Developer probe of the HBM part of the traversal stack.  The per-lane stack holds SPC_STACK_LDS (16) entries in LDS; deeper
+ * entries go to a per-thread spill area of 3 * bvh_depth - 16 words, which cannot overflow.  _arm fills every area allocated
+ * so far with a word no stack entry can hold, _count returns how many words kernels have overwritten since (tests prove the
+ * spill path ran) and the entries per thread.  Should a kernel ever drop an entry (SPCBPT_DEBUG_SPILL_ENTRIES=n in the
+ * environment at spcbpt_create caps the area, for tests), spcbpt_sync / spcbpt_read_* / spcbpt_trace_* return
+ * SPCBPT_ERR_STATE once and name the count: the reference's optixTrace has no such failure mode, a lost subtree is never silent. */
+int spcbpt_debug_spill_arm(spcbpt_ctx* ctx);
+int spcbpt_debug_spill_count(spcbpt_ctx* ctx, uint64_t* words_written, int* entries_per_thread);
 /* Enable/disable event counting in the kernels (off for timed runs). */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 

@@ -61,6 +61,21 @@ def ref_lib():
     return r
 
 
+REF_LAYOUT_LIB = os.path.join(_HERE, "_ref", "libref_layout.so")
+
+
+def ref_layout():
+    """sizeof / offsetof / default values of the reference's own Light, MaterialData, LightParameter, MaterialParameter
+    (oracle/ref_layout.cpp over cuda/Light.h, cuda/MaterialData.h, OptiXPathTracer/{light,material}_parameters.h), or None
+    when oracle/_ref has not been built."""
+    if not os.path.exists(REF_LAYOUT_LIB):
+        return None
+    import json
+    l = C.CDLL(REF_LAYOUT_LIB)
+    l.ref_layout_json.restype = C.c_char_p
+    return json.loads(l.ref_layout_json().decode())
+
+
 REF_VIEWER_LIB = os.path.join(_HERE, "_ref", "libref_viewer.so")
 
 

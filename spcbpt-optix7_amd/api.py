@@ -439,6 +439,8 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_get_counters": [vp, C.POINTER(Counters)],
         "spcbpt_reset_counters": [vp],
         "spcbpt_debug_phase_clocks": [vp, C.POINTER(C.c_uint64)],
+        "spcbpt_debug_spill_arm": [vp],
+        "spcbpt_debug_spill_count": [vp, C.POINTER(C.c_uint64), C.POINTER(i32)],
         "spcbpt_enable_counters": [vp, i32],
         "spcbpt_stream": [vp, C.POINTER(vp)],
         "spcbpt_sync": [vp],
@@ -503,7 +505,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
-    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -729,6 +731,15 @@ class Renderer:
         return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect", "node_slots", "node_lanes", "tri_slots", "tri_lanes", "sample_lane_clocks",
                          "wave_start_min", "wave_end_max", "wave_end_sum", "waves"),
                         [int(v) for v in out]))
+
+    def spill_arm(self):
+        self._chk(self.lib.spcbpt_debug_spill_arm(self.h), "debug_spill_arm")
+
+    def spill_count(self):
+        """(words of the HBM traversal-stack spill areas written since spill_arm(), spill entries per thread)"""
+        n, e = C.c_uint64(), C.c_int32()
+        self._chk(self.lib.spcbpt_debug_spill_count(self.h, C.byref(n), C.byref(e)), "debug_spill_count")
+        return int(n.value), int(e.value)
 
     def reset_counters(self):
         self._chk(self.lib.spcbpt_reset_counters(self.h), "reset_counters")

@@ -84,8 +84,25 @@ void Context::resolve_spans() {
     spans.clear();
 }
 
-int Context::ensure_spill(size_t threads, bool render) {
+int Context::spill_entries_needed() const {
     const int entries = std::max(0, 3 * bvh_depth - kStackLds);  // a 4-wide node pushes up to 3 children
+    return spill_entries_debug >= 0 ? std::min(entries, spill_entries_debug) : entries;
+}
+// A kernel that had to drop traversal-stack entries (deeper than LDS + spill area; cannot happen while the area is sized from
+// the BVH depth) has lost subtrees: its results are wrong, and the caller is told so at the next synchronising call.
+int Context::check_diag() {
+    if (!d_diag) return 0;
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIP_TRY(this, hipMemcpy(h, d_diag, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[0] == 0) return 0;
+    HIP_TRY(this, hipMemset(d_diag, 0, sizeof(h)));
+    error = "traversal stack overflow: " + std::to_string(h[0]) + " entries did not fit LDS + spill area (BVH depth " + std::to_string(bvh_depth) +
+            ", spill entries per thread " + std::to_string(spill_entries_needed()) + "); results since the last sync are invalid";
+    return SPCBPT_ERR_STATE;
+}
+
+int Context::ensure_spill(size_t threads, bool render) {
+    const int entries = spill_entries_needed();
     kp.spill_entries = entries;
     if (entries == 0) { kp.spill = nullptr; return 0; }
     const size_t need = threads * (size_t)entries;
@@ -274,8 +291,9 @@ int Context::launch_light(uint32_t frame) {
     kp.lvc_scratch = scratch; kp.core_counts = core_counts;
     int rc = 0;
     {   // traversal-stack spill area of this lane's light kernel
-        const int entries = std::max(0, 3 * bvh_depth - kStackLds);
+        const int entries = spill_entries_needed();
         kp.spill_entries = entries;
+        // TravStack indexes the area by blockIdx.x * 256 + threadIdx.x of the grid launched (launch_light_trace)
         const size_t need = (((size_t)lt.core_count + 255) / 256 * 256) * (size_t)entries;
         uint32_t*& buf = lane ? b_spill : d_spill;
         size_t& cap = lane ? b_spill_capacity : spill_capacity;
@@ -290,6 +308,11 @@ int Context::launch_light(uint32_t frame) {
     lset = (lset + 1) % n_sets;
     select_set(lset);
     if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[lset], 0));
+    // ... and a sampler build or an import copy of the set's previous contents may still be queued on `stream` (a set that was
+    // built or imported but never rendered carries no fresh ev_render): the second lane does not run in `stream`'s order
+    if (ls != stream) {
+        if (ev_set_touched[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_set_stream[lset], 0));
+    }
     HIP_TRY(this, hipMemsetAsync(core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), ls));
     HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), ls));
     kp.path_counter = d_sampler_counts + 1;
@@ -393,6 +416,8 @@ int Context::build_sampler() {
     eset = bset;
     HIP_TRY(this, hipEventRecord(ev_sampler[eset], stream));
     ev_sampler_set[eset] = true;
+    HIP_TRY(this, hipEventRecord(ev_set_stream[eset], stream));
+    ev_set_touched[eset] = true;
     have_sampler = true;
     for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == bset) ? built_sets.erase(it) : it + 1;
     built_sets.push_back(bset);
@@ -509,8 +534,6 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     }
     HIP_TRY(this, hipMemcpyAsync(d_frames[rk], hf, sizeof(FrameDesc) * (size_t)n, hipMemcpyHostToDevice, rstream));
     HIP_TRY(this, hipEventRecord(ev_desc[rk][gen], rstream));
-    int rc = ensure_spill((size_t)render_thread_count(kp), true);
-    if (rc) return rc;
     kp.n_tiles = (uint32_t)render_tile_count(kp);
     kp.frames = d_frames[rk]; kp.n_frames = (uint32_t)n;
     kp.work_counter = d_work_counter + rk;
@@ -521,6 +544,10 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile
     const int percent = grid_percent > 0 ? grid_percent : 94;
     if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
+    // the spill area is indexed by the thread of the grid ACTUALLY launched: n frames' tiles, capped by the resident slots
+    // (sizing it for one frame's tiles let the blocks beyond one frame's share write past its end whenever that share was below max_blocks)
+    int rc = ensure_spill((size_t)spcbpt_batch_blocks(kp, max_blocks) * 256, true);
+    if (rc) return rc;
     time_begin("spcbpt_render", rstream);
     launch_spcbpt_batch(kp, max_blocks, rstream);
     time_end();
@@ -654,7 +681,7 @@ Context::~Context() {
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
-    dev_free(d_counters); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
+    dev_free(d_counters); dev_free(d_diag); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
     for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
     if (h_frames) (void)hipHostFree(h_frames);
     for (int g2 = 0; g2 < 2; g2++) if (ev_import[g2]) (void)hipEventDestroy(ev_import[g2]);
@@ -671,6 +698,7 @@ Context::~Context() {
         if (ev_sampler[s]) (void)hipEventDestroy(ev_sampler[s]);
         if (ev_render[s]) (void)hipEventDestroy(ev_render[s]);
         if (ev_light[s]) (void)hipEventDestroy(ev_light[s]);
+        if (ev_set_stream[s]) (void)hipEventDestroy(ev_set_stream[s]);
     }
 }
 
@@ -744,6 +772,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_sampler[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_light[s], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&c->ev_set_stream[s], hipEventDisableTiming));
             c->set_count_host[s] = -1;
         }
         CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_import_counts), (size_t)Context::kMaxSets * 2 * sizeof(int)));
@@ -847,12 +876,16 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         c->eye_megakernel = !(mode && std::string(mode) == "wavefront");
     }
     CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)Context::kMaxRender + 2));   // tile queues of the render streams + core queues of the two light lanes
+    CREATE_TRY(dev_alloc(&c->d_diag, (size_t)4));
+    CREATE_TRY(hipMemset(c->d_diag, 0, 4 * sizeof(uint32_t)));
+    if (const char* e = getenv("SPCBPT_DEBUG_SPILL_ENTRIES")) c->spill_entries_debug = std::max(0, atoi(e));
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
     CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
     memset(&c->kp, 0, sizeof(c->kp));
     c->kp.scene.nodes = c->d_nodes; c->kp.scene.tris = c->d_tris; c->kp.scene.tri_orig = c->d_tri_orig; c->kp.scene.mats = c->d_mats;
     c->kp.scene.lights = c->d_lights; c->kp.scene.tex = c->d_tex; c->kp.scene.n_lights = c->n_lights; c->kp.scene.n_mats = c->n_mats;
     c->kp.sampler_counts = c->d_sampler_counts;
+    c->kp.diag = c->d_diag;
     c->kp.row_step = 1;
     CREATE_TRY(hipDeviceSynchronize());   // the uploads above went through the default stream; the context's streams do not wait for it
 #undef CREATE_TRY
@@ -990,6 +1023,8 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
         HIP_TRY(c, hipEventRecord(ev, c->stream));
         c->import_gen++;
     }
+    HIP_TRY(c, hipEventRecord(c->ev_set_stream[b], c->stream));
+    c->ev_set_touched[b] = true;
     c->set_count_host[b] = count;
     c->light_counts_valid[b] = false;
     c->light_lane_of_set[b] = 0;   // from here on the set's contents are ordered on `stream`
@@ -1039,6 +1074,7 @@ int spcbpt_read_accum(spcbpt_ctx* c, float* out) {
     CTX_CHECK(c);
     if (!out || !c->d_accum) { c->error = "no accum buffer"; return SPCBPT_ERR_STATE; }
     if (c->sync_all()) return SPCBPT_ERR_HIP;
+    if (int rc = c->check_diag()) return rc;
     HIP_TRY(c, hipMemcpy(out, c->d_accum, (size_t)c->kp.width * c->kp.height * 16, hipMemcpyDeviceToHost));
     return SPCBPT_OK;
 }
@@ -1046,6 +1082,7 @@ int spcbpt_read_frame(spcbpt_ctx* c, uint8_t* out) {
     CTX_CHECK(c);
     if (!out || !c->d_frame) { c->error = "no frame buffer"; return SPCBPT_ERR_STATE; }
     if (c->sync_all()) return SPCBPT_ERR_HIP;
+    if (int rc = c->check_diag()) return rc;
     HIP_TRY(c, hipMemcpy(out, c->d_frame, (size_t)c->kp.width * c->kp.height * 4, hipMemcpyDeviceToHost));
     return SPCBPT_OK;
 }
@@ -1127,7 +1164,38 @@ int spcbpt_sync_light(spcbpt_ctx* c) {
     else HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SPCBPT_OK;
 }
-int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); if (c->sync_all()) return SPCBPT_ERR_HIP; return SPCBPT_OK; }
+int spcbpt_sync(spcbpt_ctx* c) { CTX_CHECK(c); if (c->sync_all()) return SPCBPT_ERR_HIP; return c->check_diag(); }
+
+// Developer probe of the HBM part of the traversal stack (tests/): _arm fills every spill area allocated so far with a word no
+// stack entry can hold; _count returns how many words kernels have overwritten since.  Zero kernel cost.
+int spcbpt_debug_spill_arm(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    if (c->d_spill) HIP_TRY(c, hipMemset(c->d_spill, 0xff, c->spill_capacity * 4));
+    if (c->b_spill) HIP_TRY(c, hipMemset(c->b_spill, 0xff, c->b_spill_capacity * 4));
+    for (int k = 0; k < Context::kMaxRender; k++) if (c->d_spill_rs[k]) HIP_TRY(c, hipMemset(c->d_spill_rs[k], 0xff, c->spill_rs_capacity[k] * 4));
+    HIP_TRY(c, hipDeviceSynchronize());
+    return SPCBPT_OK;
+}
+int spcbpt_debug_spill_count(spcbpt_ctx* c, uint64_t* written, int* entries_per_thread) {
+    CTX_CHECK(c);
+    if (!written) return SPCBPT_ERR_INVALID_ARG;
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    uint64_t n = 0;
+    std::vector<uint32_t> h;
+    auto scan = [&](const uint32_t* d, size_t words) -> int {
+        if (!d || !words) return 0;
+        h.resize(words);
+        HIP_TRY(c, hipMemcpy(h.data(), d, words * 4, hipMemcpyDeviceToHost));
+        for (uint32_t w : h) n += w != 0xffffffffu;
+        return 0;
+    };
+    if (scan(c->d_spill, c->spill_capacity) || scan(c->b_spill, c->b_spill_capacity)) return SPCBPT_ERR_HIP;
+    for (int k = 0; k < Context::kMaxRender; k++) if (scan(c->d_spill_rs[k], c->spill_rs_capacity[k])) return SPCBPT_ERR_HIP;
+    *written = n;
+    if (entries_per_thread) *entries_per_thread = c->spill_entries_needed();
+    return SPCBPT_OK;
+}
 
 int spcbpt_kernel_time(spcbpt_ctx* c, const char* name, double* avg_ms, int* launches) {
     CTX_CHECK(c);
@@ -1159,12 +1227,13 @@ int spcbpt_trace_closest(spcbpt_ctx* c, const float* rays, int n, float* out_t, 
     HIP_TRY(c, dev_alloc(&d_t, (size_t)n)); HIP_TRY(c, dev_alloc(&d_tri, (size_t)n)); HIP_TRY(c, dev_alloc(&d_uv, (size_t)n * 2));
     launch_trace_closest(c->kp, d_rays, n, d_t, d_tri, d_uv, c->stream);
     hipError_t e = c->sync_all() ? hipErrorUnknown : hipSuccess;
+    const int dg = e == hipSuccess ? c->check_diag() : 0;
     if (e == hipSuccess) e = hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost);
     dev_free(d_rays); dev_free(d_t); dev_free(d_tri); dev_free(d_uv);
     if (e != hipSuccess) { c->error = hipGetErrorString(e); return SPCBPT_ERR_HIP; }
-    return SPCBPT_OK;
+    return dg;
 }
 int spcbpt_trace_any(spcbpt_ctx* c, const float* rays, int n, int32_t* out_visible) {
     CTX_CHECK(c);
@@ -1175,10 +1244,11 @@ int spcbpt_trace_any(spcbpt_ctx* c, const float* rays, int n, int32_t* out_visib
     HIP_TRY(c, dev_alloc(&d_vis, (size_t)n));
     launch_trace_any(c->kp, d_rays, n, d_vis, c->stream);
     hipError_t e = c->sync_all() ? hipErrorUnknown : hipSuccess;
+    const int dg = e == hipSuccess ? c->check_diag() : 0;
     if (e == hipSuccess) e = hipMemcpy(out_visible, d_vis, (size_t)n * 4, hipMemcpyDeviceToHost);
     dev_free(d_rays); dev_free(d_vis);
     if (e != hipSuccess) { c->error = hipGetErrorString(e); return SPCBPT_ERR_HIP; }
-    return SPCBPT_OK;
+    return dg;
 }
 
 int spcbpt_preprocess(spcbpt_ctx* c, int target_paths, int target_q_paths, int train) {

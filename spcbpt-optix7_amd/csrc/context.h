@@ -44,6 +44,8 @@ struct Context {
     bool ev_merge_set[kMaxRender] = {};
     hipEvent_t ev_sampler[kMaxSets] = {}, ev_render[kMaxSets] = {};
     bool ev_sampler_set[kMaxSets] = {}, ev_render_set[kMaxSets] = {};
+    hipEvent_t ev_set_stream[kMaxSets] = {};   // last work queued on `stream` that reads or writes the set (sampler build, import copy):
+    bool ev_set_touched[kMaxSets] = {};        // a light pass on the second lane waits for it before it rewrites the set
     int lset = 0, eset = 0;  // buffer set of the latest light pass, and of the sampler eye launches use
     // Light passes whose sampler has not been built yet, oldest first.  The host loop of a single GPU alternates
     // light pass -> sampler build, so the queue holds one set; a sharded job launches the NEXT frame's light pass before it
@@ -130,6 +132,10 @@ struct Context {
     size_t temp_capacity = 0;
     uint32_t* d_spill = nullptr;
     size_t spill_capacity = 0;
+    uint32_t* d_diag = nullptr;        // KParams::diag: [0] dropped traversal-stack entries
+    int spill_entries_debug = -1;      // SPCBPT_DEBUG_SPILL_ENTRIES: caps the spill entries per thread (tests of the overflow report)
+    int spill_entries_needed() const;  // 3 * bvh_depth - kStackLds (a 4-wide node pushes up to 3 children per level)
+    int check_diag();                  // after a sync: SPCBPT_ERR_STATE if a kernel dropped stack entries since the last check
     // instrumentation
     uint32_t* d_work_counter = nullptr;
     // wavefront eye pass (wavefront.hip): path state, queues and per-bounce counters

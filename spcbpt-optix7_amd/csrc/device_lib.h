@@ -99,18 +99,21 @@ template <int BLOCK, int STACK_LDS>
 struct TravStack {
     lds_u32* wave_lds;  // column 0 of this wave inside the BLOCK * STACK_LDS dword array (wave-uniform)
     uint32_t* spill;    // per-thread spill area or null
+    uint32_t* diag;     // KParams::diag: [0] counts entries that fit neither LDS nor the spill area (host reports an error)
     int spill_entries;
     int sp;
-    SPC_DEV void init(uint32_t* l, uint32_t* s, int se, size_t gtid) {
+    SPC_DEV void init(uint32_t* l, uint32_t* s, int se, size_t gtid, uint32_t* dg) {
         wave_lds = (lds_u32*)l + __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
         spill = s ? s + gtid * (size_t)se : nullptr;
         spill_entries = se;
+        diag = dg;
         sp = 0;
     }
     SPC_DEV lds_u32* column() const { return wave_lds + lane_id_fresh(); }
     SPC_DEV void push(uint32_t v) {
         if (sp < STACK_LDS) column()[sp * BLOCK] = v;
         else if (spill && sp - STACK_LDS < spill_entries) spill[sp - STACK_LDS] = v;
+        else if (diag) atomicAdd(diag, 1u);   // the subtree is lost: never silently (spcbpt_sync and the read-backs fail)
         sp++;
     }
     // pushes the (up to three) farther children of a node visit, farthest first; c1 >= c2 >= c3 (hits are sorted to the front)
@@ -133,7 +136,7 @@ struct TravStack {
         sp--;
         if (sp < STACK_LDS) return column()[sp * BLOCK];
         if (spill && sp - STACK_LDS < spill_entries) return spill[sp - STACK_LDS];
-        return 0xffffffffu;  // dropped subtree (stack deeper than LDS + spill): never reached when sized from the build depth
+        return NODE_EMPTY;  // the entry push() had to drop (and counted in diag[0]): a leaf of zero triangles, nothing is read
     }
 };
 

@@ -20,6 +20,7 @@ void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* v
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s);
 void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s);
 void launch_cmf(const double* prefix, const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, float* cmfs, int capacity, hipStream_t s);
+int spcbpt_batch_blocks(const KParams& p, int max_blocks);   // grid of the batched launch (the spill area is sized for it)
 void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s);
 void launch_trace_closest(const KParams& p, const float* rays, int n, float* t, int* tri, float* uv, hipStream_t s);
 void launch_pretrace(const KParams& p, uint32_t iteration, int num_core, int padding, spcbpt_pretrace_path* paths,

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
     Counts<COUNT> cn;
     cn.clear();
     TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x, p.diag);
     const int path_count = BATCH ? 0 : p.sampler_counts[1];
     const uint32_t n_tiles = BATCH ? p.n_tiles * p.n_frames : p.n_tiles;   // queue length
     uint32_t fid = 0, pool_fid = 0, pend_fid = 0;   // frame of the lane's path / of the wave's current tile / of the parked pixel
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
     if (active) {
         const DeviceScene& S = p.scene;
         TravStack<BLOCK, STACK_LDS> st;
-        st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
+        st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x, p.diag);
         uint32_t seed;
         f3 dir = camera_ray(p, x, y, seed);
         f3 origin = ld3(p.eye);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
     Counts<COUNT> cn;
     cn.clear();
     TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x);
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x, p.diag);
     int paths_started = 0;
     // per-core state
     bool has_core = false, exhausted = false;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(const KParams p, const 
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)i);
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)i, p.diag);
     const float* r = rays + (size_t)i * 8;
     Counts<false> cn;
     HitRec h;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_any(const KParams p, const floa
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)i);
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)i, p.diag);
     const float* r = rays + (size_t)i * 8;
     Counts<false> cn;
     HitRec h;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(BLOCK) void k_pretrace(const KParams p, uint32_t it
     const DeviceScene& S = p.scene;
     Counts<false> cn;
     TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)launch_index);
+    st.init(s_stack, p.spill, p.spill_entries, (size_t)launch_index, p.diag);
     WalkState w;
     w.seed = tea4((uint32_t)launch_index, iteration);
     const float jx = rnd(w.seed), jy = rnd(w.seed);
@@ -974,11 +974,16 @@ void launch_spcbpt(const KParams& p, bool count, int max_blocks, hipStream_t s) 
     else hipLaunchKernelGGL((k_spcbpt<false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 // p.frames / p.n_frames describe the batch; p.n_tiles is the tile count of ONE frame
-void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
+int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
     const long long tiles = (long long)p.n_tiles * p.n_frames;
-    if (tiles <= 0) return;
+    if (tiles <= 0) return 0;
     long long blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    return (int)blocks;
+}
+void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
+    const int blocks = spcbpt_batch_blocks(p, max_blocks);
+    if (blocks <= 0) return;
     hipLaunchKernelGGL((k_spcbpt<false, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
 }
 int spcbpt_blocks_per_cu(bool count) {

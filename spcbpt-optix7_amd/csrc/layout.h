@@ -146,6 +146,7 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     unsigned long long* counters;  // C_COUNT slots or null
     uint32_t* spill;               // per-thread traversal stack overflow area
     int32_t spill_entries;         // entries per thread in `spill`
+    uint32_t* diag;                // [0] traversal-stack entries dropped (deeper than LDS + spill): reported by the host as an error
 };
 
 // Wavefront ("streaming") eye pass: path state lives in HBM as SoA float4 arrays indexed by path slot

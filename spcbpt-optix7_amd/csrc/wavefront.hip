@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WBLOCK) void k_wf_extend(const KParams p, const WfS
     const uint32_t item = blockIdx.x * WBLOCK + threadIdx.x;
     if (item < count) {
         TravStack<WBLOCK, WSTACK> st;
-        st.init(s_stack, p.spill, p.spill_entries, (size_t)item);
+        st.init(s_stack, p.spill, p.spill_entries, (size_t)item, p.diag);
         const uint32_t slot = wf.queue[bounce & 1][item];
         const float4 o = wfq(wf, WF_POS)[slot], d = wfq(wf, WF_DIR)[slot];
         HitRec h;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WBLOCK) void k_wf_shadow(const KParams p, const WfS
         const uint32_t slot = reinterpret_cast<const uint4*>(wf.conn_rec)[item].z;
         if (slot != 0xffffffffu) {
             TravStack<WBLOCK, WSTACK> st;
-            st.init(s_stack, p.spill, p.spill_entries, (size_t)item);
+            st.init(s_stack, p.spill, p.spill_entries, (size_t)item, p.diag);
             const float4 r = reinterpret_cast<const float4*>(wf.conn_ray)[item];
             const float4 o = wfq(wf, WF_POS)[slot];
             HitRec sh;

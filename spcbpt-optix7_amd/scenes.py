@@ -244,6 +244,39 @@ def simple_room(n: int = 4) -> Scene:
     return b.finish(mats, lights, camera=cam, name="simple_room")
 
 
+def needle_room(n_needles: int = 20000, seed: int = 11) -> Scene:
+    """Test scene for deep traversal stacks: the Cornell room with a cloud of long sliver triangles that span the whole room.
+    Every sliver's bounding box covers a large part of the scene, so sibling boxes overlap at every level of the BVH, a ray
+    enters nearly all of them, and the per-lane traversal stack (up to three pushes per 4-wide node visit) runs far past the
+    16 entries it holds in LDS -- the HBM spill path of TravStack, which compact furniture scenes hardly ever reach."""
+    rng = np.random.default_rng(seed)
+    b = _Builder()
+    W, R, G = 0, 1, 2
+    b.grid((-1, 0, 1), (2, 0, 0), (0, 0, -2), 1, 1, W)
+    b.grid((-1, 2, -1), (2, 0, 0), (0, 0, 2), 1, 1, W)
+    b.grid((-1, 0, -1), (2, 0, 0), (0, 2, 0), 1, 1, W)
+    b.grid((-1, 0, 1), (0, 0, -2), (0, 2, 0), 1, 1, R)
+    b.grid((1, 0, -1), (0, 0, 2), (0, 2, 0), 1, 1, G)
+    b.grid((1, 0, 1), (-2, 0, 0), (0, 2, 0), 1, 1, W)       # front wall: closed room (the camera sits inside)
+    lo, hi = np.array([-0.95, 0.05, -0.95]), np.array([0.95, 1.9, 0.95])
+    p0 = rng.uniform(lo, hi, size=(n_needles, 3))
+    p1 = rng.uniform(lo, hi, size=(n_needles, 3))
+    d = p1 - p0
+    side = np.cross(d, rng.normal(size=(n_needles, 3)))
+    side /= np.linalg.norm(side, axis=1, keepdims=True)
+    p2 = p1 + side * rng.uniform(0.002, 0.006, size=(n_needles, 1))
+    verts = np.stack([p0, p1, p2], 1).reshape(-1, 3)
+    tris = np.arange(3 * n_needles, dtype=np.uint32).reshape(-1, 3)
+    b.add(verts, np.zeros((3 * n_needles, 2), np.float32), tris, 3)
+    mats = [dict(color=(0.73, 0.73, 0.73), roughness=0.5, metallic=0.0),
+            dict(color=(0.65, 0.05, 0.05), roughness=0.5, metallic=0.0),
+            dict(color=(0.12, 0.45, 0.15), roughness=0.5, metallic=0.0),
+            dict(color=(0.8, 0.7, 0.3), roughness=0.3, metallic=0.5)]
+    lights = [dict(position=(-0.25, 1.998, -0.25), u=(0.5, 0, 0), v=(0, 0, 0.5), emission=(17, 12, 4), div_level=4)]
+    cam = dict(eye=(0.0, 1.0, 0.9), lookat=(0.0, 1.0, 0.0), up=(0, 1, 0), fov=70.0)
+    return b.finish(mats, lights, camera=cam, name="needle_room")
+
+
 def write_scene(scene: Scene, data_root: str, rel_dir: str) -> str:
     """Writes `scene` in the reference's `.scene` + OBJ format (sceneLoader.cpp grammar) under
     data_root/rel_dir: one OBJ per material (the k-th mesh block uses the k-th material), binary PPM textures,

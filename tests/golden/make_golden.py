@@ -276,10 +276,24 @@ def ref_viewer_vectors():
     print("ref_trackball.npz:", {k: v.shape for k, v in data.items()})
 
 
+def ref_layout_vectors():
+    """ref_layout.json: sizeof / offsetof / constructor defaults of the reference's own POD headers that compile without the
+    OptiX SDK (oracle/ref_layout.cpp -> oracle/_ref/libref_layout.so): pins SURVEY.md a21 (Light 80 B, Pbr 144 B) and q17."""
+    import json
+    d = ob.ref_layout()
+    assert d is not None, "build oracle/_ref first: make -C oracle ref"
+    with open(os.path.join(HERE, "ref_layout.json"), "w") as f:
+        json.dump(d, f, indent=1, sort_keys=True)
+    print("ref_layout.json:", len(d), "entries")
+
+
 if __name__ == "__main__":
     if "--viewer" in sys.argv:      # only the row-f3 vectors
         ref_viewer_vectors()
+    elif "--layout" in sys.argv:    # only the a21 / q17 layout pins
+        ref_layout_vectors()
     else:
+        ref_layout_vectors()
         ref_vectors()
         ref_loaders()
         ref_gltf()

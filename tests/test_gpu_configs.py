@@ -1,0 +1,181 @@
+"""BASELINE.json configurations at (or near) their own sizes, on the GPU, through the C ABI.
+
+  C3  bedroom-class glTF scene, ~1 M triangles, 1920 x 1080, trained 1000-subspace tuple (the bench workload): properties
+      that need no full oracle run -- batched == frame-by-frame films bit for bit, every pixel written and finite, the two
+      independent estimators SPCBPT and PT agree in the mean, the HBM stack-spill path is in use -- plus event counters
+      against the oracle on a strided sample of the same frame (the oracle finishes 1/32 of the bands in seconds).
+  C5  hallway / door-ajar SDS scene with a TRAINED 1000-subspace tuple: image parity against the oracle at a size the
+      oracle finishes in seconds, and SPCBPT == PT in the mean at a sample count where the comparison is meaningful
+      (PT has ~50x the per-sample deviation of the mean here: that is what the scene is for).
+  C5' the comparator of config 5, "plain BDPT" = SubspaceSampler_device::uniformSample (cuProg.h:283-289): parity with the
+      oracle's restatement and unbiasedness.
+
+Tolerances are written next to each assertion.  (C1, C2 and the reduced C3 live in test_gpu_parity.py; C4, the 8-GPU run, is
+the driver's: its host loop is covered by test_gpu_pipeline.py, test_distributed_cpu.py and tests/test_mgpu_host.py.)
+"""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests.parity_util import image_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(x, scene, w, h, lt):
+    cam = scene.camera
+    x.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], w / h)
+    x.resize(w, h)
+    x.set_light_trace(*lt)
+
+
+def _renderer(pkg, scene, w, h, lt, batch=1):
+    if batch > 1:
+        os.environ["SPCBPT_EYE_BATCH"] = str(batch)
+    try:
+        r = pkg.Renderer(scene, 0)
+    finally:
+        os.environ.pop("SPCBPT_EYE_BATCH", None)
+    _setup(r, scene, w, h, lt)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def hallway_trained(gpu, pkg):
+    """Reduced hallway (~20 k triangles), full preprocessing chain on the device: pretrace -> trees -> Q -> Gamma_0 -> Adam."""
+    scene = pkg.scenes.hallway(target_tris=20000)
+    r = _renderer(pkg, scene, 256, 144, (20000, 52, 1))
+    r.set_pretrace(20000, 10)
+    r.preprocess(target_paths=200000, target_q_paths=200000, train=True)
+    return scene, r, r.get_subspace()
+
+
+def test_c5_hallway_trained_tuple_image_matches_oracle(hallway_trained, pkg, ob):
+    scene, _, tup = hallway_trained
+    et, lt, q, cmf = tup
+    assert len(et) > 1 and len(lt) > 1 and len(set(et["label"][et["leaf"] == 1].tolist())) > 200   # a real 1000-subspace tuple
+    W, H = 128, 72
+    r = _renderer(pkg, scene, W, H, (20000, 52, 1))
+    o = ob.Oracle(scene)
+    _setup(o, scene, W, H, (20000, 52, 1))
+    r.set_subspace(*tup); o.set_subspace(*tup)
+    o.set_cmf_double(True)               # the product's CMF accumulation precision
+    for f in range(4):
+        r.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
+    s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
+    # same bar as the other trained-tuple image test: >= 98.5 % of pixels within 2e-3 relative + 1e-4, mean within 1 %
+    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s
+    # PT+NEE on the same scene (caustic paths through the door gap only by chance): the kernels agree pixel by pixel too
+    r.clear_accum(); o.clear_accum()
+    for f in range(4):
+        r.launch("pt", f); o.launch("pt", f)
+    s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
+    assert s["frac_close"] >= 0.985, s
+
+
+def test_c5_hallway_spcbpt_and_pt_converge_to_the_same_mean(hallway_trained, pkg):
+    """Unbiasedness on the SDS scene.  Per-sample deviation / mean is ~50 for PT and ~10 for trained SPCBPT here, so the means are
+    compared at 4.4e8 PT samples and 2.2e7 SPCBPT samples: expected standard error of the difference ~0.35 % -> tolerance 1 %."""
+    scene, r, tup = hallway_trained
+    W, H = 256, 144
+    n_pt, n_sp = 12000, 600
+    r.clear_accum()
+    for f in range(n_pt):
+        r.launch("pt", f)
+    pt = r.read_accum()[..., :3].astype(np.float64)
+    r.clear_accum()
+    for f in range(n_sp):
+        r.render_frame("SPCBPT_eye", f, launch_frame=100000 + f)
+    sp = r.read_accum()[..., :3].astype(np.float64)
+    assert np.isfinite(pt).all() and np.isfinite(sp).all()
+    rel = abs(sp.mean() - pt.mean()) / pt.mean()
+    print("hallway means: pt %.6g (%d spp)  spcbpt %.6g (%d spp)  rel %.4f" % (pt.mean(), n_pt, sp.mean(), n_sp, rel))
+    assert rel < 0.01, (pt.mean(), sp.mean())
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def bench_scene(gpu, pkg):
+    """The bench workload: the generated bedroom written as glTF 2.0 and read back through the C++ reader (bench.py's default route)."""
+    scene = pkg.scenes.bedroom()
+    with tempfile.TemporaryDirectory(prefix="spcbpt_test_") as tmp:
+        scene, warn = pkg.load_gltf(pkg.scenes.write_gltf(scene, tmp, "bedroom"))
+    return scene
+
+
+def test_c3_full_size_bench_scene_properties_and_counters(bench_scene, pkg, ob):
+    scene = bench_scene
+    W, H, M, NF = 1920, 1080, 100000, 4
+    r = _renderer(pkg, scene, W, H, (M, 52, 1), batch=NF)
+    info = r.scene_info()
+    assert info["n_triangles"] > 900000 and 3 * info["bvh_depth"] - 16 > 0, info
+    r.preprocess(target_paths=2_000_000, target_q_paths=2_000_000, train=True)
+    tup = r.get_subspace()
+
+    # ---- frame by frame
+    for f in range(NF):
+        r.launch("light trace", f + 1); r.build_sampler(); r.launch("SPCBPT_eye", f)
+    r.sync()
+    plain = r.read_accum().copy()
+    assert (plain[..., 3] == 1.0).all() and np.isfinite(plain).all()          # every pixel written, nothing NaN/Inf
+    # ---- the same frames as ONE batched launch (the bench's form), with the HBM part of the traversal stack watched
+    r.clear_accum()
+    for f in range(NF):
+        r.launch("light trace", f + 1); r.build_sampler()
+    r.spill_arm()
+    r.launch_eye_batch(list(range(NF)))
+    r.sync()
+    written, entries = r.spill_count()
+    assert entries > 0 and written > 0, (written, entries)                    # the 986 k-triangle BVH does go past 16 entries
+    batched = r.read_accum()
+    assert np.array_equal(batched, plain), int((np.abs(batched - plain).max(axis=2) > 0).sum())
+
+    # ---- SPCBPT vs PT: two independent estimators of the same image, 16 spp each.  Per-pixel RMSE at 16 spp is ~0.30 (PT)
+    # and ~0.12 (SPCBPT) on a mean of 0.64 -> standard error of the image mean ~2e-4 relative; tolerance 0.5 %.
+    r.clear_accum()
+    for f in range(16):
+        r.launch("pt", f)
+    pt = r.read_accum()[..., :3].astype(np.float64)
+    r.clear_accum()
+    q = []
+    for f in range(16):
+        r.launch("light trace", 1000 + f); r.build_sampler(); q.append(f)
+        if len(q) == NF:
+            r.launch_eye_batch(q); q = []
+    r.sync()
+    sp = r.read_accum()
+    assert (sp[..., 3] == 1.0).all() and np.isfinite(sp).all()
+    sp = sp[..., :3].astype(np.float64)
+    rel = abs(sp.mean() - pt.mean()) / pt.mean()
+    print("bedroom 1080p means: pt %.6g  spcbpt %.6g  rel %.5f" % (pt.mean(), sp.mean(), rel))
+    assert rel < 5e-3, (pt.mean(), sp.mean())
+
+    # ---- event counters of one frame against the oracle on the same strided sample of bands (every 32nd 8-row band + the
+    # whole light pass).  Paths are the same paths up to rare FP flips, so per-path event counts agree to well under 1 %.
+    stride = 32
+    rows = (0, H, stride)
+    o = ob.Oracle(scene, nthreads=os.cpu_count() or 1)
+    _setup(o, scene, W, H, (M, 52, 1))
+    o.set_subspace(*tup)
+    o.set_cmf_double(True)
+    o.set_skip_null_connections(True)      # count what the product counts; the image does not depend on it
+    o.enable_counters(True); o.reset_counters()
+    o.launch("light trace", 7); o.build_sampler(); o.launch("SPCBPT_eye", 3, rows=rows)
+    co = o.counters()
+    r.clear_accum()
+    r.enable_counters(True); r.reset_counters()
+    r.launch("light trace", 7); r.build_sampler(); r.launch("SPCBPT_eye", 3, rows)
+    r.sync()
+    cg = r.counters()
+    r.enable_counters(False)
+    assert cg["eye_paths"] == co["eye_paths"] and cg["light_paths"] == co["light_paths"] == M
+    for k in ("closest_rays", "shadow_rays", "surface_vertices", "connections", "textured_hits", "lvc_stores", "cmf_probes",
+              "tree_nodes", "gamma_q_reads"):
+        assert abs(cg[k] - co[k]) <= 0.01 * max(co[k], 1), (k, cg[k], co[k])
+    # and the sampled bands themselves: same seeds, same tuple -> pixel parity on the ~65 k pixels the oracle rendered
+    band = np.array([(y // 8) % stride == 0 for y in range(H)])
+    s = image_parity(r.read_accum()[band][..., :3], o.read_accum()[band][..., :3])
+    assert s["frac_close"] >= 0.98 and s["mean_rel"] < 2e-2, s

@@ -304,3 +304,108 @@ def test_error_behaviour(gpu, pkg):
         r.launch("pt", 0, rows=(3, 16, 1))     # row_begin must be a band boundary
     r.launch("pt", 0)
     r.sync()
+
+
+# ---- the HBM part of the traversal stack -----------------------------------------------------------------------------------
+def _needle_rays(n, seed=5):
+    rng = np.random.default_rng(seed)
+    return _rays(rng, n, np.array([-0.9, 0.1, -0.9]), np.array([0.9, 1.85, 0.9]))
+
+
+def test_deep_traversal_stack_spills_to_hbm_and_matches_oracle(gpu, pkg, ob):
+    """TravStack keeps 16 entries per lane in LDS and spills deeper ones to HBM (csrc/device_lib.h).  Furniture scenes hardly
+    ever go past 16; a cloud of room-spanning slivers (scenes.needle_room) makes sibling boxes overlap at every level, so a ray
+    enters nearly every child and the stack runs to ~3 x depth.  Same bar as the other traversal cases (same triangle for
+    >= 99.9 % of rays, |dt| <= 1e-5), plus proof that the spill area was written."""
+    scene = pkg.scenes.needle_room(20000)
+    r, o = _pair(pkg, ob, scene, 8, 8)
+    info = r.scene_info()
+    assert 3 * info["bvh_depth"] - 16 > 0, info
+    rays = _needle_rays(20000)
+    r.trace_closest(rays[:256])            # sizes the spill area of the light stream
+    r.spill_arm()
+    t1, tri1, uv1 = r.trace_closest(rays)
+    written, entries = r.spill_count()
+    assert entries == 3 * info["bvh_depth"] - 16 and written > 1000, (written, entries)
+    t0, tri0, uv0 = o.trace_closest(rays)
+    same = tri0 == tri1
+    assert same.mean() >= 0.999, same.mean()
+    # slivers are hit at all angles and their Moller-Trumbore determinant is tiny: the distance keeps the 1e-5 bar for >= 99.9 % of
+    # the rays (all of them on the furniture scenes above) and 1e-3 for every ray
+    err = np.abs(t0 - t1)[same] / np.maximum(1.0, t0[same])
+    assert (err <= 1e-5).mean() >= 0.999 and err.max() <= 1e-3, ((err <= 1e-5).mean(), err.max())
+    rays2 = _needle_rays(20000, seed=6)
+    rays2[:, 7] = np.random.default_rng(7).uniform(0.05, 2.0, len(rays2))
+    r.spill_arm()
+    v1 = r.trace_any(rays2)
+    assert r.spill_count()[0] > 0
+    assert (o.trace_any(rays2) == v1).mean() >= 0.999
+
+
+def test_traversal_stack_overflow_is_reported_not_silent(gpu, pkg, monkeypatch):
+    """A spill area that is too small (only reachable with the developer cap SPCBPT_DEBUG_SPILL_ENTRIES) loses subtrees; the
+    next synchronising call must say so instead of returning wrong hits."""
+    scene = pkg.scenes.needle_room(20000)
+    monkeypatch.setenv("SPCBPT_DEBUG_SPILL_ENTRIES", "1")
+    r = pkg.Renderer(scene, 0)
+    monkeypatch.delenv("SPCBPT_DEBUG_SPILL_ENTRIES")
+    with pytest.raises(pkg.SpcbptError, match="traversal stack overflow"):
+        r.trace_closest(_needle_rays(4000))
+    r.sync()                                        # the report is one-shot: the context stays usable
+    cam = scene.camera
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+    r.resize(32, 32)
+    r.launch("pt", 0)
+    with pytest.raises(pkg.SpcbptError, match="traversal stack overflow"):
+        r.sync()
+
+
+def test_batched_eye_launch_sizes_its_spill_area_for_the_grid_it_launches(gpu, pkg, ob):
+    """A batch of 4 frames of a small image launches up to 4x the blocks of one frame; every block indexes the spill area by its
+    own block id.  (Round-1 bug: the area was sized for one frame's blocks, the other blocks wrote past its end whenever one
+    frame's share was below the resident grid.)  Deep-stack scene, 160 x 120: batched == frame by frame, bit for bit, the spill
+    path in use, and the image agrees with the oracle."""
+    import os
+    scene = pkg.scenes.needle_room(20000)
+    cam = scene.camera
+    W, H, NF = 160, 120, 4
+
+    def make(batch):
+        if batch > 1:
+            os.environ["SPCBPT_EYE_BATCH"] = str(batch)
+        try:
+            r = pkg.Renderer(scene, 0)
+        finally:
+            os.environ.pop("SPCBPT_EYE_BATCH", None)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+        r.resize(W, H)
+        r.set_light_trace(4000, 64, 1)
+        return r
+
+    a = make(1)
+    o = ob.Oracle(scene)
+    o.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+    o.resize(W, H); o.set_light_trace(4000, 64, 1)
+    tup = minimal_tuple(o, 2)
+    a.set_subspace(*tup); o.set_subspace(*tup); o.set_cmf_double(True)
+    for f in range(NF):
+        a.launch("light trace", f + 1); a.build_sampler(); a.launch("SPCBPT_eye", f)
+    a.sync()
+    want = a.read_accum().copy()
+    b = make(NF)
+    b.set_subspace(*tup)
+    for f in range(NF):
+        b.launch("light trace", f + 1); b.build_sampler()
+    b.launch_eye_batch([0])                # allocates this stream's spill area ... for ONE frame's grid
+    b.sync(); b.clear_accum()
+    for f in range(NF):
+        b.launch("light trace", f + 1); b.build_sampler()
+    b.spill_arm()
+    b.launch_eye_batch(list(range(NF)))
+    b.sync()
+    assert b.spill_count()[0] > 0
+    assert np.array_equal(b.read_accum(), want)
+    for f in range(NF):
+        o.launch("light trace", f + 1); o.build_sampler(); o.launch("SPCBPT_eye", f)
+    s = image_parity(want[..., :3], o.read_accum()[..., :3])
+    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s

@@ -38,6 +38,13 @@ def make_scene(pkg, name, tris):
     raise SystemExit(f"unknown scene {name}")
 
 
+def light_geometry(args):
+    """(num_core, core_padding, m_per_core) of LightTraceParams"""
+    if args.light_geometry == "reference":
+        return (1000, 800, 100)      # lt_params_setup, optixPathTracer.cpp:464-467
+    return (args.light_paths, 52, 1)
+
+
 def cpu_baseline(pkg, scene, args, tup):
     """The oracle (scalar CPU restatement, `kind: port`) timed on this host's cores on a bounded sample of the same
     workload: the full light pass + sampler build + every `stride`-th band of the eye pass."""
@@ -47,7 +54,7 @@ def cpu_baseline(pkg, scene, args, tup):
     cam = scene.camera
     o.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
     o.resize(args.width, args.height)
-    o.set_light_trace(args.light_paths, 52, 1)
+    o.set_light_trace(*light_geometry(args))
     o.set_subspace(*tup)
     o.enable_counters(False)
     o.set_skip_null_connections(True)   # the same work as the product; the image does not depend on it
@@ -86,7 +93,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
     ap.add_argument("--render-streams", type=int, default=0,
-                    help="frames in flight per GPU (0 = 2 on one GPU, 4 when the frame is sharded: a rank's share of a frame does not fill the GPU)")
+                    help="render streams per GPU, each with one (batched) eye launch in flight (0 = 2)")
+    ap.add_argument("--light-geometry", default="lane", choices=["lane", "reference"],
+                    help="lane (default): one light path per core, M cores of 52 slots, BSDF stream decorrelated (DESIGN.md d1); "
+                         "reference: the reference's launch geometry lt_params_setup (optixPathTracer.cpp:462-477): 1000 cores x 100 paths, "
+                         "800 slots per core, both random streams of a core start equal (q4)")
     ap.add_argument("--write-image", default="")
     ap.add_argument("--eye-batch", type=int, default=0,
                     help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 4: several frames in one tile queue pay the drain phase of the "
@@ -142,10 +153,13 @@ def main():
     cam = scene.camera
     r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
     r.resize(args.width, args.height)
+    if args.light_geometry == "reference":
+        args.light_paths = 100_000   # 1000 cores x 100 paths
     M = args.light_paths
+    ncore, pad, mpc = light_geometry(args)
     # the subspace tuple is computed with the full light pass, then the pass is sharded.  N > 1: rank 0 trains and
     # broadcasts (start-up, outside the timed region), so that every rank labels and weights with the same tuple
-    r.set_light_trace(M, 52, 1)
+    r.set_light_trace(ncore, pad, mpc)
     t_pre = time.perf_counter()
     if rank == 0 or dist is None:
         if args.tuple == "trained":
@@ -158,8 +172,8 @@ def main():
         if rank != 0:
             r.set_subspace(*tup)
     t_pre = time.perf_counter() - t_pre
-    begin, count = pkg.dist.core_range(M, rank, world)
-    r.set_light_trace(M, 52, 1, core_begin=begin, core_count=count)
+    begin, count = pkg.dist.core_range(ncore, rank, world)
+    r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
     rows = pkg.dist.band_rows(args.height, rank, world)
     ex = pkg.dist.FrameExchanger(r, rank, world, device) if dist is not None else None
     info = r.scene_info()
@@ -226,8 +240,11 @@ def main():
     r.launch("SPCBPT_eye", 999, rows)
     r.sync()
     c_eye = r.counters()
+    ph = r.phase_clocks()
     r.enable_counters(False)
     bytes_per_launch = pkg.algorithmic_bytes(c_eye)
+    bytes_actual_per_launch = pkg.algorithmic_bytes(c_eye, pkg.api.BYTES_ACTUAL)
+    lane_util = {"node_step": round(ph["node_lanes"] / max(ph["node_slots"], 1), 4), "triangle_step": round(ph["tri_lanes"] / max(ph["tri_slots"], 1), 4)}
 
     # duration of the dominant kernel by itself (roofline): a few frames with a sync after each, so that no neighbouring
     # frame's kernel shares the GPU with it; HIP events on the kernel's own stream (spcbpt_kernel_time)
@@ -241,6 +258,7 @@ def main():
     r.sync()
     k_ms, k_n = r.kernel_time("spcbpt_render")
     bytes_per_launch *= batch             # a batched launch renders `batch` frames (the last one of this pass may hold fewer)
+    bytes_actual_per_launch *= batch
     lt_ms, _ = r.kernel_time("light_trace")
     sb_ms, _ = r.kernel_time("sampler_build")
     cp_ms, _ = r.kernel_time("lvc_compact")
@@ -273,17 +291,22 @@ def main():
         np.save(args.write_image, img)
 
     if rank == 0:
-        traffic = None
+        # HBM-side traffic comes from rocprofv3 PMC passes (tools/profile_round.sh -> tools/pmc_summary.py), which cannot run inside
+        # this process; the committed summary is quoted only if it profiled THIS code (hash of csrc/) in THIS launch form
+        traffic = traffic_low = valu_issue = None
+        traffic_note = "no PMC summary for this code and launch form (profiles/traffic_latest.json)"
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        # the PMC passes behind that file profile the single-GPU default run (one whole frame per launch); a rank's share or a
-        # batched launch moves other amounts, and no counter run exists for those: null there
-        if os.path.exists(tfile) and world == 1 and ex is None:
+        if os.path.exists(tfile) and world == 1 and ex is None and args.light_geometry == "lane" and args.tuple == "trained":
             try:
                 t = json.load(open(tfile))
-                if int(t.get("frames_per_launch", 1)) == batch:
+                if int(t.get("frames_per_launch", 1)) == batch and t.get("source_hash") == pkg.api.source_hash():
                     traffic = t.get("spcbpt_render_hbm_bytes_per_launch")
+                    traffic_low = t.get("spcbpt_render_hbm_bytes_per_launch_low")
+                    valu_issue = t.get("valu_issue_frac")
+                    traffic_note = "rocprofv3 PMC passes of this code (" + str(t.get("tag")) + "): traffic = 2*FETCH_SIZE + WRITE_SIZE (upper bracket, gfx950 half-count correction for 128-B requests), traffic_low = FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are included in both"
             except Exception:
-                traffic = None
+                pass
+        achieved_actual = bytes_actual_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "Mpaths/sec (whole node), SPCBPT, 1920x1080",
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -291,12 +314,21 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
-                                   f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}",
+                                   f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}, light pass geometry "
+                                   f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
                        "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": depth if ahead else 0, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel_ms": round(k_ms, 4), "launches": k_n},
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel_ms": round(k_ms, 4), "launches": k_n,
+                         # the honest second reading: the same events at the record sizes this build actually fetches, the
+                         # memory-side brackets, and what the kernel is really bound by (VALU issue on partly filled waves)
+                         "actual": {"bytes_per_launch": int(bytes_actual_per_launch), "achieved": round(achieved_actual, 2),
+                                    "frac": round(achieved_actual / HBM_PEAK_GBS, 5),
+                                    "record_bytes": pkg.api.BYTES_ACTUAL, "traffic_low": traffic_low, "traffic_high": traffic,
+                                    "traffic_frac_low": None if traffic_low is None or k_ms <= 0 else round(traffic_low / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "traffic_frac_high": None if traffic is None or k_ms <= 0 else round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "valu_issue_frac": valu_issue, "lane_utilisation": lane_util, "traffic_source": traffic_note}},
             "kernels_ms": {"spcbpt_render": round(k_ms, 4), "light_trace": round(lt_ms, 4), "lvc_compact": round(cp_ms, 4),
                            "sampler_build": round(sb_ms, 4),
                            "spcbpt_render_span_in_timed_region": round(k_ms_overlapped, 4),

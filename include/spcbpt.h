@@ -281,6 +281,39 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[14]);
  * SPCBPT_ERR_STATE once and name the count: the reference's optixTrace has no such failure mode, a lost subtree is never silent. */
 int spcbpt_debug_spill_arm(spcbpt_ctx* ctx);
 int spcbpt_debug_spill_count(spcbpt_ctx* ctx, uint64_t* words_written, int* entries_per_thread);
+
+/* "Plain BDPT", the comparator BASELINE config 5 names: with mode = SPCBPT_SAMPLER_UNIFORM the "SPCBPT_eye" launch draws each of
+ * its CONNECTION_N light vertices with SubspaceSampler_device::uniformSample (cuProg.h:283-289: uniform over jump_buffer, pmf
+ * 1 / vertex_count, one random number) instead of sampleFirstStage + sampleSecondStage; everything else -- shadow ray,
+ * connectVertex_SPCBPT, recursive MIS weights (a partition of unity over strategies whatever the sampler) -- is unchanged, so
+ * the estimator stays unbiased.  The reference defines uniformSample and never calls it.  Default SPCBPT_SAMPLER_SUBSPACE. */
+enum { SPCBPT_SAMPLER_SUBSPACE = 0, SPCBPT_SAMPLER_UNIFORM = 1 };
+int spcbpt_set_connection_sampler(spcbpt_ctx* ctx, int mode);
+
+/* Per-function device harness (tests/test_gpu_units.py): evaluates ONE device function of the hot path on n caller-supplied
+ * records (one lane each) with the context's scene, subspace tuple and -- for STAGE2 / UNIFORM -- the sampler of the last
+ * spcbpt_build_sampler.  Records are arrays of 32-bit words (floats by bit pattern), `in_words` / `out_words` per record:
+ *   SPCBPT_UNIT_BSDF     in 24: material(base3, metallic, roughness, specular, specular_tint, subsurface, sheen, sheen_tint, clearcoat,
+ *                        clearcoat_gloss) N3 V3 L3 seed pad2        out 12: Sample(N,V;seed)3, seed', Eval(N,V,L)3, Pdf(N,V,L), Eval(N,V,Ls)3, Pdf(N,V,Ls)
+ *   SPCBPT_UNIT_TREE     in 10: tree(0 eye, 1 light) position3 normal3 direction3                      out 1: label
+ *   SPCBPT_UNIT_STAGE1   in 2: eye subspace, seed        out 6: l, pmf, seed' as the kernels sample (counting passes) ; l, pmf, seed' by binary_sample
+ *   SPCBPT_UNIT_BSEARCH  in 3: offset, size, seed (CMF = aux + offset)                                  out 3: bin, pmf, seed'
+ *   SPCBPT_UNIT_STAGE2   in 2: light subspace, seed                                                     out 5: size, bin (-1: empty), LVC slot, pmf, seed'
+ *   SPCBPT_UNIT_UNIFORM  in 1: seed                                                                     out 3: LVC slot, pmf, seed'
+ *   SPCBPT_UNIT_CONNECT  in 52: eye vertex (spcbpt_unit_eye_vertex, 25) light vertex (spcbpt_light_vertex, 24) pad3   out 4: connectVertex_SPCBPT rgb, RMIS weight
+ *   SPCBPT_UNIT_EYE_STEP in 36: last eye vertex (25) NextVertex.flux3 NextVertex.singlePdf seed ray direction3 flags(bit 0: d11) pad2
+ *                        out 40: kind (0 miss, 1 surface vertex, 2 emitter front, 3 emitter back), new vertex (25), next direction3,
+ *                        NextVertex.flux3, NextVertex.singlePdf, seed', done, emitter radiance3 (lightStraghtHit), t_hit, pad
+ * The ray of EYE_STEP starts at the last vertex's position.  Host pointers; returns after the kernel has run. */
+typedef struct spcbpt_unit_eye_vertex {   /* the BDPTVertex fields an eye sub-path vertex carries (BDPTVertex.h:9-70) */
+    float position[3], normal[3], flux[3], color[3], last_position[3], rmis3[3];
+    float pdf, single_pdf, last_normal_projection;
+    int32_t material_id, subspace_id, depth, last_zone_id;
+} spcbpt_unit_eye_vertex;
+enum spcbpt_unit_op { SPCBPT_UNIT_BSDF = 0, SPCBPT_UNIT_TREE = 1, SPCBPT_UNIT_STAGE1 = 2, SPCBPT_UNIT_BSEARCH = 3, SPCBPT_UNIT_STAGE2 = 4,
+                      SPCBPT_UNIT_UNIFORM = 5, SPCBPT_UNIT_CONNECT = 6, SPCBPT_UNIT_EYE_STEP = 7 };
+int spcbpt_debug_unit(spcbpt_ctx* ctx, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n,
+                      const float* aux, int aux_floats);
 /* Enable/disable event counting in the kernels (off for timed runs). */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 

@@ -36,6 +36,12 @@ EYE_VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("flu
                              ("depth", "<i4"), ("last_zone_id", "<i4")])
 assert EYE_VERTEX_DTYPE.itemsize == C.sizeof(EyeVertex)
 
+EYE_STEP_IN_DTYPE = np.dtype([("last", EYE_VERTEX_DTYPE), ("next_flux", "<f4", 3), ("next_single_pdf", "<f4"), ("seed", "<u4"),
+                              ("dir", "<f4", 3), ("flags", "<u4"), ("pad", "<u4", 2)])
+EYE_STEP_OUT_DTYPE = np.dtype([("kind", "<u4"), ("mid", EYE_VERTEX_DTYPE), ("dir", "<f4", 3), ("next_flux", "<f4", 3),
+                               ("next_single_pdf", "<f4"), ("seed", "<u4"), ("done", "<u4"), ("emit", "<f4", 3), ("t_hit", "<f4"), ("pad", "<u4")])
+assert EYE_STEP_IN_DTYPE.itemsize == 36 * 4 and EYE_STEP_OUT_DTYPE.itemsize == 40 * 4   # include/spcbpt.h: SPCBPT_UNIT_EYE_STEP
+
 _lib = None
 
 
@@ -240,6 +246,17 @@ class Oracle:
         vis = np.zeros(n, np.int32)
         self.l.orc_trace_any(self.h, C.c_void_p(r.ctypes.data), n, C.c_void_p(vis.ctypes.data), self.nthreads)
         return vis
+
+    def set_uniform_lvc(self, on):
+        """"plain BDPT": uniformSample (cuProg.h:283-289) instead of the two-stage subspace sampler"""
+        self.l.orc_set_uniform_lvc(self.h, int(bool(on)))
+
+    def eye_step(self, records):
+        """One step of the eye walk per record (EYE_STEP_IN_DTYPE -> EYE_STEP_OUT_DTYPE), see orc_eye_step."""
+        a = np.ascontiguousarray(records, dtype=EYE_STEP_IN_DTYPE)
+        out = np.zeros(a.shape[0], EYE_STEP_OUT_DTYPE)
+        self.l.orc_eye_step(self.h, C.c_void_p(a.ctypes.data), a.shape[0], C.c_void_p(out.ctypes.data))
+        return out
 
     def connect(self, eye_vertices, light_vertices):
         a = np.ascontiguousarray(eye_vertices, dtype=EYE_VERTEX_DTYPE)

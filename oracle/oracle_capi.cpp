@@ -104,6 +104,7 @@ int orc_set_light_trace(orc_ctx* c, int num_core, int core_padding, int m_per_co
 }
 int orc_set_cmf_double(orc_ctx* c, int on) { c->P.cmf_double = on != 0; return 0; }
 int orc_set_skip_null_connections(orc_ctx* c, int on) { c->P.skip_null_connections = on != 0; return 0; }
+int orc_set_uniform_lvc(orc_ctx* c, int on) { c->P.uniform_lvc = on != 0; return 0; }
 int orc_enable_counters(orc_ctx* c, int on) { c->count_events = on != 0; return 0; }
 
 // switchRaygen(name) + optixLaunch
@@ -334,6 +335,73 @@ int orc_connect(orc_ctx* c, const orc_eye_vertex* a, const spcbpt_light_vertex* 
         float3 r = connectVertex_SPCBPT(c->P, ev, lv);
         out_rgb[3 * i] = r.x; out_rgb[3 * i + 1] = r.y; out_rgb[3 * i + 2] = r.z;
         out_w[i] = lv.depth == 0 ? rmis::connection_lightSource(c->P, ev, lv) : rmis::general_connection(c->P, ev, lv);
+    }
+    return 0;
+}
+
+static void import_eye_vertex(const orc_eye_vertex& a, BDPTVertex& ev) {
+    ev.position = load3(a.position); ev.normal = load3(a.normal); ev.flux = load3(a.flux);
+    ev.color = load3(a.color); ev.lastPosition = load3(a.last_position);
+    ev.RMIS_pointer_3 = load3(a.rmis3); ev.pdf = a.pdf; ev.singlePdf = a.single_pdf;
+    ev.lastNormalProjection = a.last_normal_projection; ev.materialId = (short)a.material_id;
+    ev.subspaceId = (short)a.subspace_id; ev.depth = (short)a.depth; ev.lastZoneId = (short)a.last_zone_id;
+    ev.type = NORMALHIT;
+    ev.isOrigin = a.depth == 0;
+}
+static void export_eye_vertex(const BDPTVertex& v, orc_eye_vertex& a) {
+    auto st3 = [](float* d, float3 s) { d[0] = s.x; d[1] = s.y; d[2] = s.z; };
+    st3(a.position, v.position); st3(a.normal, v.normal); st3(a.flux, v.flux); st3(a.color, v.color);
+    st3(a.last_position, v.lastPosition); st3(a.rmis3, v.RMIS_pointer_3);
+    a.pdf = v.pdf; a.single_pdf = v.singlePdf; a.last_normal_projection = v.lastNormalProjection;
+    a.material_id = v.materialId; a.subspace_id = v.subspaceId; a.depth = v.depth; a.last_zone_id = v.lastZoneId;
+}
+// One step of the eye walk from an explicit state: traceEyeSubPath + the closest-hit program the SBT picks
+// (__closesthit__eyeSubpath / __closesthit__eyeSubpath_LightSource with rmis::light_hit) + lightStraghtHit, on the record
+// layout of spcbpt_debug_unit(SPCBPT_UNIT_EYE_STEP) (include/spcbpt.h): the per-function parity of rows a8 / a10 / a16.
+typedef struct orc_eye_step_in { orc_eye_vertex last; float next_flux[3]; float next_single_pdf; uint32_t seed; float dir[3]; uint32_t flags; uint32_t pad[2]; } orc_eye_step_in;
+typedef struct orc_eye_step_out {
+    uint32_t kind; orc_eye_vertex mid; float dir[3]; float next_flux[3]; float next_single_pdf; uint32_t seed; uint32_t done; float emit[3]; float t_hit; uint32_t pad;
+} orc_eye_step_out;
+static_assert(sizeof(orc_eye_step_in) == 36 * 4 && sizeof(orc_eye_step_out) == 40 * 4, "unit record sizes (include/spcbpt.h)");
+int orc_eye_step(orc_ctx* c, const orc_eye_step_in* in, int n, orc_eye_step_out* out) {
+    const Scene& S = c->scene;
+    for (int i = 0; i < n; i++) {
+        Params P = c->P;
+        P.counters = nullptr;
+        P.skip_null_connections = (in[i].flags & 1u) != 0;
+        PayloadBDPTVertex prd;
+        prd.clear();
+        prd.path.size = 1;
+        import_eye_vertex(in[i].last, prd.path.currentVertex());
+        prd.path.nextVertex().flux = load3(in[i].next_flux);
+        prd.path.nextVertex().singlePdf = in[i].next_single_pdf;
+        prd.seed = in[i].seed;
+        prd.origin = prd.path.currentVertex().position;
+        prd.ray_direction = load3(in[i].dir);
+        orc_eye_step_out& o = out[i];
+        memset(&o, 0, sizeof(o));
+        const float3 d = prd.ray_direction;
+        Hit h = S.closest_hit(prd.origin, d, SPCBPT_SCENE_EPSILON, 1e16f, nullptr);
+        if (h.tri < 0) { o.kind = 0; continue; }
+        o.t_hit = h.t;
+        HitInfo hi{h.tri, h.t, d, h.bu, h.bv};
+        const int size0 = prd.path.size;
+        if (S.tri_is_emitter(h.tri)) {
+            closesthit_eyeSubpath_LightSource(P, &prd, hi);
+            o.kind = prd.path.size == size0 ? 3u : 2u;   // back side: no vertex
+            if (prd.path.size != size0) {
+                float3 e = lightStraghtHit(prd.path.currentVertex());
+                o.emit[0] = e.x; o.emit[1] = e.y; o.emit[2] = e.z;
+            }
+        } else {
+            closesthit_subpath(P, &prd, hi, false);
+            o.kind = 1;
+            export_eye_vertex(prd.path.currentVertex(), o.mid);
+            o.dir[0] = prd.ray_direction.x; o.dir[1] = prd.ray_direction.y; o.dir[2] = prd.ray_direction.z;
+            const BDPTVertex& nx = prd.path.nextVertex();
+            o.next_flux[0] = nx.flux.x; o.next_flux[1] = nx.flux.y; o.next_flux[2] = nx.flux.z;
+            o.next_single_pdf = nx.singlePdf; o.seed = prd.seed; o.done = prd.done ? 1u : 0u;
+        }
     }
     return 0;
 }

@@ -122,6 +122,9 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
     // of a connection whose BSDF factor is zero and the rest of an eye path whose sampled direction has a
     // BSDF value of zero (d11).  The image is unchanged; only the event counts differ.
     bool skip_null_connections = false;
+    // "plain BDPT", the comparator of BASELINE config 5: draw the light vertex with SubspaceSampler_device::uniformSample
+    // (cuProg.h:283-289; defined in the reference, never called there) instead of the two-stage subspace sampler
+    bool uniform_lvc = false;
 
     float Gamma(int eye_id, int light_id) const {
         if (CMFGamma && Q) {
@@ -743,6 +746,13 @@ inline const BDPTVertex& sampleSecondStage(const Params& P, int subspaceId, uint
     int index = binary_sample(P, s.cmfs + begin_index, s.subspace[subspaceId].size, seed, sample_pmf) + begin_index;
     return s.LVC[s.jump_buffer[index]];
 }
+inline const BDPTVertex& uniformSample(const Params& P, uint32_t& seed, float& sample_pmf) {  // cuProg.h:283-289
+    const SubspaceSampler& s = P.sampler;
+    sample_pmf = (float)(1.0 / s.vertex_count);
+    int index = (int)(rnd(seed) * s.vertex_count);
+    if (index > s.vertex_count - 1) index = s.vertex_count - 1;  // rnd * n may round up to n in FP32: the reference would read one past jump_buffer
+    return s.LVC[s.jump_buffer[index]];
+}
 inline int sampleFirstStage(const Params& P, int eye_subspace, uint32_t& seed, float& sample_pmf) {  // cuProg.h:290-301
     int begin_index = eye_subspace * SPCBPT_NUM_SUBSPACE;
     return binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf);
@@ -810,10 +820,14 @@ inline float3 spcbpt_sample(const Params& P, unsigned x, unsigned y) {
         for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
             int light_id = 0;
             float pmf_firstStage = 1;
-            if (P.light_tree) light_id = sampleFirstStage(P, eye_subpath.subspaceId, payload.seed, pmf_firstStage);
-            if (P.sampler.subspace[light_id].size == 0) continue;
             float pmf_secondStage;
-            const BDPTVertex& light_subpath = sampleSecondStage(P, light_id, payload.seed, pmf_secondStage);
+            if (P.uniform_lvc && P.sampler.vertex_count == 0) continue;
+            if (!P.uniform_lvc) {
+                if (P.light_tree) light_id = sampleFirstStage(P, eye_subpath.subspaceId, payload.seed, pmf_firstStage);
+                if (P.sampler.subspace[light_id].size == 0) continue;
+            }
+            const BDPTVertex& light_subpath = P.uniform_lvc ? uniformSample(P, payload.seed, pmf_secondStage)
+                                                            : sampleSecondStage(P, light_id, payload.seed, pmf_secondStage);
             if (P.counters) P.counters->connections++;
             if (P.skip_null_connections) {
                 const float3 cd = normalize(eye_subpath.position - light_subpath.position);

@@ -90,9 +90,28 @@ assert PRETRACE_PATH_DTYPE.itemsize == 48 and PRETRACE_NODE_DTYPE.itemsize == 96
 BYTES = dict(node=64, tri=48, hit=72, mat=144, tex=16, tree=56, cmf=4, sub=20, jump=4, lvc=120, gq=4, lvcw=121, fb=36)
 
 
-def algorithmic_bytes(c: dict) -> int:
+# The same events at the record sizes THIS build fetches (csrc/layout.h): 64-B quantised 4-wide node, 48-B triangle test (+ the
+# fourth quad for the hit), 64-B material, 16-B classifier node, 16-B subspace record, 96-B light vertex (32 B of it for the
+# shadow ray alone), 16-B radiance store + the film merge (16 R + 16 W + 4 W).  Reported next to the contract number, which
+# credits the kernel with bytes it no longer needs.
+BYTES_ACTUAL = dict(node=64, tri=48, hit=64, mat=64, tex=16, tree=16, cmf=4, sub=16, jump=4, lvc=96, gq=4, lvcw=96, fb=52)
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources: profiles/traffic_latest.json carries the hash of the code its PMC passes profiled, and
+    bench.py reports that traffic only for the same code (the GPU box has no .git to compare heads with)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def algorithmic_bytes(c: dict, table: Optional[dict] = None) -> int:
     """bytes = sum_e count_e * B_e  (SURVEY.md 8(d))."""
-    b = BYTES
+    b = table or BYTES
     return (c["node_visits"] * b["node"] + c["tri_tests"] * b["tri"] + c["surface_vertices"] * (b["hit"] + b["mat"])
             + c["textured_hits"] * b["tex"] + c["tree_nodes"] * b["tree"] + c["cmf_probes"] * b["cmf"]
             + c["connections"] * (b["sub"] + b["jump"] + b["lvc"] + 2 * b["mat"]) + c["gamma_q_reads"] * b["gq"]
@@ -439,6 +458,8 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_get_counters": [vp, C.POINTER(Counters)],
         "spcbpt_reset_counters": [vp],
         "spcbpt_debug_phase_clocks": [vp, C.POINTER(C.c_uint64)],
+        "spcbpt_set_connection_sampler": [vp, i32],
+        "spcbpt_debug_unit": [vp, i32, vp, i32, vp, i32, i32, vp, i32],
         "spcbpt_debug_spill_arm": [vp],
         "spcbpt_debug_spill_count": [vp, C.POINTER(C.c_uint64), C.POINTER(i32)],
         "spcbpt_enable_counters": [vp, i32],
@@ -505,7 +526,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
-    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -731,6 +752,22 @@ class Renderer:
         return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect", "node_slots", "node_lanes", "tri_slots", "tri_lanes", "sample_lane_clocks",
                          "wave_start_min", "wave_end_max", "wave_end_sum", "waves"),
                         [int(v) for v in out]))
+
+    def set_connection_sampler(self, mode: int):
+        """0 = the subspace sampler (sampleFirstStage + sampleSecondStage), 1 = uniformSample ("plain BDPT", cuProg.h:283-289)"""
+        self._chk(self.lib.spcbpt_set_connection_sampler(self.h, int(mode)), "set_connection_sampler")
+
+    def unit(self, op: int, records: np.ndarray, out_words: int, aux: Optional[np.ndarray] = None) -> np.ndarray:
+        """spcbpt_debug_unit: `records` is an (n, in_words) array of 32-bit words (any 4-byte dtype / structured dtype of that
+        size); returns an (n, out_words) uint32 array."""
+        a = np.ascontiguousarray(records)
+        n = a.shape[0]
+        in_words = a.dtype.itemsize // 4 if a.ndim == 1 else a.shape[1] * a.dtype.itemsize // 4
+        out = np.zeros((n, out_words), np.uint32)
+        ax = None if aux is None else np.ascontiguousarray(aux, dtype=np.float32)
+        self._chk(self.lib.spcbpt_debug_unit(self.h, int(op), C.c_void_p(a.ctypes.data), in_words, C.c_void_p(out.ctypes.data), out_words, n,
+                                             None if ax is None else C.c_void_p(ax.ctypes.data), 0 if ax is None else int(ax.size)), "debug_unit")
+        return out
 
     def spill_arm(self):
         self._chk(self.lib.spcbpt_debug_spill_arm(self.h), "debug_spill_arm")

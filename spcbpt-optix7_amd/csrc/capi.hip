@@ -1251,6 +1251,56 @@ int spcbpt_trace_any(spcbpt_ctx* c, const float* rays, int n, int32_t* out_visib
     return dg;
 }
 
+int spcbpt_set_connection_sampler(spcbpt_ctx* c, int mode) {
+    CTX_CHECK(c);
+    if (mode != SPCBPT_SAMPLER_SUBSPACE && mode != SPCBPT_SAMPLER_UNIFORM) { c->error = "set_connection_sampler: unknown mode"; return SPCBPT_ERR_INVALID_ARG; }
+    if (mode == SPCBPT_SAMPLER_UNIFORM && !c->eye_megakernel) { c->error = "set_connection_sampler: uniformSample is built into the megakernel eye pass only"; return SPCBPT_ERR_STATE; }
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    c->kp.uniform_lvc = mode;
+    return SPCBPT_OK;
+}
+
+int spcbpt_debug_unit(spcbpt_ctx* c, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n, const float* aux, int aux_floats) {
+    CTX_CHECK(c);
+    static const int need_in[8] = {24, 10, 2, 3, 2, 1, 52, 36}, need_out[8] = {12, 1, 6, 3, 5, 3, 4, 40};
+    if (op < 0 || op > 7 || !in || !out || n < 0 || in_words < need_in[op] || out_words < need_out[op]) { c->error = "debug_unit: bad op or record size"; return SPCBPT_ERR_INVALID_ARG; }
+    if (op != SPCBPT_UNIT_BSDF && op != SPCBPT_UNIT_BSEARCH && !c->have_subspace) { c->error = "debug_unit: needs a subspace tuple"; return SPCBPT_ERR_STATE; }
+    if ((op == SPCBPT_UNIT_STAGE2 || op == SPCBPT_UNIT_UNIFORM) && !c->have_sampler) { c->error = "debug_unit: needs a built sampler"; return SPCBPT_ERR_STATE; }
+    if (op == SPCBPT_UNIT_BSEARCH && (!aux || aux_floats < 1)) { c->error = "debug_unit: BSEARCH needs the CMF in aux"; return SPCBPT_ERR_INVALID_ARG; }
+    if (n == 0) return SPCBPT_OK;
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    float* d_aux = nullptr;
+    int rc = SPCBPT_OK;
+    hipError_t e = dev_alloc(&d_in, (size_t)n * in_words);
+    if (e == hipSuccess) e = dev_alloc(&d_out, (size_t)n * out_words);
+    if (e == hipSuccess && aux && aux_floats > 0) e = dev_alloc(&d_aux, (size_t)aux_floats);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * in_words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_out, 0, (size_t)n * out_words * 4);
+    if (e == hipSuccess && d_aux) e = hipMemcpy(d_aux, aux, (size_t)aux_floats * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        KParams kp = c->kp;
+        const int es = c->eset;   // the tables of the last sampler build
+        kp.lvc = c->set_lvc[es]; kp.subspace = c->set_subspace[es]; kp.cmfs = c->set_cmfs[es];
+        kp.jump = reinterpret_cast<const int32_t*>(c->set_vals2[es]); kp.sampler_counts = c->set_counts[es];
+        kp.counters = nullptr;
+        if (op == SPCBPT_UNIT_EYE_STEP) {
+            rc = c->ensure_spill(((size_t)n + 255) / 256 * 256);
+            kp.spill = c->kp.spill; kp.spill_entries = c->kp.spill_entries;
+        }
+        if (rc == SPCBPT_OK) {
+            launch_unit(kp, op, d_in, in_words, d_out, out_words, n, d_aux, c->stream);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * out_words * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    dev_free(d_in); dev_free(d_out); dev_free(d_aux);
+    if (e != hipSuccess) { c->error = std::string("debug_unit: ") + hipGetErrorString(e); return SPCBPT_ERR_HIP; }
+    if (rc) return rc;
+    return c->check_diag();
+}
+
 int spcbpt_preprocess(spcbpt_ctx* c, int target_paths, int target_q_paths, int train) {
     CTX_CHECK(c);
     return c->preprocess(target_paths, target_q_paths, train != 0);

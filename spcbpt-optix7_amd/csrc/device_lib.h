@@ -637,6 +637,15 @@ SPC_DEV int binary_sample(const float* cmf, int size, uint32_t& seed, float& pmf
     return l;
 }
 
+// uniformSample (cuProg.h:283-289): "plain BDPT" draws the light vertex uniformly over the whole cache, pmf 1 / vertex_count
+// (double division, as `1.0 / vertex_count` is written).  `rnd * vertex_count` can round up to vertex_count in FP32 for large
+// caches -- the reference would then read one past jump_buffer; clamped here.
+SPC_DEV int uniform_sample(const int32_t* jump, int vertex_count, uint32_t& seed, float& pmf) {
+    pmf = (float)(1.0 / (double)vertex_count);
+    const int index = min((int)(rnd(seed) * (float)vertex_count), vertex_count - 1);
+    return jump[index];
+}
+
 // sampleFirstStage (cuProg.h:290-301) = binary_sample over the 1000-entry CMF row of the eye subspace: ten DEPENDENT probes.
 // For a non-decreasing CMF the bisection returns the first bin with u < cmf[bin], i.e. the number of entries <= u, which two
 // counting passes over 32 values each find in two round trips (coarse: every 32nd entry; fine: the 32 entries of that
@@ -766,7 +775,7 @@ SPC_DEV bool null_connection(f3 apos, f3 an, f3 bpos, f3 bn) {
 // connectVertex_SPCBPT (raygen.cu:253-303) with rmis::general_connection / connection_lightSource
 // (rmis.h:212-247 / 281-313) fused: every BSDF lobe is fetched once.
 template <bool COUNT>
-SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn) {
+SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn, float* w_out = nullptr) {
     const DeviceScene& S = p.scene;
     const f3 bpos = ld3(b.position), bn = ld3(b.normal), bflux = ld3(b.flux);
     const f3 connectVec = a.c.pos - bpos;
@@ -811,6 +820,7 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
         D_B = (b.rmis_pointer * LL_pdf_B + wB) * pdf_B / b.single_pdf;
     }
     const float w_rmis = weight / (weight + D_A + D_B);
+    if (w_out) *w_out = w_rmis;   // per-function harness only (unit.hip); the render kernels pass nothing
     const f3 contri = a.flux * bflux * fa * fb * G;
     const f3 ans = contri / (a.pdf * b.pdf) * w_rmis;
     return ans;

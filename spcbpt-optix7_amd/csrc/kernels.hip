@@ -288,19 +288,29 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     const LightVertex* f_lvc = p.lvc; const DSubspace* f_subspace = p.subspace; const float* f_cmfs = p.cmfs;
                     const int32_t* f_jump = p.jump;
                     int f_path_count = path_count;
+                    const int32_t* f_counts = p.sampler_counts;
                     if (BATCH) {   // the sampler tables of this path's frame
                         const FrameDesc& D = p.frames[fid];
                         f_lvc = D.lvc; f_subspace = D.subspace; f_cmfs = D.cmfs; f_jump = D.jump; f_path_count = D.sampler_counts[1];
+                        f_counts = D.sampler_counts;
                     }
 #pragma unroll
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                        float pmf1, pmf2;
+                        float pmf1 = 1.0f, pmf2;
                         float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
-                        const int l = sample_first_stage(p, cur.sub, w.seed, pmf1, cn);
-                        const DSubspace ss = f_subspace[l];
-                        if (ss.size != 0) {
-                            const int k = binary_sample(f_cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
-                            const int lslot = f_jump[ss.jump_bias + k];
+                        int lslot = -1;
+                        if (p.uniform_lvc) {   // the comparator of BASELINE config 5: uniformSample (cuProg.h:283-289), one random number
+                            const int vc = f_counts[0];
+                            if (vc > 0) lslot = uniform_sample(f_jump, vc, w.seed, pmf2);
+                        } else {
+                            const int l = sample_first_stage(p, cur.sub, w.seed, pmf1, cn);
+                            const DSubspace ss = f_subspace[l];
+                            if (ss.size != 0) {
+                                const int k = binary_sample(f_cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
+                                lslot = f_jump[ss.jump_bias + k];
+                            }
+                        }
+                        if (lslot >= 0) {
                             w_slot[it * 64 + lane] = lslot;
                             cn.add(C_CONN);
                             const float4 bq0 = reinterpret_cast<const float4*>(f_lvc + lslot)[0];

@@ -132,6 +132,7 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     const float* cmfs;
     const int32_t* jump;
     const int32_t* sampler_counts;  // [0] vertex_count, [1] path_count (device-resident: no host round trip)
+    int32_t uniform_lvc;            // != 0: "SPCBPT_eye" draws its light vertices with uniformSample (cuProg.h:283-289) = plain LVC-BDPT
     // light pass (LightTraceParams)
     int32_t num_core, core_padding, m_per_core, core_begin, core_count, lt_decorrelate;
     uint32_t launch_frame;

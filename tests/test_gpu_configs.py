@@ -77,11 +77,13 @@ def test_c5_hallway_trained_tuple_image_matches_oracle(hallway_trained, pkg, ob)
 
 
 def test_c5_hallway_spcbpt_and_pt_converge_to_the_same_mean(hallway_trained, pkg):
-    """Unbiasedness on the SDS scene.  Per-sample deviation / mean is ~50 for PT and ~10 for trained SPCBPT here, so the means are
-    compared at 4.4e8 PT samples and 2.2e7 SPCBPT samples: expected standard error of the difference ~0.35 % -> tolerance 1 %."""
+    """Unbiasedness on the SDS scene.  Both estimators are heavy-tailed here (that is what the scene is for): batch means measured
+    with tools/hallway_means.py give a standard error of the image mean of 0.32 % for PT at 16 000 spp and 1.0 % for the trained
+    sampler at 800 spp (256 x 144).  At 32 000 / 6 400 spp the difference has a standard error of ~0.4 %; tolerance 1 %.  The
+    kernels are deterministic, so this is a fixed comparison, not a coin flip per run."""
     scene, r, tup = hallway_trained
     W, H = 256, 144
-    n_pt, n_sp = 12000, 600
+    n_pt, n_sp = 32000, 6400
     r.clear_accum()
     for f in range(n_pt):
         r.launch("pt", f)

@@ -12,6 +12,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
@@ -47,7 +48,15 @@ if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[k
     w = summary[key]["WRITE_SIZE"]["avg_per_launch"] * 1024.0
     out["spcbpt_render_hbm_bytes_per_launch_low"] = f + w
     out["spcbpt_render_hbm_bytes_per_launch_high"] = 2 * f + w
+    import __graft_entry__ as g
+    d = summary[key]
+    valu = None
+    if "SQ_INSTS_VALU" in d and "SQ_BUSY_CYCLES" in d:
+        # wave-instructions x 4 cycles (one wave's issue cost, MI355X_MICROARCH.md) over the cycles of all 1024 SIMDs
+        # (SQ_BUSY_CYCLES is summed over the 32 shader engines: x 32 SIMDs per engine)
+        valu = d["SQ_INSTS_VALU"]["avg_per_launch"] * 4.0 / (d["SQ_BUSY_CYCLES"]["avg_per_launch"] * 32.0)
     json.dump({"tag": tag, "kernel": key, "frames_per_launch": frames_per_launch, "spcbpt_render_hbm_bytes_per_launch": 2 * f + w,
+               "spcbpt_render_hbm_bytes_per_launch_low": f + w, "source_hash": g.load_package().api.source_hash(), "valu_issue_frac": valu,
                "definition": "2*FETCH_SIZE + WRITE_SIZE (KB*1024) per k_spcbpt<false> launch, gfx950 FETCH_SIZE half-count correction applied; "
                              "uncorrected lower bound = FETCH_SIZE + WRITE_SIZE = %.4g" % (f + w)},
               open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)

@@ -248,6 +248,26 @@ int spcbpt_build_sampler(spcbpt_ctx* ctx);
  * vertices from a device (is_device != 0) or host buffer. */
 int spcbpt_lvc_export(spcbpt_ctx* ctx, void** d_vertices, void** d_count, int* capacity);
 int spcbpt_lvc_import(spcbpt_ctx* ctx, const void* vertices, int count, int is_device);
+/* The same exchange without host round trips (libspcbpt_mgpu's RCCL host, include/spcbpt_mgpu.h):
+ *   spcbpt_lvc_export_on        hands out the oldest pending shard like spcbpt_lvc_export and makes `hip_stream` (the caller's
+ *                               exchange stream) wait for the light pass that fills it -- the host does not.
+ *   spcbpt_lvc_import_gathered  `shards` = world x shard_capacity vertices exactly as an all-gather of every rank's shard (padded
+ *                               to shard_capacity) leaves them, `counts_all` = world x {vertex_count, path_count} (device int32).
+ *                               A device kernel queued on `hip_stream` concatenates the shards in rank order into the set and
+ *                               leaves the totals on the device; spcbpt_build_sampler then runs over the upper bound
+ *                               min(world x shard_capacity, LVC capacity) with pad keys instead of reading a count back.  A
+ *                               shard larger than shard_capacity raises a device flag: the next spcbpt_sync returns
+ *                               SPCBPT_ERR_CAPACITY.
+ *   spcbpt_film_pack_bands / spcbpt_film_unpack_bands   exchange 2: this rank's 8-row bands (band b with b % world == rank) as one
+ *                               contiguous block of ceil(bands / world) x 8 x width float4, and back from the all-gathered
+ *                               world x that block into a full width x height float4 image (`out_image`, device). */
+int spcbpt_lvc_export_on(spcbpt_ctx* ctx, void* hip_stream, void** d_vertices, void** d_count, int* capacity);
+int spcbpt_lvc_import_gathered(spcbpt_ctx* ctx, const void* shards, const void* counts_all, int world, int shard_capacity, void* hip_stream);
+int spcbpt_film_pack_bands(spcbpt_ctx* ctx, int rank, int world, void* packed, void* hip_stream);
+int spcbpt_film_unpack_bands(spcbpt_ctx* ctx, int world, const void* packed_all, void* out_image, void* hip_stream);
+int spcbpt_image_size(spcbpt_ctx* ctx, int* width, int* height);
+/* The light-pass geometry in force (spcbpt_set_light_trace with core_count resolved; the defaults before any call). */
+int spcbpt_get_light_trace(spcbpt_ctx* ctx, spcbpt_light_trace_params* out);
 /* Host copy of the LVC in deterministic order (path_id, depth). */
 int spcbpt_lvc_read(spcbpt_ctx* ctx, spcbpt_light_vertex* out, int capacity, int* count);
 

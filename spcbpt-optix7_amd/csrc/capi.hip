@@ -94,8 +94,12 @@ int Context::check_diag() {
     if (!d_diag) return 0;
     uint32_t h[4] = {0, 0, 0, 0};
     HIP_TRY(this, hipMemcpy(h, d_diag, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[0] == 0) return 0;
+    if (h[0] == 0 && h[1] == 0) return 0;
     HIP_TRY(this, hipMemset(d_diag, 0, sizeof(h)));
+    if (h[0] == 0) {
+        error = "LVC exchange: a rank's shard did not fit the agreed shard capacity (or the gathered cache did not fit the LVC); frames since the last sync are invalid -- raise the capacity (spcbpt_comm_set_shard_capacity)";
+        return SPCBPT_ERR_CAPACITY;
+    }
     error = "traversal stack overflow: " + std::to_string(h[0]) + " entries did not fit LDS + spill area (BVH depth " + std::to_string(bvh_depth) +
             ", spill entries per thread " + std::to_string(spill_entries_needed()) + "); results since the last sync are invalid";
     return SPCBPT_ERR_STATE;
@@ -223,7 +227,7 @@ int Context::ensure_lvc_capacity(size_t n) {
         dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
         HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
     }
-    for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; }   // the sets are empty again
+    for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; set_bound[s2] = -1; ev_exch_set[s2] = false; }   // the sets are empty again
     pending.clear();
     select_set(lset);
     HIP_TRY(this, dev_alloc(&d_keys, n)); HIP_TRY(this, dev_alloc(&d_keys2, n));
@@ -313,6 +317,8 @@ int Context::launch_light(uint32_t frame) {
     if (ls != stream) {
         if (ev_set_touched[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_set_stream[lset], 0));
     }
+    if (ev_exch_set[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_exch[lset], 0));   // a gathered import of the set's previous contents (exchange stream)
+    set_bound[lset] = -1;
     HIP_TRY(this, hipMemsetAsync(core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), ls));
     HIP_TRY(this, hipMemsetAsync(d_sampler_counts, 0, 2 * sizeof(int), ls));
     kp.path_counter = d_sampler_counts + 1;
@@ -380,8 +386,11 @@ int Context::build_sampler() {
     if (light_lane_of_set[bset] != 0 && light_counts_valid[bset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_light[bset], 0));   // traced on the second lane
     // the radix sort needs its item count on the host: an import told it, or the light pass left it in pinned memory (wait for
     // that pass's event), or -- a cache written some other way -- one 8-byte readback
-    bool count_known = set_count_host[bset] >= 0;
-    if (count_known) lvc_count = set_count_host[bset];
+    const bool dev_count = set_bound[bset] >= 0;   // gathered import: totals on the device, build over the upper bound
+    if (dev_count && ev_exch_set[bset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_exch[bset], 0));
+    bool count_known = set_count_host[bset] >= 0 || dev_count;
+    if (dev_count) { lvc_count = set_bound[bset]; path_count = -1; }
+    else if (count_known) lvc_count = set_count_host[bset];
     else if (light_counts_valid[bset]) {
         HIP_TRY(this, hipEventSynchronize(ev_light[bset]));
         lvc_count = h_light_counts[2 * bset]; path_count = h_light_counts[2 * bset + 1];
@@ -390,7 +399,9 @@ int Context::build_sampler() {
     if (rc) { select_set(lset); return rc; }
     const int n = lvc_count;
     time_begin("sampler_build");
-    if (!(keys_ready && keys_set == bset)) {
+    if (dev_count) {
+        launch_fill_keys_devcount(d_lvc, n, d_keys, d_vals, d_weights, d_sampler_counts, stream);
+    } else if (!(keys_ready && keys_set == bset)) {
         HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
         launch_fill_keys(d_lvc, n, d_keys, d_vals, d_weights, d_sampler_counts, stream);
     }
@@ -423,7 +434,48 @@ int Context::build_sampler() {
     built_sets.push_back(bset);
     while ((int)built_sets.size() > kMaxBatchFrames) built_sets.pop_front();
     if (!pending.empty() && pending.front() == bset) pending.pop_front();
+    if (dev_count) lvc_count = -1;   // the host does not know it
     select_set(lset);   // the members name the latest light pass's set again
+    return 0;
+}
+
+// The oldest pending light pass's shard for an exchange that runs on the caller's stream `xs`: instead of the host waiting for
+// the pass (spcbpt_sync_light), `xs` waits for it on the device.
+int Context::export_on(hipStream_t xs, void** dv, void** dc, int* cap) {
+    if (!d_lvc) { error = "no LVC allocated"; return SPCBPT_ERR_STATE; }
+    const int b = build_set();
+    if (light_counts_valid[b]) HIP_TRY(this, hipStreamWaitEvent(xs, ev_light[b], 0));
+    else {   // a cache written some other way (import): ordered on `stream`
+        HIP_TRY(this, hipEventRecord(ev_set_stream[b], stream));
+        ev_set_touched[b] = true;
+        HIP_TRY(this, hipStreamWaitEvent(xs, ev_set_stream[b], 0));
+    }
+    *dv = set_lvc[b]; *dc = set_counts[b]; *cap = (int)lvc_capacity;
+    return 0;
+}
+
+// Receiving side of exchange 1 (k_gather_compact): `shards` = world x shard_cap vertices as the all-gather left them, `counts_all`
+// = world x (vertex_count, path_count), both device memory that `xs` has finished writing by the time this is queued.  Everything
+// is queued on `xs`; nothing here waits on the host.
+int Context::import_gathered(const void* shards, const int* counts_all, int world, int shard_cap, hipStream_t xs) {
+    if (!shards || !counts_all || world < 1 || shard_cap < 1) { error = "lvc_import_gathered: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
+    if (!d_lvc) { error = "no LVC allocated"; return SPCBPT_ERR_STATE; }
+    const int b = build_set();
+    // the set's previous readers: eye kernels (ev_render) were waited for by the light pass that refilled it; its own light pass
+    // and the all-gather that read it as the send buffer precede this call on `xs` (export_on)
+    launch_gather_compact(reinterpret_cast<const LightVertex*>(shards), counts_all, world, shard_cap, (int)std::min<size_t>(lvc_capacity, 0x7fffffff),
+                          set_lvc[b], set_counts[b], reinterpret_cast<int*>(d_diag + 1), xs);
+    HIP_TRY(this, hipGetLastError());
+    HIP_TRY(this, hipEventRecord(ev_exch[b], xs));
+    ev_exch_set[b] = true;
+    set_bound[b] = (int)std::min<size_t>((size_t)world * (size_t)shard_cap, lvc_capacity);
+    set_count_host[b] = -1;
+    light_counts_valid[b] = false;
+    light_lane_of_set[b] = 0;
+    for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == b) ? built_sets.erase(it) : it + 1;
+    if (b == lset) lvc_count = -1;
+    if (keys_set == b) keys_ready = false;
+    have_sampler = false;
     return 0;
 }
 
@@ -699,6 +751,7 @@ Context::~Context() {
         if (ev_render[s]) (void)hipEventDestroy(ev_render[s]);
         if (ev_light[s]) (void)hipEventDestroy(ev_light[s]);
         if (ev_set_stream[s]) (void)hipEventDestroy(ev_set_stream[s]);
+        if (ev_exch[s]) (void)hipEventDestroy(ev_exch[s]);
     }
 }
 
@@ -773,6 +826,8 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_render[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_light[s], hipEventDisableTiming));
             CREATE_TRY(hipEventCreateWithFlags(&c->ev_set_stream[s], hipEventDisableTiming));
+            CREATE_TRY(hipEventCreateWithFlags(&c->ev_exch[s], hipEventDisableTiming));
+            c->set_bound[s] = -1;
             c->set_count_host[s] = -1;
         }
         CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_import_counts), (size_t)Context::kMaxSets * 2 * sizeof(int)));
@@ -1026,6 +1081,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     HIP_TRY(c, hipEventRecord(c->ev_set_stream[b], c->stream));
     c->ev_set_touched[b] = true;
     c->set_count_host[b] = count;
+    c->set_bound[b] = -1;
     c->light_counts_valid[b] = false;
     c->light_lane_of_set[b] = 0;   // from here on the set's contents are ordered on `stream`
     for (auto it = c->built_sets.begin(); it != c->built_sets.end();) it = (*it == b) ? c->built_sets.erase(it) : it + 1;   // a sampler built from the old contents is gone
@@ -1034,6 +1090,42 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     c->have_sampler = false;
     return SPCBPT_OK;
 }
+
+int spcbpt_lvc_export_on(spcbpt_ctx* c, void* hip_stream, void** dv, void** dc, int* cap) {
+    CTX_CHECK(c);
+    if (!dv || !dc || !cap) return SPCBPT_ERR_INVALID_ARG;
+    return c->export_on(reinterpret_cast<hipStream_t>(hip_stream), dv, dc, cap);
+}
+int spcbpt_lvc_import_gathered(spcbpt_ctx* c, const void* shards, const void* counts_all, int world, int shard_capacity, void* hip_stream) {
+    CTX_CHECK(c);
+    return c->import_gathered(shards, reinterpret_cast<const int*>(counts_all), world, shard_capacity, reinterpret_cast<hipStream_t>(hip_stream));
+}
+// film exchange helpers of a sharded job (exchange 2, once per read-out): pack this rank's 8-row bands contiguously / scatter
+// every rank's packed bands back into the full image.  Queued on `hip_stream` after the render streams' merges.
+int spcbpt_film_pack_bands(spcbpt_ctx* c, int rank, int world, void* packed, void* hip_stream) {
+    CTX_CHECK(c);
+    if (!packed || !c->d_accum || world < 1 || rank < 0 || rank >= world) return SPCBPT_ERR_INVALID_ARG;
+    if (c->sync_all()) return SPCBPT_ERR_HIP;   // a read-out: every frame's merge has to be in the film
+    launch_pack_bands(c->d_accum, (int)c->kp.width, (int)c->kp.height, rank, world, reinterpret_cast<float*>(packed), false, reinterpret_cast<hipStream_t>(hip_stream));
+    HIP_TRY(c, hipGetLastError());
+    return SPCBPT_OK;
+}
+int spcbpt_film_unpack_bands(spcbpt_ctx* c, int world, const void* packed_all, void* out_image, void* hip_stream) {
+    CTX_CHECK(c);
+    if (!packed_all || !out_image || world < 1) return SPCBPT_ERR_INVALID_ARG;
+    launch_pack_bands(reinterpret_cast<float*>(out_image), (int)c->kp.width, (int)c->kp.height, 0, world,
+                      reinterpret_cast<float*>(const_cast<void*>(packed_all)), true, reinterpret_cast<hipStream_t>(hip_stream));
+    HIP_TRY(c, hipGetLastError());
+    return SPCBPT_OK;
+}
+int spcbpt_get_light_trace(spcbpt_ctx* c, spcbpt_light_trace_params* out) {
+    CTX_CHECK(c);
+    if (!out) return SPCBPT_ERR_INVALID_ARG;
+    *out = c->lt;
+    if (out->core_count == 0) out->core_count = out->num_core - out->core_begin;
+    return SPCBPT_OK;
+}
+int spcbpt_image_size(spcbpt_ctx* c, int* w, int* h) { CTX_CHECK(c); if (w) *w = (int)c->kp.width; if (h) *h = (int)c->kp.height; return SPCBPT_OK; }
 
 int spcbpt_lvc_read(spcbpt_ctx* c, spcbpt_light_vertex* out, int capacity, int* count) {
     CTX_CHECK(c);

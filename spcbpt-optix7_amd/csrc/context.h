@@ -57,6 +57,14 @@ struct Context {
     int set_count_host[kMaxSets];            // vertex count of the set when the host knows it (after an import), else -1
     bool light_counts_valid[kMaxSets] = {};  // h_light_counts of the set describe its current contents
     int keys_set = -1;                       // the set whose compaction left d_keys / d_vals / d_weights (valid if keys_ready)
+    // Sharded job without host round trips (spcbpt_lvc_export_on / spcbpt_lvc_import_gathered, libspcbpt_mgpu): the all-gathered
+    // shards are compacted on the exchange stream with the totals left on the DEVICE; the sampler build then runs over a host-known
+    // upper bound (`set_bound`, pad keys sort behind the real items) instead of reading the count back.
+    int set_bound[kMaxSets];                 // >= 0: the set's vertex count lives on the device only, this is its upper bound
+    hipEvent_t ev_exch[kMaxSets] = {};       // gathered compaction of the set done (recorded on the caller's exchange stream)
+    bool ev_exch_set[kMaxSets] = {};
+    int export_on(hipStream_t xs, void** dv, void** dc, int* cap);
+    int import_gathered(const void* shards, const int* counts_all, int world, int shard_cap, hipStream_t xs);
     hipEvent_t ev_import[2] = {};            // device-to-device import copies done (alternating: the caller alternates two staging buffers)
     long long import_gen = 0;
     int* h_import_counts = nullptr;          // pinned [kMaxSets][2]: source of the counts upload of an import (no host wait)

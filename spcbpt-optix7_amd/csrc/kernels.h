@@ -17,6 +17,10 @@ void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
                         LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
+void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys, uint32_t* vals, float* weights, const int* sampler_counts, hipStream_t s);
+void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, LightVertex* lvc,
+                           int* sampler_counts, int* overflow, hipStream_t s);
+void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s);
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s);
 void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s);
 void launch_cmf(const double* prefix, const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, float* cmfs, int capacity, hipStream_t s);

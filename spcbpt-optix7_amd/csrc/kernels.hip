@@ -700,6 +700,85 @@ __global__ void k_fill_keys_from_lvc(const LightVertex* __restrict__ lvc, int n,
     if ((threadIdx.x & 63) == 0 && start) atomicAdd(&sampler_counts[1], start);
 }
 
+// The same with the item count on the DEVICE (sampler_counts[0]) and a host-known upper bound `bound` as the grid: slots beyond the
+// count get the pad key 1023 (no subspace id reaches it: ids are < 1000) and weight 0, so a 10-bit radix sort over `bound` items
+// leaves the real items sorted in front.  sampler_counts[1] (path count) is left as the caller set it.
+__global__ void k_fill_keys_devcount(const LightVertex* __restrict__ lvc, int bound, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                     float* __restrict__ weights, const int* __restrict__ sampler_counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bound) return;
+    const int n = sampler_counts[0];
+    if (i < n) {
+        const LightVertex& v = lvc[i];
+        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;
+        if (isinf(w) || isnan(w)) w = 0.0f;
+        keys[i] = (uint32_t)v.subspace_id;
+        weights[i] = w;
+    } else {
+        keys[i] = 1023u;
+        weights[i] = 0.0f;
+    }
+    vals[i] = (uint32_t)i;
+}
+
+// Exchange 1 of a sharded job, receiving side: `gathered` holds `world` shards of `cap` slots each (the all-gather of every rank's
+// compact shard, padded to the agreed capacity), counts_all[2 r] / [2 r + 1] the vertex / path count of rank r.  The shards are
+// concatenated in rank order = global (path, depth) order into the set's LVC; the totals go to sampler_counts (device-resident:
+// the sampler build sizes itself from them, no host round trip).  A shard that did not fit `cap` raises *overflow.
+__global__ void k_gather_compact(const LightVertex* __restrict__ gathered, const int* __restrict__ counts_all, int world, int cap, int lvc_capacity,
+                                 LightVertex* __restrict__ lvc, int* __restrict__ sampler_counts, int* __restrict__ overflow) {
+    const int chunks = (cap + 255) / 256;
+    const int r = blockIdx.x / chunks, c = blockIdx.x % chunks;
+    int base = 0, total = 0, paths = 0;
+    bool over = false;
+    for (int q = 0; q < world; q++) {
+        const int n = counts_all[2 * q];
+        if (n > cap) over = true;
+        if (q < r) base += min(n, cap);
+        total += min(n, cap);
+        paths += counts_all[2 * q + 1];
+    }
+    if (total > lvc_capacity) over = true;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sampler_counts[0] = min(total, lvc_capacity);
+        sampler_counts[1] = paths;
+        if (over) *overflow = 1;
+    }
+    const int n_r = min(counts_all[2 * r], cap);
+    const int i = c * 256 + (int)threadIdx.x;
+    if (i >= n_r || base + i >= lvc_capacity) return;
+    const float4* src = reinterpret_cast<const float4*>(gathered + (size_t)r * cap + i);
+    float4* dst = reinterpret_cast<float4*>(lvc + base + i);
+    float4 q[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) q[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dst[k] = q[k];
+}
+
+// film exchange of a sharded job: the 8-row bands of rank `rank` (band b with b % world == rank) packed contiguously / unpacked
+__global__ void k_pack_bands(const float4* __restrict__ accum, int width, int height, int rank, int world, float4* __restrict__ packed, int unpack_all) {
+    // unpack_all == 0: accum -> packed (own bands, band-major); != 0: packed (world x bands_per_rank x 8 x width) -> accum (every band)
+    const int bands = (height + 7) / 8, per_rank = (bands + world - 1) / world;
+    const size_t band_px = (size_t)8 * width;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!unpack_all) {
+        if (t >= (size_t)per_rank * band_px) return;
+        const int k = (int)(t / band_px), b = rank + k * world;
+        const size_t in_band = t % band_px;
+        const int y = b * 8 + (int)(in_band / width), x = (int)(in_band % width);
+        packed[t] = (b < bands && y < height) ? accum[(size_t)y * width + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        if (t >= (size_t)world * per_rank * band_px) return;
+        const int r = (int)(t / ((size_t)per_rank * band_px));
+        const size_t tr = t % ((size_t)per_rank * band_px);
+        const int k = (int)(tr / band_px), b = r + k * world;
+        const size_t in_band = tr % band_px;
+        const int y = b * 8 + (int)(in_band / width), x = (int)(in_band % width);
+        if (b < bands && y < height) reinterpret_cast<float4*>(const_cast<float4*>(accum))[(size_t)y * width + x] = packed[t];
+    }
+}
+
 __global__ void k_subspace_ranges(const uint32_t* __restrict__ sorted_keys, const int* __restrict__ sampler_counts, DSubspace* __restrict__ sub) {
     const int n = sampler_counts[0];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1048,6 +1127,23 @@ void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, cons
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_fill_keys_from_lvc, dim3((n + 255) / 256), dim3(256), 0, s, lvc, n, keys, vals, weights, sampler_counts);
+}
+void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys, uint32_t* vals, float* weights, const int* sampler_counts, hipStream_t s) {
+    if (bound <= 0) return;
+    hipLaunchKernelGGL(k_fill_keys_devcount, dim3((bound + 255) / 256), dim3(256), 0, s, lvc, bound, keys, vals, weights, sampler_counts);
+}
+void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, LightVertex* lvc,
+                           int* sampler_counts, int* overflow, hipStream_t s) {
+    const int chunks = (cap + 255) / 256;
+    hipLaunchKernelGGL(k_gather_compact, dim3((unsigned)(world * chunks)), dim3(256), 0, s, gathered, counts_all, world, cap, lvc_capacity, lvc,
+                       sampler_counts, overflow);
+}
+void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s) {
+    const int bands = (height + 7) / 8, per_rank = (bands + world - 1) / world;
+    const size_t n = (size_t)(unpack_all ? world : 1) * per_rank * 8 * width;
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_pack_bands, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(accum), width, height, rank, world,
+                       reinterpret_cast<float4*>(packed), unpack_all ? 1 : 0);
 }
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_subspace_ranges, dim3((capacity + 255) / 256), dim3(256), 0, s, sorted_keys, sampler_counts, sub);

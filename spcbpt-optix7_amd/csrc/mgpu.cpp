@@ -1,0 +1,428 @@
+// libspcbpt_mgpu.so -- the N-GPU host of the hot path (include/spcbpt_mgpu.h): one rank per MI355X, RCCL over xGMI.  Everything
+// device-side lives in libspcbpt_hip.so behind include/spcbpt.h (spcbpt_lvc_export_on, spcbpt_lvc_import_gathered,
+// spcbpt_film_pack_bands / _unpack_bands); this file owns the communicator, its stream, the gather buffers and the call order.
+// The reference has no counterpart (single GPU: optixPathTracer.cpp:791-822); the partitioning is BASELINE.json's north_star.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/spcbpt_mgpu.h"
+
+namespace {
+
+constexpr size_t kVertexBytes = sizeof(spcbpt_light_vertex);   // 96
+
+struct LocalGroup;
+
+}  // namespace
+
+struct spcbpt_comm {
+    spcbpt_ctx* ctx = nullptr;
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t nccl = nullptr;      // RCCL transport, or
+    LocalGroup* grp = nullptr;      // ranks that share one device (copies as the transport)
+    hipStream_t xs = nullptr;       // exchange stream (high priority: small transfers next to persistent render kernels)
+    int shard_cap = 0;              // vertices per shard in exchange 1 (agreed by all ranks)
+    int scratch_cap = 0;            // upper limit of shard_cap: what a light pass of this rank can produce at most
+    void* d_gather = nullptr; size_t gather_bytes = 0;      // world x shard_cap vertices
+    int* d_counts_all = nullptr;                            // world x {vertex_count, path_count}
+    int* h_counts_all = nullptr;                            // pinned mirror (calibration only)
+    float* d_pack = nullptr; float* d_pack_all = nullptr; size_t pack_floats = 0;   // film bands: own block / every rank's
+    void* d_stage = nullptr; size_t stage_bytes = 0;        // broadcast staging
+    double* d_scalar = nullptr;                             // barrier / max
+    std::string error;
+    // local transport: what this rank contributed to the collective in flight
+    void* l_send = nullptr; void* l_counts = nullptr; hipEvent_t l_ready = nullptr; bool l_posted = false;
+    bool l_film_posted = false; void* l_film_out = nullptr;
+};
+
+namespace {
+
+struct LocalGroup {
+    std::vector<spcbpt_comm*> ranks;
+    std::mutex mu;
+    int refs = 0;
+    // broadcast_subspace
+    bool have_tuple = false;
+    std::vector<spcbpt_tree_node> et, lt;
+    std::vector<float> q, g;
+    std::vector<bool> wants_tuple;
+    double running_max = 0.0; int max_calls = 0;
+    int calib_max = 0;
+};
+
+int fail(spcbpt_comm* c, int code, const std::string& msg) {
+    if (c) c->error = msg;
+    return code;
+}
+#define HIPX(c, expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return fail(c, SPCBPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+#define NCCLX(c, expr)                                                                                    \
+    do {                                                                                                  \
+        ncclResult_t r__ = (expr);                                                                        \
+        if (r__ != ncclSuccess) return fail(c, SPCBPT_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+    } while (0)
+#define CTXX(c, expr)                                                                                     \
+    do {                                                                                                  \
+        int r__ = (expr);                                                                                 \
+        if (r__ != 0) return fail(c, r__, std::string(#expr) + ": " + spcbpt_last_error((c)->ctx));          \
+    } while (0)
+
+int ensure_gather(spcbpt_comm* c) {
+    const size_t need = (size_t)c->world * (size_t)c->shard_cap * kVertexBytes;
+    if (need > c->gather_bytes) {
+        HIPX(c, hipStreamSynchronize(c->xs));
+        if (c->d_gather) (void)hipFree(c->d_gather);
+        c->d_gather = nullptr;
+        HIPX(c, hipMalloc(&c->d_gather, need));
+        c->gather_bytes = need;
+    }
+    return 0;
+}
+
+int common_init(spcbpt_comm* c) {
+    HIPX(c, hipGetDevice(&c->device));
+    int least = 0, greatest = 0;
+    HIPX(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPX(c, hipStreamCreateWithPriority(&c->xs, hipStreamNonBlocking, greatest));
+    HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts_all), (size_t)c->world * 2 * sizeof(int)));
+    HIPX(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_counts_all), (size_t)c->world * 2 * sizeof(int)));
+    HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_scalar), 2 * sizeof(double)));
+    HIPX(c, hipEventCreateWithFlags(&c->l_ready, hipEventDisableTiming));
+    // default shard capacity: whatever this rank's light pass can produce (export hands out the LVC capacity = the whole job's
+    // num_core x core_padding; a rank's own scratch is its core_count x core_padding <= that).  Tightened by calibrate.
+    spcbpt_light_trace_params lt;
+    CTXX(c, spcbpt_get_light_trace(c->ctx, &lt));
+    c->scratch_cap = (int)std::min<long long>((long long)lt.core_count * lt.core_padding, 0x7fffffff);
+    c->shard_cap = c->scratch_cap;
+    return 0;
+}
+
+// every rank's block of exchange 2: ceil(bands / world) bands of 8 rows
+int film_block_floats(spcbpt_comm* c, size_t* floats) {
+    int w = 0, h = 0;
+    CTXX(c, spcbpt_image_size(c->ctx, &w, &h));
+    if (w < 1 || h < 1) return fail(c, SPCBPT_ERR_STATE, "gather_film before spcbpt_resize");
+    const int bands = (h + 7) / 8, per_rank = (bands + c->world - 1) / c->world;
+    *floats = (size_t)per_rank * 8 * (size_t)w * 4;
+    return 0;
+}
+int ensure_pack(spcbpt_comm* c, size_t floats) {
+    if (floats > c->pack_floats) {
+        HIPX(c, hipStreamSynchronize(c->xs));
+        if (c->d_pack) (void)hipFree(c->d_pack);
+        if (c->d_pack_all) (void)hipFree(c->d_pack_all);
+        c->d_pack = c->d_pack_all = nullptr;
+        HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_pack), floats * sizeof(float)));
+        HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_pack_all), floats * sizeof(float) * (size_t)c->world));
+        c->pack_floats = floats;
+    }
+    return 0;
+}
+int ensure_stage(spcbpt_comm* c, size_t bytes) {
+    if (bytes > c->stage_bytes) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        c->d_stage = nullptr;
+        HIPX(c, hipMalloc(&c->d_stage, bytes));
+        c->stage_bytes = bytes;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spcbpt_comm_unique_id(char id[SPCBPT_UNIQUE_ID_BYTES]) {
+    if (!id) return SPCBPT_ERR_INVALID_ARG;
+    ncclUniqueId u;
+    if (ncclGetUniqueId(&u) != ncclSuccess) return SPCBPT_ERR_HIP;
+    static_assert(sizeof(u.internal) == SPCBPT_UNIQUE_ID_BYTES, "unique id size");
+    memcpy(id, u.internal, SPCBPT_UNIQUE_ID_BYTES);
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_create(spcbpt_ctx* ctx, int rank, int world, const char id[SPCBPT_UNIQUE_ID_BYTES], spcbpt_comm** out) {
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return SPCBPT_ERR_INVALID_ARG;
+    *out = nullptr;
+    spcbpt_comm* c = new spcbpt_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    int rc = common_init(c);
+    if (rc) { fprintf(stderr, "spcbpt_comm_create: %s\n", c->error.c_str()); delete c; return rc; }
+    ncclUniqueId u;
+    memcpy(u.internal, id, SPCBPT_UNIQUE_ID_BYTES);
+    ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);
+    if (r != ncclSuccess) { fprintf(stderr, "spcbpt_comm_create: ncclCommInitRank: %s\n", ncclGetErrorString(r)); delete c; return SPCBPT_ERR_HIP; }
+    *out = c;
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_create_local(spcbpt_ctx* const* ctxs, int world, spcbpt_comm** out) {
+    if (!ctxs || !out || world < 1) return SPCBPT_ERR_INVALID_ARG;
+    LocalGroup* g = new LocalGroup();
+    g->wants_tuple.assign(world, false);
+    for (int r = 0; r < world; r++) {
+        spcbpt_comm* c = new spcbpt_comm();
+        c->ctx = ctxs[r]; c->rank = r; c->world = world; c->grp = g;
+        int rc = common_init(c);
+        if (rc) { fprintf(stderr, "spcbpt_comm_create_local: %s\n", c->error.c_str()); delete c; return rc; }
+        g->ranks.push_back(c);
+        out[r] = c;
+    }
+    g->refs = world;
+    // one agreed capacity: the largest scratch of any rank
+    int cap = 0;
+    for (spcbpt_comm* c : g->ranks) cap = std::max(cap, c->scratch_cap);
+    for (spcbpt_comm* c : g->ranks) c->shard_cap = c->scratch_cap = cap;
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_destroy(spcbpt_comm* c) {
+    if (!c) return SPCBPT_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->xs) (void)hipStreamSynchronize(c->xs);
+    if (c->nccl) (void)ncclCommDestroy(c->nccl);
+    if (c->d_gather) (void)hipFree(c->d_gather);
+    if (c->d_counts_all) (void)hipFree(c->d_counts_all);
+    if (c->h_counts_all) (void)hipHostFree(c->h_counts_all);
+    if (c->d_pack) (void)hipFree(c->d_pack);
+    if (c->d_pack_all) (void)hipFree(c->d_pack_all);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_scalar) (void)hipFree(c->d_scalar);
+    if (c->l_ready) (void)hipEventDestroy(c->l_ready);
+    if (c->xs) (void)hipStreamDestroy(c->xs);
+    if (c->grp && --c->grp->refs == 0) delete c->grp;
+    delete c;
+    return SPCBPT_OK;
+}
+
+const char* spcbpt_comm_last_error(const spcbpt_comm* c) { return c ? c->error.c_str() : "null communicator"; }
+
+int spcbpt_comm_set_shard_capacity(spcbpt_comm* c, int vertices) {
+    if (!c || vertices < 1) return SPCBPT_ERR_INVALID_ARG;
+    c->shard_cap = std::min(vertices, c->scratch_cap);
+    return SPCBPT_OK;
+}
+int spcbpt_comm_get_shard_capacity(const spcbpt_comm* c, int* vertices) {
+    if (!c || !vertices) return SPCBPT_ERR_INVALID_ARG;
+    *vertices = c->shard_cap;
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
+    if (!c) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    int rc = ensure_gather(c);
+    if (rc) return rc;
+    void *dv = nullptr, *dc = nullptr;
+    int cap = 0;
+    CTXX(c, spcbpt_lvc_export_on(c->ctx, c->xs, &dv, &dc, &cap));   // xs waits for the light pass on the device
+    if (cap < c->shard_cap) return fail(c, SPCBPT_ERR_CAPACITY, "exchange_lvc: the LVC is smaller than the shard capacity");
+    if (c->nccl) {
+        NCCLX(c, ncclGroupStart());
+        NCCLX(c, ncclAllGather(dc, c->d_counts_all, 2, ncclInt32, c->nccl, c->xs));
+        NCCLX(c, ncclAllGather(dv, c->d_gather, (size_t)c->shard_cap * kVertexBytes, ncclUint8, c->nccl, c->xs));
+        NCCLX(c, ncclGroupEnd());
+        CTXX(c, spcbpt_lvc_import_gathered(c->ctx, c->d_gather, c->d_counts_all, c->world, c->shard_cap, c->xs));
+        return SPCBPT_OK;
+    }
+    LocalGroup* g = c->grp;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (c->l_posted) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc (local): this rank already posted; every rank must call before any calls again");
+    c->l_send = dv; c->l_counts = dc; c->l_posted = true;
+    HIPX(c, hipEventRecord(c->l_ready, c->xs));                       // behind the wait for the light pass
+    for (spcbpt_comm* s : g->ranks) if (!s->l_posted) return SPCBPT_OK;    // completed by the last rank to post
+    for (spcbpt_comm* s : g->ranks) { int r2 = ensure_gather(s); if (r2) return r2; }
+    // copies first (on every destination's stream), then the imports -- which overwrite the send buffers -- behind all of them
+    for (spcbpt_comm* d : g->ranks) {
+        for (spcbpt_comm* s : g->ranks) {
+            HIPX(d, hipStreamWaitEvent(d->xs, s->l_ready, 0));
+            HIPX(d, hipMemcpyAsync(reinterpret_cast<char*>(d->d_gather) + (size_t)s->rank * d->shard_cap * kVertexBytes, s->l_send,
+                                   (size_t)d->shard_cap * kVertexBytes, hipMemcpyDeviceToDevice, d->xs));
+            HIPX(d, hipMemcpyAsync(d->d_counts_all + 2 * s->rank, s->l_counts, 2 * sizeof(int), hipMemcpyDeviceToDevice, d->xs));
+        }
+    }
+    std::vector<hipEvent_t> copied(g->ranks.size());
+    for (size_t k = 0; k < g->ranks.size(); k++) {
+        HIPX(c, hipEventCreateWithFlags(&copied[k], hipEventDisableTiming));
+        HIPX(c, hipEventRecord(copied[k], g->ranks[k]->xs));
+    }
+    int result = SPCBPT_OK;
+    for (spcbpt_comm* d : g->ranks) {
+        for (size_t k = 0; k < copied.size(); k++) (void)hipStreamWaitEvent(d->xs, copied[k], 0);
+        int r2 = spcbpt_lvc_import_gathered(d->ctx, d->d_gather, d->d_counts_all, d->world, d->shard_cap, d->xs);
+        if (r2 && !result) result = fail(c, r2, std::string("spcbpt_lvc_import_gathered: ") + spcbpt_last_error(d->ctx));
+        d->l_posted = false;
+    }
+    for (hipEvent_t e : copied) (void)hipEventDestroy(e);
+    return result;
+}
+
+int spcbpt_comm_calibrate(spcbpt_comm* c, int passes, uint32_t first_frame, float slack) {
+    if (!c || passes < 1 || !(slack >= 1.0f)) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    int own_max = 0;
+    for (int k = 0; k < passes; k++) {
+        CTXX(c, spcbpt_launch(c->ctx, "light trace", first_frame + (uint32_t)k, 0, 0, 1));
+        int n = 0;
+        CTXX(c, spcbpt_lvc_read(c->ctx, nullptr, 0, &n));   // host wait: start-up only
+        own_max = std::max(own_max, n);
+    }
+    int global_max = own_max;
+    if (c->nccl) {
+        int* d = reinterpret_cast<int*>(c->d_scalar);
+        HIPX(c, hipMemcpyAsync(d, &own_max, sizeof(int), hipMemcpyHostToDevice, c->xs));
+        NCCLX(c, ncclAllReduce(d, d + 1, 1, ncclInt32, ncclMax, c->nccl, c->xs));
+        HIPX(c, hipMemcpyAsync(&global_max, d + 1, sizeof(int), hipMemcpyDeviceToHost, c->xs));
+        HIPX(c, hipStreamSynchronize(c->xs));
+    } else {   // local: the ranks calibrate one after the other; the agreed capacity follows the largest shard seen so far
+        std::lock_guard<std::mutex> lk(c->grp->mu);
+        c->grp->calib_max = std::max(c->grp->calib_max, own_max);
+        global_max = c->grp->calib_max;
+    }
+    int cap = (int)((double)global_max * slack) + 1;
+    cap = (cap + 1023) / 1024 * 1024;
+    if (c->nccl) c->shard_cap = std::max(1024, std::min(cap, c->scratch_cap));
+    else {
+        std::lock_guard<std::mutex> lk(c->grp->mu);
+        for (spcbpt_comm* s : c->grp->ranks) s->shard_cap = std::max(1024, std::min(cap, s->scratch_cap));
+    }
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_gather_film(spcbpt_comm* c, void* out_device) {
+    if (!c) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    size_t floats = 0;
+    int rc = film_block_floats(c, &floats);
+    if (rc) return rc;
+    rc = ensure_pack(c, floats);
+    if (rc) return rc;
+    void* accum = nullptr;
+    CTXX(c, spcbpt_accum_device_ptr(c->ctx, &accum));
+    void* out = out_device ? out_device : accum;
+    CTXX(c, spcbpt_film_pack_bands(c->ctx, c->rank, c->world, c->d_pack, c->xs));   // waits for this rank's render streams
+    if (c->nccl) {
+        NCCLX(c, ncclAllGather(c->d_pack, c->d_pack_all, floats, ncclFloat, c->nccl, c->xs));
+        CTXX(c, spcbpt_film_unpack_bands(c->ctx, c->world, c->d_pack_all, out, c->xs));
+        HIPX(c, hipStreamSynchronize(c->xs));
+        return SPCBPT_OK;
+    }
+    LocalGroup* g = c->grp;
+    std::lock_guard<std::mutex> lk(g->mu);
+    c->l_film_posted = true; c->l_film_out = out;
+    HIPX(c, hipEventRecord(c->l_ready, c->xs));
+    for (spcbpt_comm* s : g->ranks) if (!s->l_film_posted) return SPCBPT_OK;   // the image is complete when the last rank has called
+    for (spcbpt_comm* d : g->ranks) {
+        for (spcbpt_comm* s : g->ranks) {
+            HIPX(d, hipStreamWaitEvent(d->xs, s->l_ready, 0));
+            HIPX(d, hipMemcpyAsync(d->d_pack_all + (size_t)s->rank * floats, s->d_pack, floats * sizeof(float), hipMemcpyDeviceToDevice, d->xs));
+        }
+        int r2 = spcbpt_film_unpack_bands(d->ctx, d->world, d->d_pack_all, d->l_film_out, d->xs);
+        if (r2) return fail(c, r2, std::string("spcbpt_film_unpack_bands: ") + spcbpt_last_error(d->ctx));
+    }
+    for (spcbpt_comm* d : g->ranks) { HIPX(d, hipStreamSynchronize(d->xs)); d->l_film_posted = false; }
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_broadcast_subspace(spcbpt_comm* c, int root) {
+    if (!c || root < 0 || root >= c->world) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    const size_t NS = SPCBPT_NUM_SUBSPACE;
+    std::vector<spcbpt_tree_node> et, lt;
+    std::vector<float> q(NS), g(NS * NS);
+    int ne = 0, nl = 0;
+    if (c->rank == root) {
+        CTXX(c, spcbpt_get_subspace(c->ctx, nullptr, &ne, 0, nullptr, &nl, 0, nullptr, nullptr));
+        et.resize(ne); lt.resize(nl);
+        CTXX(c, spcbpt_get_subspace(c->ctx, et.data(), &ne, ne, lt.data(), &nl, nl, q.data(), g.data()));
+    }
+    if (c->nccl) {
+        int sizes[2] = {ne, nl};
+        int* d = reinterpret_cast<int*>(c->d_scalar);
+        HIPX(c, hipMemcpyAsync(d, sizes, sizeof(sizes), hipMemcpyHostToDevice, c->xs));
+        NCCLX(c, ncclBroadcast(d, d, 2, ncclInt32, root, c->nccl, c->xs));
+        HIPX(c, hipMemcpyAsync(sizes, d, sizeof(sizes), hipMemcpyDeviceToHost, c->xs));
+        HIPX(c, hipStreamSynchronize(c->xs));
+        ne = sizes[0]; nl = sizes[1];
+        if (ne < 1 || nl < 1) return fail(c, SPCBPT_ERR_STATE, "broadcast_subspace: the root has no tuple");
+        const size_t b_et = (size_t)ne * sizeof(spcbpt_tree_node), b_lt = (size_t)nl * sizeof(spcbpt_tree_node), b_q = NS * 4, b_g = NS * NS * 4;
+        const size_t total = b_et + b_lt + b_q + b_g;
+        int rc = ensure_stage(c, total);
+        if (rc) return rc;
+        char* s = reinterpret_cast<char*>(c->d_stage);
+        if (c->rank == root) {
+            HIPX(c, hipMemcpyAsync(s, et.data(), b_et, hipMemcpyHostToDevice, c->xs));
+            HIPX(c, hipMemcpyAsync(s + b_et, lt.data(), b_lt, hipMemcpyHostToDevice, c->xs));
+            HIPX(c, hipMemcpyAsync(s + b_et + b_lt, q.data(), b_q, hipMemcpyHostToDevice, c->xs));
+            HIPX(c, hipMemcpyAsync(s + b_et + b_lt + b_q, g.data(), b_g, hipMemcpyHostToDevice, c->xs));
+        }
+        NCCLX(c, ncclBroadcast(s, s, total, ncclUint8, root, c->nccl, c->xs));
+        if (c->rank != root) {
+            et.resize(ne); lt.resize(nl);
+            HIPX(c, hipMemcpyAsync(et.data(), s, b_et, hipMemcpyDeviceToHost, c->xs));
+            HIPX(c, hipMemcpyAsync(lt.data(), s + b_et, b_lt, hipMemcpyDeviceToHost, c->xs));
+            HIPX(c, hipMemcpyAsync(q.data(), s + b_et + b_lt, b_q, hipMemcpyDeviceToHost, c->xs));
+            HIPX(c, hipMemcpyAsync(g.data(), s + b_et + b_lt + b_q, b_g, hipMemcpyDeviceToHost, c->xs));
+        }
+        HIPX(c, hipStreamSynchronize(c->xs));
+        if (c->rank != root) CTXX(c, spcbpt_set_subspace(c->ctx, et.data(), ne, lt.data(), nl, q.data(), g.data()));
+        return SPCBPT_OK;
+    }
+    LocalGroup* grp = c->grp;
+    std::lock_guard<std::mutex> lk(grp->mu);
+    if (c->rank == root) {
+        grp->et = et; grp->lt = lt; grp->q = q; grp->g = g; grp->have_tuple = true;
+        for (spcbpt_comm* s : grp->ranks)
+            if (grp->wants_tuple[s->rank]) {
+                int r2 = spcbpt_set_subspace(s->ctx, grp->et.data(), (int)grp->et.size(), grp->lt.data(), (int)grp->lt.size(), grp->q.data(), grp->g.data());
+                if (r2) return fail(c, r2, std::string("spcbpt_set_subspace: ") + spcbpt_last_error(s->ctx));
+                grp->wants_tuple[s->rank] = false;
+            }
+    } else if (grp->have_tuple) {
+        CTXX(c, spcbpt_set_subspace(c->ctx, grp->et.data(), (int)grp->et.size(), grp->lt.data(), (int)grp->lt.size(), grp->q.data(), grp->g.data()));
+    } else {
+        grp->wants_tuple[c->rank] = true;   // installed when the root calls
+    }
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_barrier(spcbpt_comm* c) {
+    if (!c) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    if (c->nccl) {
+        float* d = reinterpret_cast<float*>(c->d_scalar);
+        NCCLX(c, ncclAllReduce(d, d + 1, 1, ncclFloat, ncclSum, c->nccl, c->xs));
+    }
+    HIPX(c, hipStreamSynchronize(c->xs));
+    return SPCBPT_OK;
+}
+
+int spcbpt_comm_max_double(spcbpt_comm* c, double* value) {
+    if (!c || !value) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    if (c->nccl) {
+        HIPX(c, hipMemcpyAsync(c->d_scalar, value, sizeof(double), hipMemcpyHostToDevice, c->xs));
+        NCCLX(c, ncclAllReduce(c->d_scalar, c->d_scalar + 1, 1, ncclDouble, ncclMax, c->nccl, c->xs));
+        HIPX(c, hipMemcpyAsync(value, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, c->xs));
+        HIPX(c, hipStreamSynchronize(c->xs));
+        return SPCBPT_OK;
+    }
+    std::lock_guard<std::mutex> lk(c->grp->mu);   // local: the running maximum (exact once every rank has called)
+    if (c->grp->max_calls % c->world == 0) c->grp->running_max = *value;
+    c->grp->running_max = std::max(c->grp->running_max, *value);
+    c->grp->max_calls++;
+    *value = c->grp->running_max;
+    return SPCBPT_OK;
+}
+
+}  // extern "C"

@@ -96,6 +96,50 @@ def test_c5_hallway_spcbpt_and_pt_converge_to_the_same_mean(hallway_trained, pkg
     rel = abs(sp.mean() - pt.mean()) / pt.mean()
     print("hallway means: pt %.6g (%d spp)  spcbpt %.6g (%d spp)  rel %.4f" % (pt.mean(), n_pt, sp.mean(), n_sp, rel))
     assert rel < 0.01, (pt.mean(), sp.mean())
+    # C5': the comparator "plain BDPT" (uniformSample over the cache, same RMIS weights) is unbiased too; its batch-mean standard
+    # error is 0.6 % at 800 spp -> ~0.2 % here
+    r.set_connection_sampler(1)
+    r.clear_accum()
+    for f in range(n_sp):
+        r.render_frame("SPCBPT_eye", f, launch_frame=100000 + f)
+    un = r.read_accum()[..., :3].astype(np.float64)
+    r.set_connection_sampler(0)
+    rel_u = abs(un.mean() - pt.mean()) / pt.mean()
+    print("hallway means: uniformSample %.6g (%d spp)  rel to pt %.4f" % (un.mean(), n_sp, rel_u))
+    assert np.isfinite(un).all() and rel_u < 0.01, (pt.mean(), un.mean())
+
+
+def test_c5_plain_bdpt_comparator_matches_oracle(hallway_trained, pkg, ob):
+    """SubspaceSampler_device::uniformSample (cuProg.h:283-289) as the light-vertex sampler of "SPCBPT_eye": one random number per
+    connection, pmf = path_count / vertex_count.  Same seeds on both sides -> pixel parity; and the mode really changes the
+    estimator (it is not the two-stage sampler under another name)."""
+    scene, _, tup = hallway_trained
+    W, H = 128, 72
+    r = _renderer(pkg, scene, W, H, (20000, 52, 1))
+    o = ob.Oracle(scene)
+    _setup(o, scene, W, H, (20000, 52, 1))
+    r.set_subspace(*tup); o.set_subspace(*tup)
+    o.set_cmf_double(True)
+    for f in range(4):
+        r.render_frame("SPCBPT_eye", f)
+    two_stage = r.read_accum()[..., :3].copy()
+    # uniformSample picks jump_buffer[rnd * vertex_count]: ONE light vertex more or fewer on one side (a Russian-roulette decision
+    # within rounding -- the two light passes differ by ~0.1 % of their vertices on this glossy scene) shifts every draw, so the
+    # comparison runs on the oracle's cache imported into the product (the two-stage sampler does not need this: CMF bins are
+    # stable under such flips)
+    r.set_connection_sampler(1); o.set_uniform_lvc(True)
+    r.clear_accum()
+    for f in range(4):
+        o.launch("light trace", f + 1)
+        r.lvc_import(o.lvc_read())
+        r.build_sampler(); o.build_sampler()
+        r.launch("SPCBPT_eye", f); o.launch("SPCBPT_eye", f)
+    got = r.read_accum()[..., :3]
+    s = image_parity(got, o.read_accum()[..., :3])
+    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s
+    assert not np.array_equal(got, two_stage) and (np.abs(got - two_stage).max(axis=2) > 1e-4).mean() > 0.5
+    with pytest.raises(pkg.SpcbptError):
+        r.set_connection_sampler(7)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

@@ -106,6 +106,10 @@ def main():
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
+    ap.add_argument("--exchange", default="native", choices=["native", "python"],
+                    help="native (default): the C++ RCCL host (libspcbpt_mgpu.so: all-gather of fixed-capacity shards + device counts, "
+                         "device-side compaction, no host wait per frame, film band gather); python: the torch.distributed harness of "
+                         "dist.FrameExchanger (per-frame host syncs; kept for comparison)")
     args = ap.parse_args()
 
     # exactly ONE line on stdout: native libraries (RCCL prints a version banner) write to fd 1 too, so fd 1 is pointed
@@ -167,15 +171,27 @@ def main():
         else:
             r.set_subspace()
     tup = r.get_subspace() if (rank == 0 or dist is None) else None
-    if dist is not None:
+    begin, count = pkg.dist.core_range(ncore, rank, world)
+    ex = comm = None
+    if dist is not None and args.exchange == "python":
         tup = pkg.dist.broadcast_subspace(tup, 0, device)
         if rank != 0:
             r.set_subspace(*tup)
+        r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
+        ex = pkg.dist.FrameExchanger(r, rank, world, device)
+    elif dist is not None:
+        # the C++ N-GPU host: its own RCCL communicator per rank (the unique id travels over torch.distributed, which otherwise only
+        # provides the barrier and the max-over-ranks of the timing contract)
+        r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
+        uid = torch.tensor(list(pkg.dist.unique_id() if rank == 0 else bytes(pkg.dist.UNIQUE_ID_BYTES)), dtype=torch.uint8, device=device)
+        dist.broadcast(uid, 0)
+        comm = pkg.dist.Comm(r, rank, world, bytes(uid.cpu().tolist()))
+        comm.broadcast_subspace(0)             # rank 0 trained; ncclBroadcast of trees, Q, Gamma
+        comm.calibrate(passes=2, slack=1.5)    # shard capacity of exchange 1 from two light passes (host waits: start-up only)
+    else:
+        r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
     t_pre = time.perf_counter() - t_pre
-    begin, count = pkg.dist.core_range(ncore, rank, world)
-    r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
     rows = pkg.dist.band_rows(args.height, rank, world)
-    ex = pkg.dist.FrameExchanger(r, rank, world, device) if dist is not None else None
     info = r.scene_info()
 
     # The light pass of the NEXT frame is launched before this frame's shards are gathered and its sampler is built, so the
@@ -199,6 +215,8 @@ def main():
             r.launch("light trace", state["next_light"]); state["next_light"] += 1   # consumed by the next step
         if ex is not None:
             ex.allgather_lvc()
+        elif comm is not None:
+            comm.exchange_lvc()                # queues the all-gather + compaction on the communicator's stream; no host wait
         r.build_sampler()
         if isolate and (batch == 1 or len(queued) == batch - 1):
             r.sync()                           # roofline pass: the light pass launched above must not share the GPU with the eye kernel
@@ -234,6 +252,8 @@ def main():
         r.launch("light trace", state["next_light"]); state["next_light"] += 1
     if ex is not None:
         ex.allgather_lvc()
+    elif comm is not None:
+        comm.exchange_lvc()
     r.build_sampler()
     r.enable_counters(True)
     r.reset_counters()
@@ -272,6 +292,8 @@ def main():
     flush()
     if ex is not None:
         ex.reduce_framebuffer()
+    elif comm is not None:
+        comm.gather_film()                     # read-out: every rank ends up with the whole film (band all-gather, 4 MB per rank)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -296,7 +318,7 @@ def main():
         traffic = traffic_low = valu_issue = None
         traffic_note = "no PMC summary for this code and launch form (profiles/traffic_latest.json)"
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile) and world == 1 and ex is None and args.light_geometry == "lane" and args.tuple == "trained":
+        if os.path.exists(tfile) and world == 1 and ex is None and comm is None and args.light_geometry == "lane" and args.tuple == "trained":
             try:
                 t = json.load(open(tfile))
                 if int(t.get("frames_per_launch", 1)) == batch and t.get("source_hash") == pkg.api.source_hash():
@@ -316,7 +338,7 @@ def main():
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}, light pass geometry "
                                    f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": depth if ahead else 0, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + framebuffer sum over RCCL"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": depth if ahead else 0, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu' if comm is not None else 'torch.distributed harness'}" + (f", shard capacity {comm.shard_capacity} vertices" if comm is not None else "") + ")"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -341,6 +363,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, args, tup)
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -293,6 +293,8 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
  * resampling (part of [2], summed over the lanes that sample); [10..13] 100 MHz wall clock of the megakernel's waves: earliest
  * start, latest end, sum of ends, number of waves (how long the last waves run alone). */
 int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[14]);
+/* Hash of the sources this library was built from (csrc/source_hash.py); the Python mirror refuses a stale library. */
+const char* spcbpt_build_source_hash(void);
 /* Developer probe of the HBM part of the traversal stack.  The per-lane stack holds SPC_STACK_LDS (16) entries in LDS; deeper
  * entries go to a per-thread spill area of 3 * bvh_depth - 16 words, which cannot overflow.  _arm fills every area allocated
  * so far with a word no stack entry can hold, _count returns how many words kernels have overwritten since (tests prove the

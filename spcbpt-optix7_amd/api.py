@@ -98,15 +98,9 @@ BYTES_ACTUAL = dict(node=64, tri=48, hit=64, mat=64, tex=16, tree=16, cmf=4, sub
 
 
 def source_hash() -> str:
-    """sha256 over the kernel sources: profiles/traffic_latest.json carries the hash of the code its PMC passes profiled, and
-    bench.py reports that traffic only for the same code (the GPU box has no .git to compare heads with)."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
-            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+    """csrc/source_hash.py: the hash the Makefile embeds in the library (spcbpt_build_source_hash)."""
+    import runpy
+    return runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "source_hash.py"))["source_hash"]()
 
 
 def algorithmic_bytes(c: dict, table: Optional[dict] = None) -> int:
@@ -434,7 +428,15 @@ def load_library(path: str = LIB_PATH):
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)   # libspcbpt_mgpu.so resolves the C ABI against this handle
+    # a library built from other sources than the tree holds must not be tested or benchmarked silently
+    try:
+        lib.spcbpt_build_source_hash.restype = C.c_char_p
+        built = lib.spcbpt_build_source_hash().decode()
+    except AttributeError:
+        built = "none"
+    if path == LIB_PATH and built != source_hash() and not os.environ.get("SPCBPT_ALLOW_STALE_LIB"):
+        raise SpcbptError(f"{path} was built from other sources (library {built}, tree {source_hash()}): run `make -C spcbpt-optix7_amd/csrc`")
     vp, i32, u32, f32p = C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_float)
     sig = {
         "spcbpt_create": [C.POINTER(SceneDesc), i32, C.POINTER(vp)],
@@ -526,7 +528,8 @@ EXPORTED_SYMBOLS = [
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
-    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit",
+    "spcbpt_build_source_hash", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",

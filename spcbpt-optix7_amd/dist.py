@@ -159,11 +159,131 @@ class FrameExchanger:
         return total
 
     def reduce_framebuffer(self):
-        """Sum of the per-rank accum buffers (disjoint bands, zero elsewhere) in place on every rank."""
+        """Sum of the per-rank accum buffers (disjoint bands, zero elsewhere) into a SEPARATE tensor, which is returned: the
+        rank's own accum buffer keeps holding its own bands only, so the call may be repeated (a progressive read-out every K
+        frames) without summing already-reduced bands again.  (The C++ host gathers bands instead: Comm.gather_film.)"""
         torch = self.torch
         import torch.distributed as dist
         r = self.r
         r.sync()
         acc = device_view(r.accum_device_ptr(), r.width * r.height * 16, self.device).view(torch.float32)
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        own = torch.zeros_like(acc)
+        own_rows = torch.tensor(rows_of_rank(r.height, self.rank, self.world), dtype=torch.long, device=self.device)
+        img = acc.view(r.height, r.width * 4)
+        own.view(r.height, r.width * 4)[own_rows] = img[own_rows]     # bands this rank does not own are zero whatever accum holds
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(self.device)
+        return own.view(r.height, r.width, 4)
+
+
+# ---- the C++ RCCL host (libspcbpt_mgpu.so, include/spcbpt_mgpu.h) -------------------------------------------------------------
+import ctypes as _C
+import os as _os
+
+MGPU_LIB_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "csrc", "libspcbpt_mgpu.so")
+UNIQUE_ID_BYTES = 128
+MGPU_SYMBOLS = ["spcbpt_comm_unique_id", "spcbpt_comm_create", "spcbpt_comm_create_local", "spcbpt_comm_destroy", "spcbpt_comm_last_error",
+                "spcbpt_comm_set_shard_capacity", "spcbpt_comm_get_shard_capacity", "spcbpt_comm_calibrate", "spcbpt_comm_exchange_lvc",
+                "spcbpt_comm_gather_film", "spcbpt_comm_broadcast_subspace", "spcbpt_comm_barrier", "spcbpt_comm_max_double"]
+_mgpu = None
+
+
+def load_mgpu():
+    """ctypes handle of libspcbpt_mgpu.so (needs libspcbpt_hip.so and librccl; loads without a GPU)."""
+    global _mgpu
+    if _mgpu is None:
+        from .api import load_library
+        load_library()
+        if not _os.path.exists(MGPU_LIB_PATH):
+            raise RuntimeError(f"{MGPU_LIB_PATH} missing: run `make -C spcbpt-optix7_amd/csrc` (there is no Python fallback for the N-GPU host)")
+        lib = _C.CDLL(MGPU_LIB_PATH, mode=_C.RTLD_GLOBAL)
+        vp, i32 = _C.c_void_p, _C.c_int32
+        sig = {"spcbpt_comm_unique_id": [_C.c_char_p], "spcbpt_comm_create": [vp, i32, i32, _C.c_char_p, _C.POINTER(vp)],
+               "spcbpt_comm_create_local": [_C.POINTER(vp), i32, _C.POINTER(vp)], "spcbpt_comm_destroy": [vp],
+               "spcbpt_comm_set_shard_capacity": [vp, i32], "spcbpt_comm_get_shard_capacity": [vp, _C.POINTER(i32)],
+               "spcbpt_comm_calibrate": [vp, i32, _C.c_uint32, _C.c_float], "spcbpt_comm_exchange_lvc": [vp],
+               "spcbpt_comm_gather_film": [vp, vp], "spcbpt_comm_broadcast_subspace": [vp, i32], "spcbpt_comm_barrier": [vp],
+               "spcbpt_comm_max_double": [vp, _C.POINTER(_C.c_double)]}
+        for name, args in sig.items():
+            getattr(lib, name).argtypes = args
+            getattr(lib, name).restype = i32
+        lib.spcbpt_comm_last_error.argtypes = [vp]
+        lib.spcbpt_comm_last_error.restype = _C.c_char_p
+        _mgpu = lib
+    return _mgpu
+
+
+def unique_id() -> bytes:
+    buf = _C.create_string_buffer(UNIQUE_ID_BYTES)
+    if load_mgpu().spcbpt_comm_unique_id(buf) != 0:
+        raise RuntimeError("spcbpt_comm_unique_id failed")
+    return buf.raw
+
+
+class Comm:
+    """One rank of the C++ N-GPU host.  `Comm(renderer, rank, world, uid)` = RCCL (every rank constructs its own, collectively);
+    `Comm.local(renderers)` = ranks sharing one device (tests on a one-GPU box): call a collective on EVERY rank before using its
+    result on any of them."""
+
+    def __init__(self, renderer, rank: int, world: int, uid: bytes = None, _handle=None):
+        self.lib = load_mgpu()
+        self.r, self.rank, self.world = renderer, rank, world
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = _C.c_void_p()
+        rc = self.lib.spcbpt_comm_create(renderer.h, rank, world, uid, _C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"spcbpt_comm_create failed ({rc})")
+        self.h = h
+
+    @classmethod
+    def local(cls, renderers):
+        lib = load_mgpu()
+        n = len(renderers)
+        ctxs = (_C.c_void_p * n)(*[r.h for r in renderers])
+        out = (_C.c_void_p * n)()
+        rc = lib.spcbpt_comm_create_local(ctxs, n, out)
+        if rc != 0:
+            raise RuntimeError(f"spcbpt_comm_create_local failed ({rc})")
+        return [cls(r, k, n, _handle=_C.c_void_p(out[k])) for k, r in enumerate(renderers)]
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            from .api import SpcbptError
+            raise SpcbptError(f"{what} failed ({rc}): {self.lib.spcbpt_comm_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.spcbpt_comm_destroy(self.h)
+            self.h = None
+
+    def calibrate(self, passes=2, first_frame=900000, slack=1.5):
+        self._chk(self.lib.spcbpt_comm_calibrate(self.h, passes, first_frame, slack), "comm_calibrate")
+        return self.shard_capacity
+
+    @property
+    def shard_capacity(self):
+        v = _C.c_int32()
+        self._chk(self.lib.spcbpt_comm_get_shard_capacity(self.h, _C.byref(v)), "comm_get_shard_capacity")
+        return int(v.value)
+
+    def set_shard_capacity(self, vertices: int):
+        self._chk(self.lib.spcbpt_comm_set_shard_capacity(self.h, int(vertices)), "comm_set_shard_capacity")
+
+    def exchange_lvc(self):
+        self._chk(self.lib.spcbpt_comm_exchange_lvc(self.h), "comm_exchange_lvc")
+
+    def gather_film(self, out_device_ptr=None):
+        self._chk(self.lib.spcbpt_comm_gather_film(self.h, out_device_ptr), "comm_gather_film")
+
+    def broadcast_subspace(self, root=0):
+        self._chk(self.lib.spcbpt_comm_broadcast_subspace(self.h, root), "comm_broadcast_subspace")
+
+    def barrier(self):
+        self._chk(self.lib.spcbpt_comm_barrier(self.h), "comm_barrier")
+
+    def max_double(self, v: float) -> float:
+        d = _C.c_double(v)
+        self._chk(self.lib.spcbpt_comm_max_double(self.h, _C.byref(d)), "comm_max_double")
+        return float(d.value)

@@ -38,9 +38,16 @@ def ob(pkg):
 @pytest.fixture(scope="session")
 def hip_lib(pkg):
     """the product shared library (cross-compiled by hipcc when missing; needs no GPU to load)"""
-    if not os.path.exists(pkg.api.LIB_PATH):
-        _make(os.path.join(ROOT, "spcbpt-optix7_amd", "csrc"))
-    return pkg.load_library()
+    csrc = os.path.join(ROOT, "spcbpt-optix7_amd", "csrc")
+    if not os.path.exists(pkg.api.LIB_PATH) or not os.path.exists(pkg.dist.MGPU_LIB_PATH):
+        _make(csrc)
+    try:
+        return pkg.load_library()      # refuses a library whose embedded source hash differs from the tree's (api.source_hash)
+    except pkg.SpcbptError as e:
+        if "built from other sources" not in str(e):
+            raise
+        _make(csrc)                    # stale binary: rebuild (hipcc cross-compiles here and compiles on the GPU box), then load
+        return pkg.load_library()
 
 
 def gpu_available():

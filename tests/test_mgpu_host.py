@@ -1,0 +1,161 @@
+"""The C++ N-GPU host (libspcbpt_mgpu.so, include/spcbpt_mgpu.h).
+
+CPU: the library loads and exports every symbol its header declares.
+GPU: (a) `world` ranks sharing the one GPU of the test box (local transport: device copies stand in for RCCL, everything else --
+fixed-capacity shards, device-side counts, gathered compaction, sampler build over an upper bound, band gather -- is the code the
+RCCL ranks run): the gathered film must equal, bit for bit, the frames ONE context renders the plain way; (b) the RCCL transport
+itself at world size 1 (ncclAllGather / ncclBroadcast / ncclAllReduce really run); (c) a shard that does not fit the agreed
+capacity is reported, not truncated.  The 8-GPU run of BASELINE config 4 is the driver's (bench.py --gpus 8 uses this host)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 96, 88          # 11 bands: not a multiple of the rank count
+
+
+def test_every_declared_symbol_is_exported(hip_lib, pkg):
+    src = open(os.path.join(ROOT, "include", "spcbpt_mgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(spcbpt_comm_[a-z_0-9]+)\s*\(", src)))
+    lib = pkg.dist.load_mgpu()
+    assert sorted(pkg.dist.MGPU_SYMBOLS) == names and len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.spcbpt_comm_exchange_lvc(None) == -1 and lib.spcbpt_comm_gather_film(None, None) == -1   # null communicator: an error, not a crash
+
+
+def _make(pkg, scene, batch, lt=(3000, 64, 1)):
+    if batch > 1:
+        os.environ["SPCBPT_EYE_BATCH"] = str(batch)
+    try:
+        r = pkg.Renderer(scene, 0)
+    finally:
+        os.environ.pop("SPCBPT_EYE_BATCH", None)
+    cam = scene.camera
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+    r.resize(W, H)
+    r.set_light_trace(*lt)
+    return r
+
+
+def _single(pkg, scene, nf, lt=(3000, 64, 1)):
+    r = _make(pkg, scene, 1, lt)
+    r.set_subspace()
+    for f in range(nf):
+        r.launch("light trace", f + 1); r.build_sampler(); r.launch("SPCBPT_eye", f)
+    r.sync()
+    return r, r.read_accum().copy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,batch,lt", [(2, 2, (3000, 64, 1)), (3, 1, (3000, 64, 1)), (2, 2, (40, 200, 60))])
+def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt):
+    scene = pkg.scenes.cornell_box()
+    NF = 6
+    single, want = _single(pkg, scene, NF, lt)
+    ranks = []
+    for k in range(world):
+        r = _make(pkg, scene, batch, lt)
+        b, c = pkg.dist.core_range(lt[0], k, world)
+        r.set_light_trace(*lt, core_begin=b, core_count=c)
+        ranks.append(r)
+    ranks[0].set_subspace(*single.get_subspace())             # "rank 0 trained"
+    comms = pkg.dist.Comm.local(ranks)
+    for c in reversed(comms):                                 # non-root ranks may ask before the root has published
+        c.broadcast_subspace(0)
+    for c in comms:
+        c.calibrate(passes=2, slack=1.5)
+    cap = comms[0].shard_capacity
+    assert all(c.shard_capacity == cap for c in comms) and cap < lt[0] * lt[1]
+    for r in ranks:
+        r.set_light_ahead(True)
+        r.launch("light trace", 1)                            # the pass running ahead
+    queued = []
+    for f in range(NF):
+        for r in ranks:
+            r.launch("light trace", f + 2)
+        for c in comms:
+            c.exchange_lvc()                                  # no host wait; completes when the last rank has posted
+        for r in ranks:
+            r.build_sampler()                                 # item count stays on the device
+        queued.append(f)
+        if len(queued) == batch:
+            for k, r in enumerate(ranks):
+                if batch == 1: r.launch("SPCBPT_eye", queued[0], pkg.dist.band_rows(H, k, world))
+                else: r.launch_eye_batch(queued, pkg.dist.band_rows(H, k, world))
+            queued = []
+    for r in ranks:
+        r.sync()
+    own = [r.read_accum().copy() for r in ranks]
+    for k in range(world):                                    # before the gather a rank holds its own bands only
+        others = [y for y in range(H) if (y // 8) % world != k]
+        assert (own[k][others] == 0).all()
+    for c in comms:
+        c.gather_film()
+    for r in ranks:
+        assert np.array_equal(r.read_accum(), want)
+    for c in comms:                                           # a second read-out gathers the same image (no double counting)
+        c.gather_film()
+    assert np.array_equal(ranks[-1].read_accum(), want)
+    # the gathered sampler is the single-GPU sampler
+    sub, cmfs, jump, vc, pc = ranks[0].sampler_read()
+    single.launch("light trace", NF); single.build_sampler()  # the frame the last exchange carried: launch frame NF
+    s2 = single.sampler_read()
+    assert (vc, pc) == (s2[3], s2[4]) and np.array_equal(jump, s2[2]) and np.array_equal(cmfs, s2[1])
+    for c in comms:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_rccl_transport_at_world_size_one(gpu, pkg):
+    scene = pkg.scenes.cornell_box()
+    NF = 4
+    single, want = _single(pkg, scene, NF)
+    r = _make(pkg, scene, 2)
+    c = pkg.dist.Comm(r, 0, 1, pkg.dist.unique_id())          # ncclCommInitRank
+    r.set_subspace(*single.get_subspace())
+    c.broadcast_subspace(0)
+    c.calibrate(passes=1)
+    r.set_light_ahead(True)
+    r.launch("light trace", 1)
+    q = []
+    for f in range(NF):
+        r.launch("light trace", f + 2)
+        c.exchange_lvc()                                      # ncclAllGather of counts and shard on the communicator's stream
+        r.build_sampler()
+        q.append(f)
+        if len(q) == 2:
+            r.launch_eye_batch(q); q = []
+    c.barrier()
+    c.gather_film()
+    assert np.array_equal(r.read_accum(), want)
+    assert c.max_double(3.5) == 3.5
+    c.close()
+
+
+@pytest.mark.gpu
+def test_a_shard_that_does_not_fit_is_reported(gpu, pkg):
+    scene = pkg.scenes.cornell_box()
+    ranks = []
+    for k in range(2):
+        r = _make(pkg, scene, 1)
+        b, c = pkg.dist.core_range(3000, k, 2)
+        r.set_light_trace(3000, 64, 1, core_begin=b, core_count=c)
+        ranks.append(r)
+    ranks[0].set_subspace(); ranks[1].set_subspace(*ranks[0].get_subspace())
+    comms = pkg.dist.Comm.local(ranks)
+    for c in comms:
+        c.set_shard_capacity(1024)                            # a rank's shard holds ~4 500 vertices
+    for r in ranks:
+        r.launch("light trace", 1)
+    for c in comms:
+        c.exchange_lvc()
+    for r in ranks:
+        r.build_sampler()
+    with pytest.raises(pkg.SpcbptError, match="shard"):
+        ranks[0].sync()
+    for c in comms:
+        c.close()

@@ -168,6 +168,9 @@ int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_t
     if (rc) return rc;
     rc = upload_tree(lt, nl, d_light_tree, h_light_tree);
     if (rc) return rc;
+    tree_has_direction = false;
+    for (int i = 0; i < ne; i++) if (!et[i].leaf && et[i].type == 2) tree_has_direction = true;
+    for (int i = 0; i < nl; i++) if (!lt[i].leaf && lt[i].type == 2) tree_has_direction = true;
     h_Q.assign(q, q + SPCBPT_NUM_SUBSPACE);
     h_gamma.assign(g, g + (size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE);
     if (!d_Q) HIP_TRY(this, dev_alloc(&d_Q, SPCBPT_NUM_SUBSPACE));
@@ -327,7 +330,7 @@ int Context::launch_light(uint32_t frame) {
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
     if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
     time_begin("light_trace", ls);
-    launch_light_trace(kp, counting, light_blocks, ls);
+    launch_light_trace(kp, counting || tree_has_direction, light_blocks, ls);   // direction trees: the generic instantiation (no label caching)
     time_end();
     HIP_TRY(this, hipGetLastError());
     // compaction: exclusive scan of per-core counts (+1 sentinel gives the total) -> offsets
@@ -514,10 +517,11 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         kp.n_tiles = (uint32_t)render_tile_count(kp);
         kp.work_counter = d_work_counter + rk;
         HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
-        if (!blocks_per_cu[counting]) {
-            blocks_per_cu[counting] = spcbpt_blocks_per_cu(counting);
+        const bool generic = counting || tree_has_direction;
+        if (!blocks_per_cu[generic]) {
+            blocks_per_cu[generic] = spcbpt_blocks_per_cu(generic);
             // developer knob (occupancy experiments): fewer resident blocks per CU than the kernel's resources allow
-            if (const char* e = getenv("SPCBPT_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < blocks_per_cu[counting]) blocks_per_cu[counting] = v; }
+            if (const char* e = getenv("SPCBPT_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < blocks_per_cu[generic]) blocks_per_cu[generic] = v; }
             if (const char* e = getenv("SPCBPT_TILES_PER_WAVE")) tiles_per_wave = std::max(1, atoi(e));
             if (const char* e = getenv("SPCBPT_GRID_PERCENT")) grid_percent = std::max(1, std::min(100, atoi(e)));   // else adaptive
         }
@@ -533,11 +537,12 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         // 8.15 / 8.19 / 8.43 ms at those shares, so 94 % it is.  A policy that looks whether the previous eye kernel is still running does
         // not work: by the time the host has the vertex count it waited for, that kernel has drained.
         // SPCBPT_GRID_PERCENT fixes the share; SPCBPT_TILES_PER_WAVE bounds the waves by the tile count (experiments).
-        int max_blocks = num_cus * blocks_per_cu[counting];
+        const bool generic = counting || tree_has_direction;
+        int max_blocks = num_cus * blocks_per_cu[generic];
         if (tiles_per_wave > 1) max_blocks = std::max(1, std::min(max_blocks, (int)(kp.n_tiles / (uint32_t)(4 * tiles_per_wave))));
         const int percent = grid_percent > 0 ? grid_percent : (n_render > 1 ? 94 : 100);
         if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
-        launch_spcbpt(kp, counting, max_blocks, rstream);
+        launch_spcbpt(kp, generic, max_blocks, rstream);
     }
     else launch_pt(kp, counting, rstream);
     time_end();
@@ -558,6 +563,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     // (SPCBPT_EYE_BATCH at spcbpt_create only sizes the ring of buffer sets so that batches, light passes ahead and builds do not
     // wait for each other; correctness rests on the per-set events and on `built_sets` naming intact samplers)
     if (!eye_megakernel || counting) { error = "launch_eye_batch: megakernel eye pass without counters only"; return SPCBPT_ERR_STATE; }
+    if (tree_has_direction) { error = "launch_eye_batch: the batched kernel caches vertex labels, which needs classifier trees without direction nodes (use spcbpt_launch per frame)"; return SPCBPT_ERR_STATE; }
     if (kp.width >= 65536u || kp.height >= 65536u) { error = "launch_eye_batch: image too large"; return SPCBPT_ERR_INVALID_ARG; }
     if (rs < 1) rs = 1;
     if (r0 < 0 || (r0 % 8) != 0) { error = "row_begin must be a non-negative multiple of 8 (8-row bands)"; return SPCBPT_ERR_INVALID_ARG; }

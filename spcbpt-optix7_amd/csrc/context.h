@@ -118,6 +118,9 @@ struct Context {
     std::vector<spcbpt_tree_node> h_eye_tree, h_light_tree;
     std::vector<float> h_Q, h_gamma;
     bool have_subspace = false;
+    bool tree_has_direction = false;   // a caller-supplied classifier with direction nodes (type 2): labels depend on the viewing
+                                       // direction, so the label-caching kernels do not apply (device_lib.h) and the generic
+                                       // (counting) instantiations run instead
     // light pass + LVC + sampler
     spcbpt_light_trace_params lt = {100000, 52, 1, 0, 100000, 1};
     LightVertex* d_scratch = nullptr;

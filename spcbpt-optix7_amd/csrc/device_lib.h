@@ -613,6 +613,18 @@ SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA
     }
 }
 
+// Label caching.  The reference classifies with labelUnit(position, normal, direction) and re-derives two labels for every
+// connection and one for every RMIS update (rmis.h:58-79, 131-151): the light-tree label of the EYE-side vertex and the eye-tree
+// label of the LIGHT-side vertex, each seen from the other.  With DIR_JUDGE 0 (optixPathTracer.h:39) the classifiers never split
+// on the direction -- classTree_host.h builds position / normal nodes only -- so a vertex's label under either tree is a property
+// of the vertex alone.  The timed kernels therefore classify every vertex ONCE under both trees when it is created (the same
+// lock-step pair of descents the vertex step already pays) and carry the labels along: EyeVertex::lsub, and the light vertex's
+// eye-tree label + 1 in spcbpt_light_vertex::pad (0 = not computed: an imported cache; the connection then descends as before).
+// 13 of the 17 descents per eye path disappear, and with them the longest dependent fetch chain of the connect phase; every label
+// is the label the reference computes.  CACHE = false (the counting instantiations, the per-function harness, the wavefront
+// form) evaluates in the reference's order and charges its events; a caller-supplied tree WITH direction nodes (type 2) runs on
+// those instantiations (Context::tree_has_direction).
+
 // Gamma(e,l)/Q[l] (optixPathTracer.h:173-189); the product always runs with a full tuple installed
 template <bool COUNT>
 SPC_DEV float gamma_ss(const KParams& p, int e, int l, Counts<COUNT>& cn) {
@@ -729,6 +741,7 @@ struct EyeVertex {
     f3 flux, R3;       // flux, RMIS_pointer_3
     float pdf, singlePdf;
     int sub, lastZone, depth;
+    int lsub;          // label caching (see label_cache below): the vertex's own light-tree label
 };
 
 // tracing_weight_eye (rmis.h:131-151) with Last = `last`, Mid at `mid_pos`
@@ -774,7 +787,7 @@ SPC_DEV bool null_connection(f3 apos, f3 an, f3 bpos, f3 bn) {
 
 // connectVertex_SPCBPT (raygen.cu:253-303) with rmis::general_connection / connection_lightSource
 // (rmis.h:212-247 / 281-313) fused: every BSDF lobe is fetched once.
-template <bool COUNT>
+template <bool COUNT, bool CACHE = false>
 SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn, float* w_out = nullptr) {
     const DeviceScene& S = p.scene;
     const f3 bpos = ld3(b.position), bn = ld3(b.normal), bflux = ld3(b.flux);
@@ -793,8 +806,14 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
     // the two relabels of the connection (light-tree label of the eye vertex seen from b, eye-tree label of the light vertex
     // seen from a) in one lock-step descent; the first is skipped at depth 1, the second for an emitter vertex, as in rmis.h
     int light_label, eye_label;
-    tree_label2(p.light_tree, a.c.pos, a.c.n, normalize(bpos - a.c.pos), a.depth != 1,
-                p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), b.depth != 0, light_label, eye_label, cn);
+    if (CACHE) {
+        light_label = a.lsub;                    // unused at depth 1, like the descent it replaces
+        eye_label = (int)b.pad - 1;              // unused for an emitter vertex
+        if (b.pad == 0u && b.depth != 0) eye_label = tree_label(p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), cn);   // imported cache without labels
+    } else {
+        tree_label2(p.light_tree, a.c.pos, a.c.n, normalize(bpos - a.c.pos), a.depth != 1,
+                    p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), b.depth != 0, light_label, eye_label, cn);
+    }
     const float wA = rmis_weight_eye_l(p, a.depth, a.lastZone, light_label, cn);    // tracing_weight_eye(light, eye)
     const f3 D_A_0 = a.R3 * LL_pdf_A * fm0 + mk3(wA);
     const float weight = sum3(gamma_ss(p, a.sub, b.subspace_id, cn) * lflux * (float)SPCBPT_CONNECTION_N);

@@ -15,7 +15,7 @@ struct WalkState {
     bool done;
 };
 
-template <bool COUNT>
+template <bool COUNT, bool CACHE = false>
 SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
                              WalkState& w, EyeVertex& mid, Counts<COUNT>& cn, bool stop_dead_paths = false) {
     const DeviceScene& S = p.scene;
@@ -38,8 +38,14 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
     mid.c.mat = g.mat;
     // eye-tree label of the new vertex and light-tree relabel of the previous one (tracing_weight_eye, depth >= 3) together
     int light_label;
-    tree_label2(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, last.c.pos, last.c.n, normalize(g.P - last.c.pos),
-                last.depth + 1 != 1 && last.depth != 1, mid.sub, light_label, cn);
+    mid.lsub = 0;
+    if (CACHE) {   // both labels of the NEW vertex (device_lib.h: label caching); the previous vertex brings its own
+        tree_label2(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, g.P, N, inv_dir, last.depth + 1 != 1, mid.sub, mid.lsub, cn);
+        light_label = last.lsub;
+    } else {
+        tree_label2(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, last.c.pos, last.c.n, normalize(g.P - last.c.pos),
+                    last.depth + 1 != 1 && last.depth != 1, mid.sub, light_label, cn);
+    }
     mid.lastZone = last.sub;
     mid.depth = last.depth + 1;
     mid.singlePdf = w.next_single_pdf * pdf_G / fabsf(dot(last.c.n, ray_dir));
@@ -73,7 +79,7 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
 
 // __closesthit__eyeSubpath_LightSource + rmis::light_hit + lightStraghtHit (hit_program.cu:62-147, rmis.h:359-389,
 // raygen.cu:305-317): contribution of an eye path that runs into an emitter.
-template <bool COUNT>
+template <bool COUNT, bool CACHE = false>
 SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
                            const WalkState& w, Counts<COUNT>& cn) {
     const DeviceScene& S = p.scene;
@@ -96,7 +102,7 @@ SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_
         const f3 LB = normalize(last.c.lastPos - last.c.pos);
         const float LL_pdf_A = rmis_last_pdf(mat_e, last.c, -connect_dir);
         const f3 fm0 = rmis_flux_multiplier(mat_e, last.c, -connect_dir, LB);
-        const float wA = rmis_weight_eye(p, last.c, last.depth, last.lastZone, lpos, cn);
+        const float wA = CACHE ? rmis_weight_eye_l(p, last.depth, last.lastZone, last.lsub, cn) : rmis_weight_eye(p, last.c, last.depth, last.lastZone, lpos, cn);
         const f3 D_A_0 = last.R3 * LL_pdf_A * fm0 + mk3(wA);
         const float pdf_A = rmis_pdf_from_light(lpos, ln, last.c.pos, last.c.n);
         const float D_A = sum3(D_A_0 * pdf_A * kPi * lflux / last.singlePdf);

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
     int depth = 0;
     w.done = false; w.seed = 0; w.origin = w.dir = w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
     cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0;
-    cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0;
+    cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0; cur.lsub = 0;
+    constexpr bool CACHE = !COUNT;   // device_lib.h: label caching (the counting build evaluates in the reference's order)
 
     // software pipeline: the vertex built in iteration i is connected in iteration i + 1, in the same traversal pass that
     // extends the path by its next segment (the next direction is drawn before the connections, hit_program.cu:324-337)
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     col[12 * BLOCK] = __float_as_uint(cur.pdf); col[13 * BLOCK] = __float_as_uint(cur.singlePdf);
                     // the frame of the VERTEX: a lane that parked its pixel has already taken a tile of possibly another frame
                     col[14 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | ((pend_valid ? pend_fid : fid) << 28);
-                    col[15 * BLOCK] = (uint32_t)cur.c.mat;
+                    col[15 * BLOCK] = (uint32_t)cur.c.mat | ((uint32_t)cur.lsub << 16);   // material ids are < 32768 (spcbpt_create)
                     // (RMIS_pointer_3 does not fit the 16 stack entries four resident blocks leave: it travels by ds_bpermute below)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -222,13 +223,13 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     const uint32_t ids = col[14 * BLOCK];
                     a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)((ids >> 20) & 255u);
                     const LightVertex* job_lvc = BATCH ? p.frames[ids >> 28].lvc : p.lvc;
-                    a.c.mat = (int)col[15 * BLOCK];
+                    a.c.mat = (int)(col[15 * BLOCK] & 0xffffu); a.lsub = (int)(col[15 * BLOCK] >> 16);
                     LightVertex b;
                     const float4* src = reinterpret_cast<const float4*>(job_lvc + w_slot[slot]);
                     float4* dst = reinterpret_cast<float4*>(&b);
 #pragma unroll
                     for (int q = 0; q < 6; q++) dst[q] = src[q];
-                    f3 res = connect_vertices(p, a, b, cn);
+                    f3 res = connect_vertices<COUNT, CACHE>(p, a, b, cn);
                     if (is_invalid(res)) res = mk3(0.0f);
                     res = res / w_pmf[slot];
                     const bool ok = !is_invalid(res);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         if (fresh) {  // init_EyeSubpath (raygen.cu:216-231)
             fresh = false;
             cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
-            cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0;
+            cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0; cur.lsub = 0;
         }
         has_vertex = false;
         bool finished = alive && !has_ray;  // the path ended at that vertex (Russian roulette / depth): nothing was traced
@@ -274,11 +275,11 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                 const f3 ray_dir = w.dir;
                 depth += 1;
                 if (g.emitter) {
-                    result += eye_emitter_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
+                    result += eye_emitter_hit<COUNT, CACHE>(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
                     finished = true;
                 } else {
                     EyeVertex mid;
-                    eye_surface_hit(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn, true);
+                    eye_surface_hit<COUNT, CACHE>(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn, true);
                     cur = mid;
                     has_vertex = true;
                     long long t_s0 = COUNT ? clock64() : 0;
@@ -592,15 +593,23 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     // light-tree label of the new vertex and eye-tree relabel of the previous one (tracing_weight_light) in lock-step
                     int new_label, eye_label;
                     const f3 last_pos = ld3(last.position);
-                    tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
-                                new_label, eye_label, cn);
+                    uint32_t own_eye_label = 0u;   // device_lib.h: label caching -- the new vertex's own eye-tree label + 1
+                    if (!COUNT) {
+                        int own;
+                        tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, g.P, N, inv_dir, true, new_label, own, cn);
+                        own_eye_label = (uint32_t)own + 1u;
+                        eye_label = (int)last.pad - 1;   // the previous vertex's, cached when it was created (unused when it is the origin)
+                    } else {
+                        tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
+                                    new_label, eye_label, cn);
+                    }
                     m.subspace_id = (int16_t)new_label;
                     m.last_zone_id = last.subspace_id;
                     m.depth = (int16_t)(last.depth + 1);
                     m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
                     m.pdf = last.pdf * m.single_pdf;
                     m.last_lum = sum3(last_flux / last.pdf);
-                    m.path_id = path_id; m.pad = 0;
+                    m.path_id = path_id; m.pad = own_eye_label;
                     if (last.depth == 0) {
                         m.rmis_pointer = last.rmis_pointer / last.single_pdf;  // tracing_init_light
                     } else {  // tracing_update_light (rmis.h:80-94)

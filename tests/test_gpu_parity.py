@@ -412,3 +412,61 @@ def test_batched_eye_launch_sizes_its_spill_area_for_the_grid_it_launches(gpu, p
     # scene (57 % of pixels within 2e-3 at equal seeds); 77 k samples give the mean to a few percent
     s = image_parity(want[..., :3], o.read_accum()[..., :3])
     assert s["mean_rel"] < 0.06, s
+
+
+# ---- label caching (csrc/device_lib.h) ---------------------------------------------------------------------------------------
+def test_cached_vertex_labels_are_the_labels_the_reference_derives(gpu, pkg, ob):
+    """The timed kernels classify a vertex once under both trees and carry the labels (EyeVertex::lsub, light vertex `pad` = eye-tree
+    label + 1); the counting kernels re-derive them per connection / RMIS update as rmis.h does.  Same labels -> same image (the two
+    instantiations may contract FMAs differently: >= 99.9 % of pixels within 2e-3, not bit equality); the labels stored in the
+    cache are checked against the oracle's tree_index one by one; a classifier WITH direction nodes makes labels direction-dependent
+    and must take the generic kernels (image parity with the oracle; the batched launch, which only exists cached, refuses)."""
+    from tests.parity_util import grid_tree_tuple
+    scene = pkg.scenes.bedroom(target_tris=40000, tex_size=64)
+    r, o = _pair(pkg, ob, scene, 96, 64, lt=(4000, 64, 1))
+    tup = grid_tree_tuple(pkg, o, scene)
+    r.set_subspace(*tup); o.set_subspace(*tup); o.set_cmf_double(True)
+    for f in range(3):
+        r.render_frame("SPCBPT_eye", f)
+    cached = r.read_accum()[..., :3].copy()
+    lvc = r.lvc_read()
+    surf = lvc["depth"] > 0
+    assert (lvc["pad"][surf] > 0).all() and (lvc["pad"][~surf] == 0).all()
+    d = np.zeros((surf.sum(), 3), np.float32)                       # direction is irrelevant: no direction nodes in these trees
+    want = ob.tree_index(tup[0], np.concatenate([lvc["position"][surf], lvc["normal"][surf], d], 1))
+    assert np.array_equal(lvc["pad"][surf].astype(np.int64) - 1, want)
+    r.clear_accum(); r.enable_counters(True)
+    for f in range(3):
+        r.render_frame("SPCBPT_eye", f)
+    generic = r.read_accum()[..., :3].copy()
+    r.enable_counters(False)
+    assert (r.lvc_read()["pad"] == 0).all()                          # the reference-order light pass does not fill the cache field
+    s = image_parity(cached, generic)
+    assert s["frac_close"] >= 0.999 and s["mean_rel"] < 1e-4, s
+    # mixed: a cache traced WITHOUT labels (pad = 0) rendered by the caching eye kernel -> it descends per connection
+    r.clear_accum()
+    for f in range(3):
+        r.enable_counters(True); r.launch("light trace", f + 1); r.enable_counters(False)
+        r.build_sampler(); r.launch("SPCBPT_eye", f)
+    s = image_parity(r.read_accum()[..., :3], cached)
+    assert s["frac_close"] >= 0.999, s
+    # a classifier with a direction node on top: labels depend on the viewing direction
+    et, lt, q, g = tup
+    def with_direction_root(t):
+        n = len(t)
+        t2 = np.zeros(n + 1, dtype=t.dtype)
+        t2[1:] = t
+        t2["child"][1:] = np.where(t["leaf"][:, None] == 1, t["child"], t["child"] + 1)
+        t2[0]["type"] = 2; t2[0]["mid"] = (0.0, 0.0, 0.0); t2[0]["leaf"] = 0
+        t2[0]["child"] = [1, 1, 1, 1, n, n, n, n]                   # +z-facing directions -> a different leaf (the last node)
+        return t2
+    assert et[-1]["leaf"] == 1
+    et2, lt2 = with_direction_root(et), with_direction_root(lt)
+    r.set_subspace(et2, lt2, q, g); o.set_subspace(et2, lt2, q, g)
+    r.clear_accum(); o.clear_accum()
+    for f in range(2):
+        r.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
+    s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
+    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s
+    with pytest.raises(pkg.SpcbptError, match="direction"):
+        r.launch_eye_batch([0])

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]); streams = int(args[1]); steps = int(args[2]) if len(args) > 2 else 32
-exchange, trained = "--exchange" in sys.argv, "--trained" in sys.argv
+exchange, trained, native = "--exchange" in sys.argv, "--trained" in sys.argv, "--native" in sys.argv   # --native: the C++ RCCL host (libspcbpt_mgpu) at world size 1
 depth = max([int(a[len("--ahead="):]) for a in sys.argv if a.startswith("--ahead=")] + [1 if "--ahead" in sys.argv else 0])   # light passes ahead
 ahead = depth > 0
 batch = max([int(a[len("--batch="):]) for a in sys.argv if a.startswith("--batch=")] + [1])   # frames per eye launch
@@ -34,6 +34,11 @@ if exchange:
     dev = torch.device("cuda", 0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=True))
     ex = p.dist.FrameExchanger(r, 0, 1, dev)
+throttle = "--throttle" in sys.argv   # host waits for the light pass it is about to exchange (what the python exchange does implicitly)
+comm = None
+if native:
+    comm = p.dist.Comm(r, 0, 1, p.dist.unique_id())
+    print("shard capacity after calibration:", comm.calibrate(passes=2, slack=1.5))
 rows = (0, H, N)
 if ahead:
     r.set_light_ahead(True)
@@ -47,8 +52,10 @@ def eye(f):
 def step(f):
     r.launch("light trace", f + 1 + depth)
     if ex is not None: ex.allgather_lvc()
+    if throttle: r.sync_light()
+    if comm is not None: comm.exchange_lvc()
     r.build_sampler(); eye(f)
-for f in range(4): step(f)
+for f in range(4 * max(1, batch // 4)): step(f)
 r.sync()
 t0 = time.perf_counter()
 host = {"light": 0.0, "exchange": 0.0, "build": 0.0, "eye": 0.0}
@@ -56,6 +63,8 @@ def timed_step(f):
     a = time.perf_counter(); r.launch("light trace", f + 1 + depth)
     b = time.perf_counter()
     if ex is not None: ex.allgather_lvc()
+    if throttle: r.sync_light()
+    if comm is not None: comm.exchange_lvc()
     c2 = time.perf_counter(); r.build_sampler()
     d = time.perf_counter(); eye(f)
     e = time.perf_counter()
@@ -65,7 +74,7 @@ t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
 print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

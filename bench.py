@@ -93,16 +93,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
     ap.add_argument("--render-streams", type=int, default=0,
-                    help="render streams per GPU, each with one (batched) eye launch in flight (0 = 2)")
+                    help="render streams per GPU, each with one (batched) eye launch in flight (0 = 2 for 1-2 GPUs, 1 beyond)")
     ap.add_argument("--light-geometry", default="lane", choices=["lane", "reference"],
                     help="lane (default): one light path per core, M cores of 52 slots, BSDF stream decorrelated (DESIGN.md d1); "
                          "reference: the reference's launch geometry lt_params_setup (optixPathTracer.cpp:462-477): 1000 cores x 100 paths, "
                          "800 slots per core, both random streams of a core start equal (q4)")
     ap.add_argument("--write-image", default="")
     ap.add_argument("--eye-batch", type=int, default=0,
-                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 4: several frames in one tile queue pay the drain phase of the "
-                         "persistent kernel once (and a rank's share of a sharded frame is about one tile per resident wave: all drain); "
-                         "1 = one launch per frame")
+                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 4 for 1-2 GPUs, 8 beyond: several frames in one tile queue pay the "
+                         "drain phase of the persistent kernel once (and a rank's share of a sharded frame is about one tile per resident wave: "
+                         "all drain); 1 = one launch per frame")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
@@ -141,8 +141,12 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
 
-    batch = args.eye_batch if args.eye_batch > 0 else 4
-    streams = args.render_streams if args.render_streams > 0 else 2
+    # Frames per eye launch and render streams by rank count, measured with tools/rank_sim.py (a rank's share on one GPU, trained
+    # tuple, ms per rank-frame; 1 stream x 8 frames | 1 x 4 | 2 x 4 | 2 x 8): N = 8: 1.06 | 1.17 | 1.42 | 1.41, N = 4: 1.86 | 2.00 |
+    # 2.05 | 2.00, N = 2: 3.60 | 3.76 | 3.42 | 3.47, N = 1 (16-step runs): 2 x 4.  A rank's share of a frame is mostly drain phase, so
+    # small shares want ONE long tile queue; two persistent kernels side by side only pay when each fills the GPU by itself.
+    batch = args.eye_batch if args.eye_batch > 0 else (4 if world <= 2 else 8)
+    streams = args.render_streams if args.render_streams > 0 else (2 if world <= 2 else 1)
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets
     scene = make_scene(pkg, args.scene, args.tris)
@@ -216,6 +220,10 @@ def main():
         if ex is not None:
             ex.allgather_lvc()
         elif comm is not None:
+            # back-pressure, not a data dependency: without it the host queues dozens of frames of light passes and builds ahead of
+            # the eye kernels and a rank-frame takes 1.7 instead of 1.4 ms (N = 8 share, rank_sim); the pass waited for was launched
+            # `depth` steps ago, so the wait is normally over before it starts
+            r.sync_light()
             comm.exchange_lvc()                # queues the all-gather + compaction on the communicator's stream; no host wait
         r.build_sampler()
         if isolate and (batch == 1 or len(queued) == batch - 1):

@@ -142,12 +142,17 @@ struct TravStack {
 
 struct HitRec { float t; int tri; float u, v; };
 
+// Reciprocal direction of the slab tests.  v_rcp_f32 (1 ulp) instead of the IEEE division sequence (10 instructions per
+// component): the reciprocal only decides which quantised child boxes are entered, and those are rounded outwards by up to 1/255
+// of the node and tested with a relative slack (slab4q), so the last bit cannot lose a hit -- triangle tests use o and d.  The
+// ray set-up runs once per ray with a handful of lanes active (lanes pull rays from the pool as they finish), i.e. its
+// instructions are paid by the whole wave at ~5 % utilisation: 55 -> 25 instructions there was worth 3 % of the kernel.
 SPC_DEV f3 safe_inv(f3 d) {
     const float tiny = 1e-20f;
     f3 r;
-    r.x = 1.0f / (fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
-    r.y = 1.0f / (fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
-    r.z = 1.0f / (fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
+    r.x = __builtin_amdgcn_rcpf(fabsf(d.x) > tiny ? d.x : copysignf(tiny, d.x));
+    r.y = __builtin_amdgcn_rcpf(fabsf(d.y) > tiny ? d.y : copysignf(tiny, d.y));
+    r.z = __builtin_amdgcn_rcpf(fabsf(d.z) > tiny ? d.z : copysignf(tiny, d.z));
     return r;
 }
 SPC_DEV bool slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float tmax, float& tnear) {
@@ -331,9 +336,26 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
 //   s_next      pool cursor, must be 0 on entry
 // Wave-scope fences around the call order the LDS traffic; all 64 lanes must call this together.
 static constexpr int POOL_RAYS = 64 * SPCBPT_CONNECTION_N;
+// Compacts the slots of the wave's ray pool that hold a ray (length >= 0) into s_list, in slot order; returns their number
+// (wave-uniform).  All 64 lanes call it after the rays of the iteration have been written (wave-scope fence before and after).
+SPC_DEV uint32_t pool_ray_list(const float4* s_ray, uint8_t* s_list) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t n = 0u;
+#pragma unroll
+    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+        const bool has = s_ray[it * 64 + lane].w >= 0.0f;
+        const unsigned long long m = __ballot(has);
+        if (has) s_list[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(it * 64 + lane);
+        n += (uint32_t)__popcll(m);
+    }
+    return n;
+}
+//   s_list[n_rays]  the slots that hold a ray, compacted by the caller (pool_ray_list): a lane never draws an empty slot -- each
+//                   empty draw cost the whole wave an LDS atomic round trip with one lane active, and half the 192 slots are empty
 template <bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, bool own, f3 own_o, f3 own_d, HitRec& own_hit,
-                        const float4* s_org, const float4* s_ray, uint8_t* s_vis, uint32_t* s_next, Counts<COUNT>& cn) {
+                        const float4* s_org, const float4* s_ray, uint8_t* s_vis, uint32_t* s_next, const uint8_t* s_list, uint32_t n_rays,
+                        Counts<COUNT>& cn) {
     uint32_t r = 0;
     bool closest = own, done = false;
     f3 o = own_o, d = own_d;
@@ -345,17 +367,19 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
     if (own) cn.add(C_CLOSEST);
     own_hit.t = 1e16f; own_hit.tri = -1; own_hit.u = own_hit.v = 0.0f;
     while (true) {
-        while (node == kTravDone && !done) {  // acquire the next shadow ray of the pool
-            r = atomicAdd(s_next, 1u);
-            if (r >= (uint32_t)POOL_RAYS) { done = true; break; }
+        if (node == kTravDone && !done) {  // acquire the next shadow ray of the pool
+            const uint32_t k = atomicAdd(s_next, 1u);
+            if (k >= n_rays) { done = true; }
+            else {
+            r = s_list[k];
             const float4 rq = s_ray[r];
-            if (rq.w < 0.0f) continue;
             const float4 oq = s_org[r & 63u];
             o = mk3(oq.x, oq.y, oq.z); d = mk3(rq.x, rq.y, rq.z);
             inv = safe_inv(d); ood = o * inv;
             best_t = rq.w - kEps;
             node = 0; st.sp = 0;
             cn.add(C_SHADOW);
+            }
         }
         if (!__any(node != kTravDone)) break;
         if (node != kTravDone) {

@@ -166,8 +166,12 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         if (lane == 0) *w_next = 0u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the slots that hold a shadow ray, compacted (w_job is free here: the connect phase below rebuilds it after the pass)
+        const uint32_t n_rays = pool_ray_list(w_ray, w_job);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         HitRec h;
-        trace_pool(S, st, alive && has_ray, w.origin, w.dir, h, w_org, w_ray, w_vis, w_next, cn);
+        trace_pool(S, st, alive && has_ray, w.origin, w.dir, h, w_org, w_ray, w_vis, w_next, w_job, n_rays, cn);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         SPC_PHASE(C_T_POOL);

@@ -23,7 +23,7 @@ extern "C" int hipGetDeviceCount(int*);
 struct Job {
     spcbpt_scene_desc desc;
     float eye[3], lookat[3], up[3], fov;
-    int W = 640, H = 360, frames = 16, batch = 4, M = 100000;
+    int W = 640, H = 360, frames = 16, batch = 0, M = 100000;   // batch 0 = 4 for 1-2 ranks, 8 beyond
     bool train = true;
 };
 struct Rank {
@@ -45,6 +45,7 @@ static void core_range(int n, int rank, int world, int* begin, int* count) {
 static void rank_create(const Job& J, Rank& R) {
     hipSetDevice(R.device);
     setenv("SPCBPT_EYE_BATCH", std::to_string(J.batch).c_str(), 1);
+    if (R.world > 2) setenv("SPCBPT_RENDER_STREAMS", "1", 0);   // a small share of the frame wants one long tile queue (bench.py: measured)
     RK(R, spcbpt_create(&J.desc, R.device, &R.ctx));
     RK(R, spcbpt_set_camera_lookat(R.ctx, J.eye, J.lookat, J.up, J.fov, (float)J.W / (float)J.H));
     RK(R, spcbpt_resize(R.ctx, J.W, J.H));
@@ -70,7 +71,11 @@ static void rank_prime(const Job& J, Rank& R) {           // calibrated capacity
 }
 // the three phases of a frame; a threaded rank runs them back to back, the local driver runs each phase for every rank in turn
 static void frame_light(const Job&, Rank& R) { hipSetDevice(R.device); RK(R, spcbpt_launch(R.ctx, "light trace", (uint32_t)R.next_light++, 0, 0, 1)); }
-static void frame_exchange(const Job&, Rank& R) { hipSetDevice(R.device); RK(R, spcbpt_comm_exchange_lvc(R.comm)); }
+static void frame_exchange(const Job&, Rank& R) {
+    hipSetDevice(R.device);
+    RK(R, spcbpt_sync_light(R.ctx));   // back-pressure only (the pass was launched a batch ago): keeps the host from queueing dozens of frames ahead
+    RK(R, spcbpt_comm_exchange_lvc(R.comm));
+}
 static void frame_render(const Job& J, Rank& R, int f) {
     hipSetDevice(R.device);
     RK(R, spcbpt_build_sampler(R.ctx));
@@ -110,6 +115,7 @@ int main(int argc, char** argv) {
     int ndev = 0;
     hipGetDeviceCount(&ndev);
     const int world = local > 0 ? local : (gpus > 0 ? gpus : std::max(1, ndev));
+    if (J.batch == 0) J.batch = world <= 2 ? 4 : 8;
     if (!local && world > ndev) { fprintf(stderr, "%d GPUs asked for, %d present\n", world, ndev); return 1; }
     std::vector<Rank> R(world);
     for (int k = 0; k < world; k++) { R[k].id = k; R[k].world = world; R[k].device = local ? 0 : k; }

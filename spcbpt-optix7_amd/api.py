@@ -419,6 +419,8 @@ def load_library(path: str = LIB_PATH):
     global _lib
     if _lib is not None:
         return _lib
+    if os.environ.get("SPCBPT_LIB"):   # developer A/B runs: another build of the same ABI (no source-hash check)
+        path = os.environ["SPCBPT_LIB"]
     if not os.path.exists(path):
         raise SpcbptError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).

@@ -165,18 +165,24 @@ SPC_DEV bool slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float tmax, fl
     return t0 <= t1 * 1.0000004f;
 }
 // Moller-Trumbore on (P0, P1, P2); accepts tmin < t < tmax; culls the back face when asked (emitter quads).
+// The triangle step of the traversal loop runs at ~10 % lane utilisation (a lane sits on a leaf in one iteration out of ten, and
+// nearly every iteration has SOME lane on one), so every instruction here is paid by the whole wave: the cross products may
+// contract to FMAs (unlike cross(), whose exact zeros only matter for shading normals), 1 / det is v_rcp_f32 (1 ulp) instead of
+// the IEEE division sequence, and the back-face test reuses the determinant: dot(cross(e1, e2), d) = -det.
+SPC_DEV f3 cross_fma(f3 a, f3 b) {
+    return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
 SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, float tmax, bool cull, float& ot, float& ou, float& ov) {
     const f3 v0 = mk3(q0.x, q0.y, q0.z);
     const f3 e1 = mk3(q1.x, q1.y, q1.z) - v0, e2 = mk3(q2.x, q2.y, q2.z) - v0;
-    if (cull && dot(cross(e1, e2), d) > 0.0f) return false;
-    const f3 p = cross(d, e2);
+    const f3 p = cross_fma(d, e2);
     const float det = dot(e1, p);
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
+    if (det == 0.0f || (cull && det < 0.0f)) return false;
+    const float inv = __builtin_amdgcn_rcpf(det);
     const f3 tv = o - v0;
     const float u = dot(tv, p) * inv;
     if (u < 0.0f || u > 1.0f) return false;
-    const f3 q = cross(tv, e1);
+    const f3 q = cross_fma(tv, e1);
     const float v = dot(d, q) * inv;
     if (v < 0.0f || u + v > 1.0f) return false;
     const float t = dot(e2, q) * inv;

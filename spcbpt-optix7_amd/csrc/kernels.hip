@@ -61,24 +61,32 @@ SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
 template <bool COUNT, bool BATCH>
 __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    __shared__ float4 s_ray[(BLOCK / 64) * POOL_RAYS];
-    __shared__ float4 s_org[BLOCK];
-    __shared__ uint8_t s_vis[(BLOCK / 64) * POOL_RAYS];
-    __shared__ uint32_t s_next[BLOCK / 64];
-    __shared__ int32_t s_slot[(BLOCK / 64) * POOL_RAYS];   // LVC slot of connection it * 64 + lane
-    __shared__ float s_pmf[(BLOCK / 64) * POOL_RAYS];      // its resampling pmf (path_count * pmf2 * pmf1)
-    __shared__ uint8_t s_job[(BLOCK / 64) * POOL_RAYS];    // compacted list of the unoccluded connections of the wave
+    // everything else a wave keeps in LDS sits in ONE record per wave: every field is then the wave's base (one SGPR) plus a
+    // constant that folds into the ds instruction's offset.  As eight separate arrays the eight wave-uniform bases were spilled
+    // SGPRs, read back with v_readlane inside the traversal loop.
+    struct alignas(16) WavePool {
+        float4 ray[POOL_RAYS];      // shadow ray it * 64 + lane: direction.xyz, length (< 0: none)
+        float4 org[64];             // eye vertex of lane l: position.xyz (= origin of its shadow rays), lastNormalProjection
+        int32_t slot[POOL_RAYS];    // LVC slot of connection it * 64 + lane
+        float pmf[POOL_RAYS];       // its resampling pmf (path_count * pmf2 * pmf1)
+        uint8_t vis[POOL_RAYS];     // 1 = unoccluded
+        uint8_t job[POOL_RAYS];     // before the pass: slots that hold a ray; after it: the unoccluded connections, compacted
+        uint32_t next;              // pool cursor
+        uint32_t pad[3];
+    };
+    __shared__ WavePool s_pool[BLOCK / 64];
     const DeviceScene& S = p.scene;
-    // wave_in_block through readfirstlane: the per-wave LDS bases below are then wave-uniform values the compiler keeps in SGPRs
+    // wave_in_block through readfirstlane: the per-wave LDS base below is then a wave-uniform value the compiler keeps in an SGPR
     const uint32_t lane = threadIdx.x & 63, wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int32_t* w_slot = s_slot + wave_in_block * POOL_RAYS;
-    float* w_pmf = s_pmf + wave_in_block * POOL_RAYS;
-    uint8_t* w_job = s_job + wave_in_block * POOL_RAYS;
+    WavePool* wp = s_pool + wave_in_block;
+    int32_t* w_slot = wp->slot;
+    float* w_pmf = wp->pmf;
+    uint8_t* w_job = wp->job;
     uint32_t* w_stack = s_stack + wave_in_block * 64;      // [entry * BLOCK + lane]: free between two traversal passes
-    float4* w_ray = s_ray + wave_in_block * POOL_RAYS;
-    float4* w_org = s_org + wave_in_block * 64;
-    uint8_t* w_vis = s_vis + wave_in_block * POOL_RAYS;
-    uint32_t* w_next = s_next + wave_in_block;
+    float4* w_ray = wp->ray;
+    float4* w_org = wp->org;
+    uint8_t* w_vis = wp->vis;
+    uint32_t* w_next = &wp->next;
     Counts<COUNT> cn;
     cn.clear();
     TravStack<BLOCK, STACK_LDS> st;

@@ -223,5 +223,54 @@ def test_c3_full_size_bench_scene_properties_and_counters(bench_scene, pkg, ob):
         assert abs(cg[k] - co[k]) <= 0.01 * max(co[k], 1), (k, cg[k], co[k])
     # and the sampled bands themselves: same seeds, same tuple -> pixel parity on the ~65 k pixels the oracle rendered
     band = np.array([(y // 8) % stride == 0 for y in range(H)])
+    # 1 spp on a 986 k-triangle scene: a hit within rounding of a triangle edge or a Russian-roulette decision within rounding
+    # sends the two sides down different paths (measured: 97.5 % of the pixels within 2e-3, image mean within 6e-5)
     s = image_parity(r.read_accum()[band][..., :3], o.read_accum()[band][..., :3])
-    assert s["frac_close"] >= 0.98 and s["mean_rel"] < 2e-2, s
+    assert s["frac_close"] >= 0.97 and s["mean_rel"] < 2e-3, s
+
+
+def test_c3_reference_light_trace_geometry_at_full_size(bench_scene, pkg, ob):
+    """lt_params_setup (optixPathTracer.cpp:464-467): 1000 cores x 100 paths, 800 padded slots per core, the two random streams
+    of a core starting equal (q4) -- the reference's own launch geometry, on the bench scene.  The persistent light kernel must
+    cut every core where the per-core loop of raygen.cu:620-685 cuts it: same (path, depth) sequence, same per-vertex values,
+    and, on an identical cache, the same sampler tables (integers exact, CMFs within the double-vs-float accumulation gap)."""
+    scene = bench_scene
+    W, H = 256, 144
+    geom = (1000, 800, 100)
+    r = _renderer(pkg, scene, W, H, geom)
+    o = ob.Oracle(scene, nthreads=os.cpu_count() or 1)
+    _setup(o, scene, W, H, geom)
+    r.set_pretrace(20000, 10)
+    r.preprocess(target_paths=200000, target_q_paths=200000, train=True)       # a real multi-leaf tuple (labels on both sides)
+    tup = r.get_subspace()
+    r.set_subspace(*tup); o.set_subspace(*tup)
+    r.launch("light trace", 7); o.launch("light trace", 7)
+    a, b = r.lvc_read(), o.lvc_read()
+    assert abs(len(a) - len(b)) <= 0.002 * len(b) and len(b) > 200000, (len(a), len(b))
+    assert (b["depth"] == 0).sum() > 90000                                      # ~100 000 paths unless slot ranges fill up
+    n = min(len(a), len(b))
+    same = (a["path_id"][:n] == b["path_id"][:n]) & (a["depth"][:n] == b["depth"][:n])
+    first_div = n if same.all() else int(np.argmin(same))
+    assert first_div >= 0.3 * n, (first_div, n)      # one Russian-roulette flip shifts everything after it: compare the common prefix ...
+    # ... and the whole cache as a multiset of (path, depth) keys: cores are independent, so a flip only perturbs its own core
+    ka = a["path_id"].astype(np.int64) * 64 + a["depth"]; kb = b["path_id"].astype(np.int64) * 64 + b["depth"]
+    common = np.intersect1d(ka, kb).size
+    assert common >= 0.99 * len(b), (common, len(b))
+    a, b = a[:first_div], b[:first_div]
+    surf = a["depth"] > 0
+    assert (a["subspace_id"] == b["subspace_id"]).mean() > 0.999 and (a["material_id"] == b["material_id"]).all()
+    for k in ("position", "flux", "pdf", "single_pdf", "rmis_pointer"):
+        x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+        scale = np.abs(y).max(axis=-1, keepdims=True) if y.ndim > 1 else np.abs(y)
+        assert np.percentile(np.abs(x - y) / (scale + 1e-9), 99) < 1e-3, k
+    # identical cache -> identical tables
+    lvc = o.lvc_read()
+    r.lvc_import(lvc)
+    r.build_sampler(); o.build_sampler()
+    sg, so = r.sampler_read(), o.sampler_read()
+    assert sg[3:] == so[3:]
+    np.testing.assert_array_equal(sg[0]["size"], so[0]["size"])
+    np.testing.assert_array_equal(sg[0]["jump_bias"], so[0]["jump_bias"])
+    np.testing.assert_array_equal(sg[2], so[2])
+    assert np.abs(sg[1] - so[1]).max() < 3e-5
+    assert (sg[0]["size"] > 0).sum() > 300                                      # hundreds of populated light subspaces

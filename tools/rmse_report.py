@@ -74,19 +74,31 @@ tp = 400_000 if name == "cornell" else 2_000_000
 t1 = time.time(); r.preprocess(tp, tp, True); out["preprocess_seconds"] = time.time() - t1
 sp_tr = mean_image("SPCBPT_eye", 0, N)
 ms_tr = frame_ms("SPCBPT_eye")
+# "plain BDPT", the comparator BASELINE config 5 names: the same kernel with SubspaceSampler_device::uniformSample (cuProg.h:283-289)
+# in place of the two-stage subspace sampler (spcbpt_set_connection_sampler), at N spp and at the spp it affords in the same time
+r.set_connection_sampler(1)
+bd = mean_image("SPCBPT_eye", 0, N)
+ms_bd = frame_ms("SPCBPT_eye")
+n_bd = max(1, min(4 * N - 1, int(round(N * ms_tr / ms_bd))))
+bd_eq = mean_image("SPCBPT_eye", 0, n_bd)
+r.set_connection_sampler(0)
 n_eq = max(1, min(4 * N - 1, int(round(N * ms_tr / ms_pt))))   # samples "pt" affords in the time of N trained-SPCBPT samples
 pt_eq = mean_image("pt", 0, n_eq)
 sp_ref = mean_image("SPCBPT_eye", 32 * N, 16 * N)
 ref = 0.5 * (pt_ref + sp_ref)
 rm = lambda a: float(np.sqrt(((a - ref) ** 2).mean()))
 rel = lambda a: float((((a - ref) ** 2) / (ref ** 2 + 1e-2)).mean())
-out.update(rmse_pt=rm(pt), rmse_spcbpt_minimal=rm(sp_min), rmse_spcbpt_trained=rm(sp_tr),
-           relmse_pt=rel(pt), relmse_spcbpt_minimal=rel(sp_min), relmse_spcbpt_trained=rel(sp_tr),
+out.update(rmse_pt=rm(pt), rmse_spcbpt_minimal=rm(sp_min), rmse_spcbpt_trained=rm(sp_tr), rmse_plain_bdpt=rm(bd),
+           relmse_pt=rel(pt), relmse_spcbpt_minimal=rel(sp_min), relmse_spcbpt_trained=rel(sp_tr), relmse_plain_bdpt=rel(bd),
            mean_pt_ref=float(pt_ref.mean()), mean_spcbpt_ref=float(sp_ref.mean()),
            ref_disagreement_rmse=float(np.sqrt(((pt_ref - sp_ref) ** 2).mean())), seconds=time.time() - t0)
 out["variance_ratio_pt_over_trained"] = (out["rmse_pt"] / out["rmse_spcbpt_trained"]) ** 2
-out["ms_per_frame"] = {"pt": ms_pt, "spcbpt_minimal": ms_min, "spcbpt_trained": ms_tr}
-out["equal_time"] = {"budget_ms": N * ms_tr, "spp": {"pt": n_eq, "spcbpt_trained": N},
+out["variance_ratio_plain_bdpt_over_trained"] = (out["rmse_plain_bdpt"] / out["rmse_spcbpt_trained"]) ** 2
+out["ms_per_frame"] = {"pt": ms_pt, "spcbpt_minimal": ms_min, "spcbpt_trained": ms_tr, "plain_bdpt_uniformSample": ms_bd}
+out["equal_time"] = {"budget_ms": N * ms_tr, "spp": {"pt": n_eq, "spcbpt_trained": N, "plain_bdpt": n_bd},
+                     "rmse_plain_bdpt_measured": rm(bd_eq), "relmse_plain_bdpt_measured": rel(bd_eq),
+                     "variance_ratio_plain_bdpt_over_trained": (rm(bd_eq) / rm(sp_tr)) ** 2,
+                     "relmse_ratio_plain_bdpt_over_trained": rel(bd_eq) / rel(sp_tr),
                      "rmse_pt_measured": rm(pt_eq), "relmse_pt_measured": rel(pt_eq),
                      "rmse_pt_derived": out["rmse_pt"] * (ms_pt / ms_tr) ** 0.5,
                      "rmse_spcbpt_minimal_derived": out["rmse_spcbpt_minimal"] * (ms_min / ms_tr) ** 0.5,

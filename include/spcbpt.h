@@ -224,6 +224,12 @@ int spcbpt_set_subspace(spcbpt_ctx* ctx,
 /* Replaces lt_params_setup (optixPathTracer.cpp:462-477). */
 int spcbpt_set_light_trace(spcbpt_ctx* ctx, const spcbpt_light_trace_params* p);
 
+/* A fifth launch name, "SPCBPT_no_rmis": the raygen program __raygen__SPCBPT_no_rmis (raygen.cu:445-606) exists in the
+ * reference but is bound to no program group, so switchRaygen cannot select it there.  Same call sequence as "SPCBPT_eye"
+ * ("light trace" -> spcbpt_build_sampler -> launch); the connections are weighted with classic full-path MIS
+ * (contriCompute / pdfCompute / MISWeight_SPCBPT, cuProg.h:901-1105) instead of the recursive weights of rmis.h, and paths
+ * longer than MAX_PATH_LENGTH_FOR_MIS = 20 vertices are dropped, as written.  A validation mode (one lane per pixel-sample, the
+ * path in scratch memory, O(n^2) per connection): an independent estimator of the image "SPCBPT_eye" renders. */
 /* Replaces switchRaygen(name) + optixLaunch (see file header).  name is one of
  * "pt", "light trace", "SPCBPT_eye", "pretrace".  For "pt" and "SPCBPT_eye"
  * frame is params.subframe_index; the image is cut into bands of 8 rows and

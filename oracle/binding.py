@@ -181,7 +181,7 @@ class Oracle:
         self.l.orc_build_sampler(self.h)
 
     def render_frame(self, alg, subframe, launch_frame=None, rows=None):
-        if alg == "SPCBPT_eye":
+        if alg in ("SPCBPT_eye", "SPCBPT_no_rmis"):
             self.launch("light trace", subframe + 1 if launch_frame is None else launch_frame)
             self.build_sampler()
         self.launch(alg, subframe, rows)

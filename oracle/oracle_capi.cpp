@@ -124,8 +124,8 @@ int orc_launch(orc_ctx* c, const char* name, unsigned frame, int row_begin, int 
         if (c->lvc.empty()) orc_set_light_trace(c, c->P.lt.num_core, c->P.lt.core_padding, c->P.lt.M_per_core);
         make_views();
         parallel_for(c->P.lt.num_core, nthreads, [&](int i, int t) { raygen_lightTrace(tp[t], i); });
-    } else if (alg == "pt" || alg == "SPCBPT_eye") {
-        if (alg == "SPCBPT_eye" && !c->P.sampler.subspace) return SPCBPT_ERR_STATE;
+    } else if (alg == "pt" || alg == "SPCBPT_eye" || alg == "SPCBPT_no_rmis") {
+        if (alg != "pt" && !c->P.sampler.subspace) return SPCBPT_ERR_STATE;
         if (!c->P.accum_buffer) return SPCBPT_ERR_STATE;
         c->P.subframe_index = frame;
         if (row_step < 1) row_step = 1;
@@ -133,12 +133,13 @@ int orc_launch(orc_ctx* c, const char* name, unsigned frame, int row_begin, int 
         // 8-row bands, band k of every row_step (same rule as spcbpt_launch)
         for (int y = row_begin; y < row_end && y < (int)c->P.height; y++)
             if (((y / 8) - (row_begin / 8)) % row_step == 0) rows.push_back(y);
-        bool spc = alg == "SPCBPT_eye";
+        bool spc = alg == "SPCBPT_eye", full_mis = alg == "SPCBPT_no_rmis";
         make_views();
         parallel_for((int)rows.size(), nthreads, [&](int i, int t) {
             unsigned y = (unsigned)rows[i];
             for (unsigned x = 0; x < c->P.width; x++) {
                 if (spc) raygen_SPCBPT(tp[t], x, y);
+                else if (full_mis) raygen_SPCBPT_no_rmis(tp[t], x, y);
                 else raygen_pinhole(tp[t], x, y);
             }
         });

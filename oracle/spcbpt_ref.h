@@ -845,6 +845,200 @@ inline float3 spcbpt_sample(const Params& P, unsigned x, unsigned y) {
 }
 inline void raygen_SPCBPT(const Params& P, unsigned x, unsigned y) { accumulate(P, x, y, spcbpt_sample(P, x, y)); }
 
+// ---- __raygen__SPCBPT_no_rmis (raygen.cu:445-606): the same sampler with classic full-path MIS weights instead of the recursive
+// ones.  Defined in the reference but bound to no program group (Scene::switchRaygen knows four names); restated because it is
+// an INDEPENDENT estimator of the same image: its weights come from contriCompute / pdfCompute / MISWeight_SPCBPT over the whole
+// path (cuProg.h:901-1105), none of rmis.h.  MAX_PATH_LENGTH_FOR_MIS = 20 bounds the path (longer paths are dropped: a small,
+// deliberate bias of the variant).
+static constexpr int MAX_PATH_LENGTH_FOR_MIS = 20;
+inline float3 contriCompute(const Params& P, const BDPTVertex* path, int path_size) {  // cuProg.h:901-934
+    const Scene& S = *P.scene;
+    float3 throughput = make_float3(1);
+    const BDPTVertex& light = path[path_size - 1];
+    const BDPTVertex& lastMidPoint = path[path_size - 2];
+    float3 lightLine = lastMidPoint.position - light.position;
+    float3 lightDirection = normalize(lightLine);
+    float lAng = dot(light.normal, lightDirection);
+    if (lAng < 0.0f) return make_float3(0.0f);
+    float3 Le = light.flux * lAng;
+    throughput = throughput * Le;
+    for (int i = 1; i < path_size; i++) {
+        float3 line = path[i].position - path[i - 1].position;
+        throughput = throughput / dot(line, line);
+    }
+    for (int i = 1; i < path_size - 1; i++) {
+        const BDPTVertex& midPoint = path[i];
+        float3 lastDirection = normalize(path[i - 1].position - midPoint.position);
+        float3 nextDirection = normalize(path[i + 1].position - midPoint.position);
+        Pbr mat = S.materials[midPoint.materialId];
+        mat.base_color = midPoint.color;
+        throughput = throughput * (fabsf(dot(midPoint.normal, lastDirection)) * fabsf(dot(midPoint.normal, nextDirection)) *
+                                   Eval(mat, midPoint.normal, lastDirection, nextDirection));
+    }
+    return throughput;
+}
+// the factors shared by pdfCompute and MISWeight_SPCBPT: eye sub-path of `eyePathLength` vertices traced from the camera
+inline float eye_side_pdf(const Params& P, const BDPTVertex* path, int eyePathLength) {  // cuProg.h:972-994 = 1004-1027
+    const Scene& S = *P.scene;
+    float pdf = 1.0f;
+    for (int i = 1; i < eyePathLength; i++) {
+        float3 line = path[i].position - path[i - 1].position;
+        float3 lineDirection = normalize(line);
+        pdf *= 1.0f / dot(line, line) * fabsf(dot(path[i].normal, lineDirection));
+    }
+    for (int i = 1; i < eyePathLength - 1; i++) {
+        const BDPTVertex& midPoint = path[i];
+        float3 lastDirection = normalize(path[i - 1].position - midPoint.position);
+        float3 nextDirection = normalize(path[i + 1].position - midPoint.position);
+        Pbr mat = S.materials[midPoint.materialId];
+        mat.base_color = midPoint.color;
+        float rr_rate = fmaxf3(midPoint.color);   // NOT clamped to MIN_RR_RATE here, unlike the walk (hit_program.cu:325-328): kept as written
+        pdf *= Pdf(mat, midPoint.normal, lastDirection, nextDirection) * rr_rate;
+    }
+    return pdf;
+}
+inline float pdfCompute(const Params& P, const BDPTVertex* path, int path_size, int strategy_id) {  // cuProg.h:935-996
+    const Scene& S = *P.scene;
+    int eyePathLength = strategy_id;
+    int lightPathLength = path_size - eyePathLength;
+    float pdf = 1.0f;
+    if (lightPathLength > 0) pdf *= path[path_size - 1].pdf;
+    if (lightPathLength > 1) {
+        const BDPTVertex& light = path[path_size - 1];
+        const BDPTVertex& lastMidPoint = path[path_size - 2];
+        float3 lightDirection = normalize(lastMidPoint.position - light.position);
+        pdf = (float)((double)pdf * ((double)fabsf(dot(lightDirection, light.normal)) / M_PI));   // `pdf *= abs(..) / M_PI` with the double literal
+        for (int i = 1; i < lightPathLength; i++) {
+            const BDPTVertex& midPoint = path[path_size - i - 1];
+            float3 line = midPoint.position - path[path_size - i].position;
+            float3 lineDirection = normalize(line);
+            pdf = (float)((double)pdf * (1.0 / (double)dot(line, line) * (double)fabsf(dot(midPoint.normal, lineDirection))));   // `1.0 / dot(..)`: double
+        }
+        for (int i = 1; i < lightPathLength - 1; i++) {
+            const BDPTVertex& midPoint = path[path_size - i - 1];
+            float3 lastDirection = normalize(path[path_size - i].position - midPoint.position);
+            float3 nextDirection = normalize(path[path_size - i - 2].position - midPoint.position);
+            Pbr mat = S.materials[midPoint.materialId];
+            mat.base_color = midPoint.color;
+            float rr_rate = fmaxf3(midPoint.color);
+            pdf *= Pdf(mat, midPoint.normal, lastDirection, nextDirection) * rr_rate;
+        }
+    }
+    return pdf * eye_side_pdf(P, path, eyePathLength);
+}
+inline float MISWeight_SPCBPT(const Params& P, const BDPTVertex* path, int path_size, int strategy_id) {  // cuProg.h:998-1105
+    const Scene& S = *P.scene;
+    if (strategy_id <= 1 || strategy_id == path_size) return pdfCompute(P, path, path_size, strategy_id);
+    int eyePathLength = strategy_id;
+    int lightPathLength = path_size - eyePathLength;
+    float pdf = eye_side_pdf(P, path, eyePathLength);
+    float3 light_contri = make_float3(1.0f);
+    if (lightPathLength > 0) light_contri = light_contri * path[path_size - 1].flux;
+    if (lightPathLength > 1) {
+        const BDPTVertex& lastMidPoint = path[path_size - 2];
+        for (int i = 1; i < lightPathLength; i++) {
+            const BDPTVertex& midPoint = path[path_size - i - 1];
+            float3 line = midPoint.position - path[path_size - i].position;
+            float3 lineDirection = normalize(line);
+            // `1.0 / dot(line, line) * |n_mid . dir| * |n_lastMid . dir|` in double, times the float3 -- note lastMidPoint, not lastPoint, as written
+            double g = 1.0 / (double)dot(line, line) * (double)fabsf(dot(midPoint.normal, lineDirection)) * (double)fabsf(dot(lastMidPoint.normal, lineDirection));
+            light_contri = light_contri * (float)g;   // operator*=(float3&, float): the double narrows first
+        }
+        for (int i = 1; i < lightPathLength - 1; i++) {
+            const BDPTVertex& midPoint = path[path_size - i - 1];
+            float3 lastDirection = normalize(path[path_size - i].position - midPoint.position);
+            float3 nextDirection = normalize(path[path_size - i - 2].position - midPoint.position);
+            Pbr mat = S.materials[midPoint.materialId];
+            mat.base_color = midPoint.color;
+            light_contri = light_contri * Eval(mat, midPoint.normal, lastDirection, nextDirection);
+        }
+    }
+    float3 position = path[strategy_id - 1].position, normal = path[strategy_id - 1].normal;
+    float3 dir = normalize(path[strategy_id - 2].position - path[strategy_id - 1].position);
+    int eye_subspace_id = getLabel(P, position, normal, dir, false);
+    int light_subspace_id;
+    if (strategy_id == path_size - 1) light_subspace_id = path[strategy_id].subspaceId;
+    else {
+        position = path[strategy_id].position; normal = path[strategy_id].normal;
+        dir = normalize(path[strategy_id + 1].position - path[strategy_id].position);
+        light_subspace_id = getLabel(P, position, normal, dir, true);
+    }
+    return pdf * float3weight(connectRate_SOL(P, eye_subspace_id, light_subspace_id, light_contri));
+}
+inline float3 eval_path(const Params& P, const BDPTVertex* path, int path_size, int strategy_id) {  // raygen.cu:445-464
+    float pdf = pdfCompute(P, path, path_size, strategy_id);
+    float3 contri = contriCompute(P, path, path_size);
+    float MIS_weight_not_normalize = MISWeight_SPCBPT(P, path, path_size, strategy_id);
+    float MIS_weight_dominator = 0.0f;
+    for (int i = 2; i <= path_size; i++) MIS_weight_dominator += MISWeight_SPCBPT(P, path, path_size, i);
+    float3 ans = contri / pdf * (MIS_weight_not_normalize / MIS_weight_dominator);
+    if (is_invalid(ans)) return make_float3(0.0f);
+    return ans;
+}
+inline float3 spcbpt_no_rmis_sample(const Params& P, unsigned x, unsigned y) {  // raygen.cu:465-590
+    const Scene& S = *P.scene;
+    uint32_t seed;
+    float3 ray_direction = camera_ray(P, x, y, seed);
+    float3 ray_origin = P.eye;
+    float3 result = make_float3(0);
+    PayloadBDPTVertex payload;
+    payload.clear();
+    payload.seed = seed;
+    payload.ray_direction = ray_direction;
+    payload.origin = ray_origin;
+    init_EyeSubpath(payload.path, ray_origin, ray_direction);
+    BDPTVertex pathBuffer[MAX_PATH_LENGTH_FOR_MIS];
+    int buffer_size = 0;
+    pathBuffer[buffer_size] = payload.path.currentVertex(); buffer_size++;
+    if (P.counters) { P.counters->pixel_samples++; P.counters->eye_paths++; }
+    while (true) {
+        ray_direction = payload.ray_direction;
+        ray_origin = payload.origin;
+        if (payload.done || payload.depth > 50) break;
+        int begin_depth = payload.path.size;
+        trace_subpath(P, ray_origin, ray_direction, &payload, false);
+        if (payload.path.size == begin_depth) break;
+        payload.depth += 1;
+        pathBuffer[buffer_size] = payload.path.currentVertex(); buffer_size++;
+        if (payload.path.hit_lightSource()) {
+            lightSample light_sample;
+            light_sample.ReverseSample(P, S.lights[payload.path.currentVertex().materialId], payload.path.currentVertex().uv);
+            BDPTVertex light_vertex;
+            init_vertex_from_lightSample(light_sample, light_vertex);
+            pathBuffer[buffer_size - 1] = light_vertex;
+            result += eval_path(P, pathBuffer, buffer_size, buffer_size);
+            break;
+        }
+        if (buffer_size >= MAX_PATH_LENGTH_FOR_MIS) break;
+        BDPTVertex& eye_subpath = payload.path.currentVertex();
+        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+            int light_id = 0;
+            float pmf_firstStage = 1;
+            if (P.light_tree) light_id = sampleFirstStage(P, eye_subpath.subspaceId, payload.seed, pmf_firstStage);
+            if (P.sampler.subspace[light_id].size == 0) continue;
+            float pmf_secondStage;
+            const BDPTVertex& light_subpath = sampleSecondStage(P, light_id, payload.seed, pmf_secondStage);
+            if (P.counters) P.counters->connections++;
+            if ((buffer_size + light_subpath.depth + 1 <= MAX_PATH_LENGTH_FOR_MIS) &&
+                S.visibilityTest(eye_subpath.position, light_subpath.position, P.counters)) {
+                float pmf = P.sampler.path_count * pmf_secondStage * pmf_firstStage;
+                int origin_buffer_size = buffer_size;
+                const BDPTVertex* light_ptr = &light_subpath;
+                while (true) {   // the light sub-path sits in consecutive LVC slots, origin first: walk it backwards
+                    pathBuffer[buffer_size] = *light_ptr; buffer_size++;
+                    if (light_ptr->depth == 0) break;
+                    light_ptr--;
+                }
+                float3 res = eval_path(P, pathBuffer, buffer_size, origin_buffer_size) / pmf;
+                buffer_size = origin_buffer_size;
+                if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
+            }
+        }
+    }
+    return result;
+}
+inline void raygen_SPCBPT_no_rmis(const Params& P, unsigned x, unsigned y) { accumulate(P, x, y, spcbpt_no_rmis_sample(P, x, y)); }
+
 // __raygen__lightTrace (raygen.cu:620-685) for one core (= one OptiX thread)
 inline void raygen_lightTrace(const Params& P, int launch_index) {
     const LightTraceParams& lt = P.lt;

@@ -824,7 +824,7 @@ class Renderer:
 
     # -- the reference's per-frame sequence (optixPathTracer.cpp:791-822) ------
     def render_frame(self, alg: str, subframe: int, launch_frame: Optional[int] = None, rows=None):
-        if alg == "SPCBPT_eye":
+        if alg in ("SPCBPT_eye", "SPCBPT_no_rmis"):
             self.launch("light trace", subframe + 1 if launch_frame is None else launch_frame)
             self.build_sampler()
         self.launch(alg, subframe, rows)

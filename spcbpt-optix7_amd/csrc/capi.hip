@@ -482,7 +482,7 @@ int Context::import_gathered(const void* shards, const int* counts_all, int worl
     return 0;
 }
 
-int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs) {
+int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis) {
     if (!d_accum) { error = "render before spcbpt_resize"; return SPCBPT_ERR_STATE; }
     if (!have_camera) { error = "render before spcbpt_set_camera"; return SPCBPT_ERR_STATE; }
     if (spcbpt_alg && (!have_sampler || !have_subspace)) { error = "SPCBPT_eye needs a subspace tuple and a built sampler"; return SPCBPT_ERR_STATE; }
@@ -491,7 +491,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
     kp.counters = counting ? d_counters : nullptr;
     rk = (rk + 1) % n_render;   // consecutive render launches rotate through the render streams (see context.h)
-    if (spcbpt_alg && !eye_megakernel) rk = 0;   // the per-phase kernels share one set of queues: no overlap between their frames
+    if (spcbpt_alg && !eye_megakernel && !full_mis) rk = 0;   // the per-phase kernels share one set of queues: no overlap between their frames
     rstream = rstreams[rk];
     kp.result = d_result[rk];
     if (spcbpt_alg) {
@@ -500,7 +500,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         kp.jump = reinterpret_cast<const int32_t*>(set_vals2[eset]); kp.sampler_counts = set_counts[eset];
         if (rstream != stream && ev_sampler_set[eset]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[eset], 0));
     }
-    if (spcbpt_alg && !eye_megakernel) {
+    if (spcbpt_alg && !eye_megakernel && !full_mis) {
         kp.n_tiles = (uint32_t)render_tile_count(kp);
         time_begin(name, rstream);
         int rcw = launch_wavefront();
@@ -513,6 +513,15 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     }
     int rc = ensure_spill((size_t)render_thread_count(kp), true);
     if (rc) return rc;
+    if (full_mis) {   // "SPCBPT_no_rmis": a plain one-lane-per-pixel launch over the same sampler tables
+        time_begin(name, rstream);
+        launch_spcbpt_no_rmis(kp, rstream);
+        time_end();
+        HIP_TRY(this, hipGetLastError());
+        HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
+        ev_render_set[eset] = true;
+        return finish_frame();
+    }
     if (spcbpt_alg) {
         kp.n_tiles = (uint32_t)render_tile_count(kp);
         kp.work_counter = d_work_counter + rk;
@@ -1033,8 +1042,9 @@ int spcbpt_launch(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r
     if (alg == "light trace") return c->launch_light(frame);
     if (alg == "SPCBPT_eye") return c->launch_render("spcbpt_render", true, frame, r0, r1, rs);
     if (alg == "pt") return c->launch_render("pt", false, frame, r0, r1, rs);
+    if (alg == "SPCBPT_no_rmis") return c->launch_render("spcbpt_no_rmis", true, frame, r0, r1, rs, true);   // raygen.cu:465: defined upstream, wired to no program group
     if (alg == "pretrace") return c->launch_pretrace(frame);
-    c->error = "unknown algorithm '" + alg + "' (expected \"pt\", \"light trace\", \"SPCBPT_eye\" or \"pretrace\")";
+    c->error = "unknown algorithm '" + alg + "' (expected \"pt\", \"light trace\", \"SPCBPT_eye\", \"pretrace\" or \"SPCBPT_no_rmis\")";
     return SPCBPT_ERR_UNKNOWN_ALG;
 }
 

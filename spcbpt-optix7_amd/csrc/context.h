@@ -182,7 +182,7 @@ struct Context {
     int fetch_counts();           // counts of the latest light pass's set (lset) -> lvc_count, path_count
     int fetch_counts_of(int set);
     int build_sampler();
-    int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs);
+    int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis = false);
     // Batched eye launch (spcbpt_launch_eye_batch): the last n built samplers, one per frame, rendered by ONE persistent kernel
     // whose tile queue spans the frames (kernels.hip: BATCH).  A rank's share of a sharded frame is a few thousand tiles --
     // about one per resident wave, i.e. all drain phase; four frames in one queue regenerate like one frame four times the size.

@@ -127,4 +127,17 @@ SPC_DEV bool tile_pixel(const KParams& p, uint32_t tile, uint32_t slot, uint32_t
     return x < p.width && y < p.height && (int)y < p.row_end;
 }
 
+// pixel of this lane in the plain (non-persistent) launches: 8x8 tile per wave, 4 tiles (in x) per 256-thread block, bands of 8
+// rows selected by (row_begin, row_step)
+SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
+    const uint32_t tiles_x = (p.width + 7) / 8;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t tile_x = wave % tiles_x, band_k = wave / tiles_x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t band = (uint32_t)(p.row_begin / 8) + band_k * (uint32_t)p.row_step;
+    x = tile_x * 8 + (lane & 7);
+    y = band * 8 + (lane >> 3);
+    return x < p.width && y < p.height && (int)y < p.row_end && (int)y >= p.row_begin;
+}
+
 }  // namespace spc

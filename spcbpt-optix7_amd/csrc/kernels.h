@@ -31,6 +31,9 @@ void launch_pretrace(const KParams& p, uint32_t iteration, int num_core, int pad
                      spcbpt_pretrace_node* nodes, hipStream_t s);
 void launch_trace_any(const KParams& p, const float* rays, int n, int* vis, hipStream_t s);
 
+// "SPCBPT_no_rmis": the full-path-MIS variant (full_mis.hip)
+void launch_spcbpt_no_rmis(const KParams& p, hipStream_t s);
+
 // per-function harness (unit.hip)
 void launch_unit(const KParams& p, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n, const float* aux, hipStream_t s);
 

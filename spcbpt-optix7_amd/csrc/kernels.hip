@@ -33,18 +33,6 @@ static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye
 #define SPC_EYE_WAVES 4
 #endif
 
-// pixel of this lane: 8x8 tile per wave, 4 tiles (in x) per block, bands of 8 rows selected by (row_begin, row_step)
-SPC_DEV bool lane_pixel(const KParams& p, uint32_t& x, uint32_t& y) {
-    const uint32_t tiles_x = (p.width + 7) / 8;
-    const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-    const uint32_t tile_x = wave % tiles_x, band_k = wave / tiles_x;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t band = (uint32_t)(p.row_begin / 8) + band_k * (uint32_t)p.row_step;
-    x = tile_x * 8 + (lane & 7);
-    y = band * 8 + (lane >> 3);
-    return x < p.width && y < p.height && (int)y < p.row_end && (int)y >= p.row_begin;
-}
-
 // The SPCBPT megakernel: persistent waves with per-lane path regeneration.  A wave pulls 8x8 pixel tiles from a global
 // queue (one atomicAdd per tile); a lane whose eye path ends writes its pixel and immediately starts the next
 // pixel-sample of the wave's pool, so the 64 lanes stay busy although path lengths differ by an order of magnitude.

@@ -261,8 +261,11 @@ def test_c3_reference_light_trace_geometry_at_full_size(bench_scene, pkg, ob):
     assert (a["subspace_id"] == b["subspace_id"]).mean() > 0.999 and (a["material_id"] == b["material_id"]).all()
     for k in ("position", "flux", "pdf", "single_pdf", "rmis_pointer"):
         x, y = a[k].astype(np.float64), b[k].astype(np.float64)
-        scale = np.abs(y).max(axis=-1, keepdims=True) if y.ndim > 1 else np.abs(y)
-        assert np.percentile(np.abs(x - y) / (scale + 1e-9), 99) < 1e-3, k
+        fin = np.isfinite(x) & np.isfinite(y)
+        assert (np.isfinite(x) == np.isfinite(y)).mean() > 0.9999, k        # a grazing segment (|n . d| = 0) gives inf / NaN on both sides alike
+        scale = np.abs(np.where(fin, y, 0)).max(axis=-1, keepdims=True) if y.ndim > 1 else np.abs(np.where(fin, y, 0))
+        err = np.where(fin, np.abs(np.where(fin, x, 0) - np.where(fin, y, 0)) / (scale + 1e-9), 0.0)
+        assert np.percentile(err, 99) < 1e-3, k
     # identical cache -> identical tables
     lvc = o.lvc_read()
     r.lvc_import(lvc)
@@ -274,3 +277,37 @@ def test_c3_reference_light_trace_geometry_at_full_size(bench_scene, pkg, ob):
     np.testing.assert_array_equal(sg[2], so[2])
     assert np.abs(sg[1] - so[1]).max() < 3e-5
     assert (sg[0]["size"] > 0).sum() > 300                                      # hundreds of populated light subspaces
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_f4_full_path_mis_variant_matches_oracle_and_agrees_with_rmis(gpu, pkg, ob):
+    """"SPCBPT_no_rmis" = __raygen__SPCBPT_no_rmis (raygen.cu:445-606; contriCompute / pdfCompute / MISWeight_SPCBPT,
+    cuProg.h:901-1105): the subspace sampler weighted by classic full-path MIS.  (a) pixel parity with the oracle's restatement at
+    equal seeds; (b) it is an INDEPENDENT derivation of the weights rmis.h computes recursively, so its image mean must agree with
+    "SPCBPT_eye" and with "pt" -- on a trained multi-leaf tuple, where Gamma / Q actually differ between subspaces."""
+    scene = pkg.scenes.cornell_box()
+    W, H = 96, 96
+    r = _renderer(pkg, scene, W, H, (20000, 52, 1))
+    r.set_pretrace(20000, 10)
+    r.preprocess(target_paths=60000, target_q_paths=60000, train=True)
+    tup = r.get_subspace()
+    o = ob.Oracle(scene)
+    _setup(o, scene, W, H, (20000, 52, 1))
+    o.set_subspace(*tup); o.set_cmf_double(True)
+    for f in range(3):
+        r.render_frame("SPCBPT_no_rmis", f); o.render_frame("SPCBPT_no_rmis", f)
+    s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
+    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s
+    means = {}
+    for alg, n in (("pt", 1024), ("SPCBPT_eye", 256), ("SPCBPT_no_rmis", 256)):
+        r.clear_accum()
+        for f in range(n):
+            r.render_frame(alg, f, launch_frame=5000 + f)
+        a = r.read_accum()
+        assert (a[..., 3] == 1.0).all() and np.isfinite(a).all()
+        means[alg] = float(a[..., :3].astype(np.float64).mean())
+    print("cornell means:", means)
+    # 96 x 96 x 256 spp = 2.4 M samples each: standard error of the mean ~0.1 %; MAX_PATH_LENGTH_FOR_MIS = 20 drops longer paths
+    # (a few 1e-4 of the energy in this scene) and pdfCompute leaves the Russian-roulette rate unclamped -- tolerance 0.7 %
+    assert abs(means["SPCBPT_no_rmis"] - means["SPCBPT_eye"]) / means["SPCBPT_eye"] < 7e-3, means
+    assert abs(means["SPCBPT_no_rmis"] - means["pt"]) / means["pt"] < 7e-3, means

@@ -133,3 +133,25 @@ def test_spcbpt_agrees_with_pt(ob, pkg, scene_name):
     # coarse structure: 4x4 block means agree within 8 %
     blk = lambda a: a.reshape(4, 8, 4, 8, 3).mean(axis=(1, 3))
     assert np.abs(blk(sp) - blk(pt)).max() / blk(pt).mean() < 0.2
+
+
+def test_three_estimators_of_the_restatement_agree(ob, pkg):
+    """Row f4 / config 5's comparator on the CPU side: the recursive-MIS sampler ("SPCBPT_eye"), the same sampler with classic
+    full-path MIS ("SPCBPT_no_rmis": contriCompute / pdfCompute / MISWeight_SPCBPT, none of rmis.h) and "plain BDPT" (uniformSample
+    over the cache) estimate the same image on a multi-leaf tuple -- three derivations that would have to share a misreading."""
+    from tests.parity_util import grid_tree_tuple
+    scene = pkg.scenes.cornell_box()
+    o = _oracle(ob, pkg, scene, 40, 40, lt=(3000, 64, 1))
+    o.set_subspace(*grid_tree_tuple(pkg, o, scene))
+    means = {}
+    for name, alg, uniform, n in (("rmis", "SPCBPT_eye", False, 48), ("full_path", "SPCBPT_no_rmis", False, 48), ("uniform", "SPCBPT_eye", True, 96)):
+        o.set_uniform_lvc(uniform)
+        o.clear_accum()
+        for f in range(n):
+            o.render_frame(alg, f, launch_frame=300 + f)
+        a = o.read_accum()[..., :3]
+        assert np.isfinite(a).all()
+        means[name] = float(a.astype(np.float64).mean())
+    o.set_uniform_lvc(False)
+    assert abs(means["full_path"] - means["rmis"]) / means["rmis"] < 5e-3, means        # same samples, two weight derivations
+    assert abs(means["uniform"] - means["rmis"]) / means["rmis"] < 3e-2, means          # another sampler: Monte-Carlo noise only

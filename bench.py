@@ -103,6 +103,9 @@ def main():
                     help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 4 for 1-2 GPUs, 8 beyond: several frames in one tile queue pay the "
                          "drain phase of the persistent kernel once (and a rank's share of a sharded frame is about one tile per resident wave: "
                          "all drain); 1 = one launch per frame")
+    ap.add_argument("--light-batch", type=int, default=-1,
+                    help="1: the light passes of a batch of frames as ONE persistent launch too (spcbpt_launch_light_batch), a batch ahead; "
+                         "0: one launch per pass; -1 = 1 beyond 2 GPUs (a rank's 1/N pass is a ~1.2 ms chain whatever N, N of them cost more than one full pass)")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
@@ -204,13 +207,23 @@ def main():
     # and one eye pass; the light pass a step launches is consumed by the next step.
     ahead = not args.no_light_ahead
     depth = args.light_ahead if args.light_ahead > 0 else (batch if batch > 1 else 1)
-    state = {"next_light": 1, "primed": False}
+    state = {"next_light": 1, "primed": False, "lb_left": 0}
+    lbatch = ahead and batch > 1 and (args.light_batch == 1 or (args.light_batch < 0 and world > 2))
     if ahead:
         r.set_light_ahead(True)
+
+    def light_batch():
+        r.launch_light_batch(state["next_light"], batch); state["next_light"] += batch
 
     def step(f, isolate=False):
         if not ahead:
             r.launch("light trace", f + 1)
+        elif lbatch:                           # every `batch` steps: the passes of the batch after the one being built, as one launch
+            if state["lb_left"] == 0:
+                if not state["primed"]:
+                    light_batch(); state["primed"] = True
+                light_batch(); state["lb_left"] = batch
+            state["lb_left"] -= 1
         else:
             if not state["primed"]:
                 for _ in range(depth):
@@ -223,7 +236,8 @@ def main():
             # back-pressure, not a data dependency: without it the host queues dozens of frames of light passes and builds ahead of
             # the eye kernels and a rank-frame takes 1.7 instead of 1.4 ms (N = 8 share, rank_sim); the pass waited for was launched
             # `depth` steps ago, so the wait is normally over before it starts
-            r.sync_light()
+            if not lbatch:                     # (batched passes pace themselves: a batch waits for the eye launch that last read its sets)
+                r.sync_light()
             comm.exchange_lvc()                # queues the all-gather + compaction on the communicator's stream; no host wait
         r.build_sampler()
         if isolate and (batch == 1 or len(queued) == batch - 1):
@@ -346,7 +360,7 @@ def main():
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}, light pass geometry "
                                    f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": depth if ahead else 0, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu' if comm is not None else 'torch.distributed harness'}" + (f", shard capacity {comm.shard_capacity} vertices" if comm is not None else "") + ")"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu' if comm is not None else 'torch.distributed harness'}" + (f", shard capacity {comm.shard_capacity} vertices" if comm is not None else "") + ")"},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -361,6 +361,14 @@ int spcbpt_sync_light(spcbpt_ctx* ctx);
  * (SPCBPT_ERR_STATE otherwise).  SPCBPT_EYE_BATCH = F in the environment at spcbpt_create sizes the ring of sampler buffer
  * sets for batches of F, so that batches in flight, light passes ahead and builds never wait for a set. */
 int spcbpt_launch_eye_batch(spcbpt_ctx* ctx, int n_frames, const uint32_t* subframes, int row_begin, int row_end, int row_step);
+/* Batched light pass (no reference counterpart; needs spcbpt_set_light_ahead on): the "light trace" launches of launch frames
+ * first_frame .. first_frame + n_frames - 1 as ONE persistent kernel whose core queue spans the frames.  Every pass lands in its own
+ * buffer set and queues up exactly as n_frames spcbpt_launch("light trace", first_frame + k) calls would have left them -- the caches
+ * are bit-identical to those -- so the host goes on with n_frames x (export / import, spcbpt_build_sampler) and one
+ * spcbpt_launch_eye_batch.  The point is again the dependent chain: a rank of an 8-GPU job traces 1/8 of the cores per frame, each
+ * pass still takes the ~1.2 ms of its longest path, and beside the eye grid they run one after the other; in one queue they cost
+ * about one full-size pass.  n_frames <= 8 (SPCBPT_ERR_INVALID_ARG), SPCBPT_ERR_STATE without light-ahead mode. */
+int spcbpt_launch_light_batch(spcbpt_ctx* ctx, uint32_t first_frame, int n_frames);
 
 /* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain
  * however few paths a rank traces, and the LVC exchange makes the host wait for it; with on != 0 the host may launch frame

@@ -451,6 +451,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_launch": [vp, C.c_char_p, u32, i32, i32, i32],
         "spcbpt_build_sampler": [vp],
         "spcbpt_launch_eye_batch": [vp, i32, C.POINTER(u32), i32, i32, i32],
+        "spcbpt_launch_light_batch": [vp, u32, i32],
         "spcbpt_lvc_export": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)],
         "spcbpt_lvc_import": [vp, vp, i32, i32],
         "spcbpt_lvc_read": [vp, vp, i32, C.POINTER(i32)],
@@ -527,7 +528,7 @@ def load_library(path: str = LIB_PATH):
 
 EXPORTED_SYMBOLS = [
     "spcbpt_create", "spcbpt_destroy", "spcbpt_last_error", "spcbpt_set_camera", "spcbpt_set_camera_lookat",
-    "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_build_sampler",
+    "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_launch_light_batch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit",
@@ -626,6 +627,10 @@ class Renderer:
     def launch(self, name: str, frame: int, rows=None):
         r0, r1, rs = rows if rows is not None else (0, self.height, 1)
         self._chk(self.lib.spcbpt_launch(self.h, name.encode(), frame, r0, r1, rs), f"launch({name})")
+
+    def launch_light_batch(self, first_frame, n):
+        """The light passes of launch frames first_frame .. first_frame + n - 1 as one persistent launch (spcbpt_launch_light_batch)."""
+        self._chk(self.lib.spcbpt_launch_light_batch(self.h, first_frame, n), "launch_light_batch")
 
     def launch_eye_batch(self, subframes, rows=None):
         """One persistent eye kernel over the samplers of the last len(subframes) build_sampler calls (spcbpt_launch_eye_batch)."""

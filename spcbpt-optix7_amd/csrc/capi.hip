@@ -370,6 +370,104 @@ int Context::launch_light(uint32_t frame) {
     return 0;
 }
 
+// Batched light pass: see context.h.  Sets lset+1 .. lset+n receive the passes of launch frames first_frame .. first_frame+n-1 and
+// queue up in `pending` like n calls of launch_light; every one of them is bit-identical to the pass launch_light would have traced
+// (same seeds per core, same (core, slot) order after compaction).
+int Context::launch_light_batch(uint32_t first_frame, int n) {
+    if (!have_subspace) { error = "light trace needs a subspace tuple (spcbpt_set_subspace)"; return SPCBPT_ERR_STATE; }
+    if (n < 1 || n > kMaxBatchFrames || n > n_sets - 2) { error = "launch_light_batch: 1 .. min(8, sets - 2) frames per batch"; return SPCBPT_ERR_INVALID_ARG; }
+    if (!light_ahead) { error = "launch_light_batch: the passes queue up for build_sampler -- enable spcbpt_set_light_ahead first"; return SPCBPT_ERR_STATE; }
+    if (!d_scratch) {
+        spcbpt_light_trace_params d = {100000, 52, 1, 0, 0, 1};
+        int rc = set_light_trace(d);
+        if (rc) return rc;
+    }
+    int rc = ensure_lane_b();
+    if (rc) return rc;
+    hipStream_t ls = lstream_b;
+    const size_t slots = (size_t)lt.core_count * lt.core_padding, cstride = (size_t)lt.core_count + 1;
+    if ((size_t)n * slots > lb_scratch_capacity) {
+        if (sync_all()) return SPCBPT_ERR_HIP;
+        dev_free(lb_scratch); HIP_TRY(this, dev_alloc(&lb_scratch, (size_t)n * slots)); lb_scratch_capacity = (size_t)n * slots;
+    }
+    if ((size_t)n * cstride > lb_counts_capacity) {
+        if (sync_all()) return SPCBPT_ERR_HIP;
+        dev_free(lb_core_counts); dev_free(lb_core_offsets); dev_free(lb_path_counts);
+        HIP_TRY(this, dev_alloc(&lb_core_counts, (size_t)n * cstride)); HIP_TRY(this, dev_alloc(&lb_core_offsets, (size_t)n * cstride));
+        HIP_TRY(this, dev_alloc(&lb_path_counts, (size_t)kMaxBatchFrames));
+        lb_counts_capacity = (size_t)n * cstride;
+    }
+    kp.num_core = lt.num_core; kp.core_padding = lt.core_padding; kp.m_per_core = lt.m_per_core;
+    kp.core_begin = lt.core_begin; kp.core_count = lt.core_count; kp.launch_frame = first_frame;
+    kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
+    kp.lvc_scratch = lb_scratch; kp.core_counts = lb_core_counts; kp.path_counter = lb_path_counts;
+    kp.n_lframes = n;
+    if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
+    const int blocks = light_trace_blocks(kp, light_blocks);
+    {   // traversal-stack spill area, indexed by blockIdx.x * 256 + threadIdx.x of the grid launched
+        const int entries = spill_entries_needed();
+        kp.spill_entries = entries;
+        const size_t need = (size_t)blocks * 256 * (size_t)entries;
+        if (entries == 0) kp.spill = nullptr;
+        else {
+            if (need > lb_spill_capacity) { if (sync_all()) return SPCBPT_ERR_HIP; dev_free(lb_spill); HIP_TRY(this, dev_alloc(&lb_spill, need)); lb_spill_capacity = need; }
+            kp.spill = lb_spill;
+        }
+    }
+    kp.counters = counting ? d_counters : nullptr;
+    CompactBatch dst = {};
+    int sets[kMaxBatchFrames];
+    for (int k = 0; k < n; k++) {   // what launch_light waits for before it rewrites a set, for every set of the batch
+        const int s = (lset + 1 + k) % n_sets;
+        sets[k] = s;
+        if (ev_render_set[s]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[s], 0));
+        if (ev_set_touched[s]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_set_stream[s], 0));
+        if (ev_exch_set[s]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_exch[s], 0));
+        set_bound[s] = -1;
+        dst.lvc[k] = set_lvc[s]; dst.counts[k] = set_counts[s];
+    }
+    HIP_TRY(this, hipMemsetAsync(lb_core_counts, 0, (size_t)n * cstride * sizeof(int), ls));
+    HIP_TRY(this, hipMemsetAsync(lb_path_counts, 0, kMaxBatchFrames * sizeof(int), ls));
+    kp.work_counter = d_work_counter + kMaxRender + 1;   // the second lane's queue head
+    HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
+    time_begin("light_trace", ls);
+    launch_light_trace(kp, counting || tree_has_direction, light_blocks, ls);
+    time_end();
+    kp.n_lframes = 0;
+    HIP_TRY(this, hipGetLastError());
+    time_begin("lvc_compact", ls);
+    size_t tb = 0;
+    const int items = (int)((size_t)n * cstride);
+    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, lb_core_counts, lb_core_offsets, items, ls));
+    if (tb > b_temp_capacity) { if (sync_all()) return SPCBPT_ERR_HIP; dev_free(b_temp); HIP_TRY(this, dev_alloc(&b_temp, tb)); b_temp_capacity = tb; }
+    HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(b_temp, tb, lb_core_counts, lb_core_offsets, items, ls));
+    launch_lvc_compact_batch(lb_scratch, lb_core_counts, lb_core_offsets, lb_path_counts, lt.core_count, lt.core_padding, n, dst, ls);
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    // (vertex_count, path_count) of the sets to pinned host memory: the sets are consecutive modulo n_sets -> at most two ranges
+    {
+        const int s0 = sets[0], first = std::min(n, n_sets - s0);
+        HIP_TRY(this, hipMemcpyAsync(h_light_counts + 2 * s0, d_set_counts_all + 2 * s0, (size_t)first * 2 * sizeof(int), hipMemcpyDeviceToHost, ls));
+        if (first < n) HIP_TRY(this, hipMemcpyAsync(h_light_counts, d_set_counts_all, (size_t)(n - first) * 2 * sizeof(int), hipMemcpyDeviceToHost, ls));
+    }
+    for (int k = 0; k < n; k++) {
+        const int s = sets[k];
+        HIP_TRY(this, hipEventRecord(ev_light[s], ls));
+        if (keys_set == s) keys_ready = false;   // lane 0's keys no longer describe the set
+        set_count_host[s] = -1;
+        light_counts_valid[s] = true;
+        light_lane_of_set[s] = 1;
+        for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == s) ? built_sets.erase(it) : it + 1;
+        for (auto it = pending.begin(); it != pending.end();) it = (*it == s) ? pending.erase(it) : it + 1;
+        pending.push_back(s);
+    }
+    lset = sets[n - 1];
+    select_set(lset);
+    lvc_count = -1;
+    have_sampler = false;
+    return 0;
+}
+
 int Context::fetch_counts_of(int set) {
     int h[2] = {0, 0};
     HIP_TRY(this, hipMemcpyAsync(h, set_counts[set], sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -747,7 +845,8 @@ Context::~Context() {
     dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
-    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); dev_free(set_counts[s]); }
+    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); }
+    dev_free(d_set_counts_all); dev_free(lb_scratch); dev_free(lb_core_counts); dev_free(lb_core_offsets); dev_free(lb_path_counts); dev_free(lb_spill);
     dev_free(d_counters); dev_free(d_diag); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
     for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
     if (h_frames) (void)hipHostFree(h_frames);
@@ -930,10 +1029,11 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     }
     CREATE_TRY(dev_alloc(&c->d_tex, texs.size()));
     if (!texs.empty()) CREATE_TRY(hipMemcpy(c->d_tex, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
+    CREATE_TRY(dev_alloc(&c->d_set_counts_all, (size_t)2 * Context::kMaxSets));
+    CREATE_TRY(hipMemset(c->d_set_counts_all, 0, 2 * Context::kMaxSets * sizeof(int)));
     for (int s = 0; s < c->n_sets; s++) {
         CREATE_TRY(dev_alloc(&c->set_subspace[s], (size_t)SPCBPT_NUM_SUBSPACE));
-        CREATE_TRY(dev_alloc(&c->set_counts[s], (size_t)2));
-        CREATE_TRY(hipMemset(c->set_counts[s], 0, 2 * sizeof(int)));
+        c->set_counts[s] = c->d_set_counts_all + 2 * s;
     }
     c->select_set(0);
     {
@@ -1051,6 +1151,11 @@ int spcbpt_launch(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r
 int spcbpt_launch_eye_batch(spcbpt_ctx* c, int n_frames, const uint32_t* subframes, int r0, int r1, int rs) {
     CTX_CHECK(c);
     return c->launch_eye_batch(n_frames, subframes, r0, r1, rs);
+}
+
+int spcbpt_launch_light_batch(spcbpt_ctx* c, uint32_t first_frame, int n_frames) {
+    CTX_CHECK(c);
+    return c->launch_light_batch(first_frame, n_frames);
 }
 
 int spcbpt_build_sampler(spcbpt_ctx* c) {

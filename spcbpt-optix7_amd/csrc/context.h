@@ -84,6 +84,15 @@ struct Context {
     unsigned char* b_temp = nullptr; size_t b_temp_capacity = 0;
     uint32_t* b_spill = nullptr; size_t b_spill_capacity = 0;
     int ensure_lane_b();
+    // Batched light pass (spcbpt_launch_light_batch): the passes of n consecutive launch frames as ONE persistent launch on the
+    // second lane, each into its own set.  A rank of an 8-GPU job traces 1/8 of the cores per frame; its pass is then a ~1.2 ms
+    // chain of 50 dependent bounces that the few block slots beside the eye grid run one after the other -- eight of them per eye
+    // batch cost more than the eye batch itself.  In one queue they regenerate like one pass of eight times the cores.
+    LightVertex* lb_scratch = nullptr; size_t lb_scratch_capacity = 0;     // n * core_count * core_padding
+    int *lb_core_counts = nullptr, *lb_core_offsets = nullptr, *lb_path_counts = nullptr; size_t lb_counts_capacity = 0;   // n * (core_count + 1)
+    uint32_t* lb_spill = nullptr; size_t lb_spill_capacity = 0;
+    int launch_light_batch(uint32_t first_frame, int n);
+    int* d_set_counts_all = nullptr;         // one allocation behind set_counts[]: set s at + 2 s (a batch copies its sets' counts to the host as ranges)
     LightVertex* set_lvc[kMaxSets] = {};
     uint32_t* set_vals2[kMaxSets] = {};
     float* set_cmfs[kMaxSets] = {};

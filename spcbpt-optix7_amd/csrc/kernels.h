@@ -14,6 +14,10 @@ int render_tile_count(const KParams& p);
 void launch_pt(const KParams& p, bool count, hipStream_t s);
 void launch_film_merge(const KParams& p, hipStream_t s);
 void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s);
+struct CompactBatch { LightVertex* lvc[kMaxBatchFrames]; int* counts[kMaxBatchFrames]; };   // per frame of a batched light pass: compact LVC + (vertex_count, path_count) of its set
+void launch_lvc_compact_batch(const LightVertex* scratch, const int* core_counts, const int* core_offsets, const int* path_counts, int core_count,
+                              int core_padding, int n, const CompactBatch& dst, hipStream_t s);
+int light_trace_blocks(const KParams& p, int max_blocks);   // grid of the (batched) light pass: the spill area is sized for it
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
                         LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);

@@ -477,6 +477,9 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
     int local_core = 0, nverts = 0, npaths = 0, origins = 0;
     uint32_t seed = 0, pseed = 0;
     LightVertex* slots = nullptr;
+    const bool batched = p.n_lframes > 0;   // several frames' passes in one queue (each lane then counts its cores' paths with one atomic per core)
+    const uint32_t queue_len = batched ? (uint32_t)p.core_count * (uint32_t)p.n_lframes : (uint32_t)p.core_count;
+    int fk = 0;   // frame of the lane's core within a batched pass
     // per-path state
     bool in_path = false;
     f3 origin = mk3(0.0f), dir = mk3(0.0f), next_flux = mk3(0.0f);
@@ -494,6 +497,12 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
         nverts++;
         cn.add(C_LVCW);
     };
+    auto core_done = [&]() {   // the lane's core is complete: its vertex count, and the paths it started
+        if (batched) {
+            p.core_counts[(size_t)fk * (p.core_count + 1) + local_core] = nverts;
+            atomicAdd(p.path_counter + fk, origins);
+        } else { p.core_counts[local_core] = nverts; paths_started += origins; }
+    };
     while (true) {
         // ---- regeneration: cores of the queue to lanes without one
         unsigned long long idle = __ballot(!has_core);
@@ -502,9 +511,9 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                 uint32_t t = 0;
                 if (lane == (uint32_t)__ffsll((long long)idle) - 1u) t = atomicAdd(p.work_counter, 64u);
                 t = __shfl(t, __ffsll((long long)idle) - 1, 64);
-                if (t >= (uint32_t)p.core_count) { exhausted = true; break; }
+                if (t >= queue_len) { exhausted = true; break; }
                 pool_base = t;
-                pool_left = min(64, p.core_count - (int)t);
+                pool_left = min(64, (int)(queue_len - t));
             }
             const int n_idle = __popcll(idle);
             const int take = n_idle < pool_left ? n_idle : pool_left;
@@ -512,11 +521,19 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
             if (!has_core && my_rank < take) {
                 local_core = (int)pool_base + my_rank;
                 has_core = true;
+                uint32_t launch_frame = p.launch_frame;
+                LightVertex* scratch = p.lvc_scratch;
+                if (batched) {   // the queue spans the passes of n_lframes frames (layout.h: n_lframes)
+                    fk = local_core / p.core_count;
+                    local_core -= fk * p.core_count;
+                    launch_frame += (uint32_t)fk;
+                    scratch += (size_t)fk * p.core_count * p.core_padding;
+                }
                 const int core = p.core_begin + local_core;
-                seed = tea4((uint32_t)core, p.launch_frame);  // light sampling stream
+                seed = tea4((uint32_t)core, launch_frame);  // light sampling stream
                 // payload.seed: BSDF stream; the reference starts it equal to `seed`
-                pseed = p.lt_decorrelate ? tea4((uint32_t)core ^ 0x80000000u, p.launch_frame) : seed;
-                slots = p.lvc_scratch + (size_t)local_core * p.core_padding;
+                pseed = p.lt_decorrelate ? tea4((uint32_t)core ^ 0x80000000u, launch_frame) : seed;
+                slots = scratch + (size_t)local_core * p.core_padding;
                 nverts = 0; npaths = 0; origins = 0;
                 in_path = false;
             }
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
             next_single_pdf = dir_pdf;
             depth = 0;
             in_path = nverts < p.core_padding;   // a full slot range ends the core right after the origin vertex
-            if (!in_path) { p.core_counts[local_core] = nverts; paths_started += origins; has_core = false; }
+            if (!in_path) { core_done(); has_core = false; }
         }
         // ---- one segment of every running path (hit_program.cu:341-438)
         const bool tracing = has_core && in_path;
@@ -647,7 +664,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     npaths++;
                     if (npaths >= p.m_per_core || !(nverts < p.core_padding)) core_over = true;
                 }
-                if (core_over) { p.core_counts[local_core] = nverts; paths_started += origins; has_core = false; }
+                if (core_over) { core_done(); has_core = false; }
             }
         }
     }
@@ -690,6 +707,31 @@ __global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int
         }
     }
     (void)sampler_counts;
+}
+
+// Compaction of a batched light pass: grid.y = frame of the batch.  core_offsets is ONE exclusive scan over the n * (core_count + 1)
+// counts (each frame's segment ends in a zero sentinel), so frame k's offsets are relative to its first entry and its total is the
+// sentinel's offset minus that.  Keys are left to the sampler build (k_fill_keys_from_lvc), which also counts the paths again.
+__global__ void k_lvc_compact_batch(const LightVertex* __restrict__ scratch, const int* __restrict__ core_counts, const int* __restrict__ core_offsets,
+                                    const int* __restrict__ path_counts, int core_count, int core_padding, CompactBatch dst) {
+    const int k = blockIdx.y;
+    const int* counts = core_counts + (size_t)k * (core_count + 1);
+    const int* offs = core_offsets + (size_t)k * (core_count + 1);
+    const int base = offs[0];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) { dst.counts[k][0] = offs[core_count] - base; dst.counts[k][1] = path_counts[k]; }
+    if (t < (long long)core_count * core_padding) {
+        const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
+        if (slot < counts[core]) {
+            const float4* src = reinterpret_cast<const float4*>(scratch + (size_t)k * core_count * core_padding + t);
+            float4* out = reinterpret_cast<float4*>(dst.lvc[k] + (offs[core] - base + slot));
+            float4 q[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) q[j] = src[j];
+#pragma unroll
+            for (int j = 0; j < 6; j++) out[j] = q[j];
+        }
+    }
 }
 
 __global__ void k_fill_keys_from_lvc(const LightVertex* __restrict__ lvc, int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -1119,10 +1161,15 @@ void launch_pt(const KParams& p, bool count, hipStream_t s) {
     if (count) hipLaunchKernelGGL(k_pt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL(k_pt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
 }
-void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s) {
-    int blocks = (p.core_count + BLOCK - 1) / BLOCK;   // p.work_counter (the core queue head) must have been zeroed on `s`
-    if (blocks <= 0) return;
+int light_trace_blocks(const KParams& p, int max_blocks) {
+    const long long cores = (long long)p.core_count * (p.n_lframes > 0 ? p.n_lframes : 1);
+    long long blocks = (cores + BLOCK - 1) / BLOCK;
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    return (int)blocks;
+}
+void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s) {
+    const int blocks = light_trace_blocks(p, max_blocks);   // p.work_counter (the core queue head) must have been zeroed on `s`
+    if (blocks <= 0) return;
     if (count) hipLaunchKernelGGL(k_light_trace<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL(k_light_trace<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
 }
@@ -1132,6 +1179,12 @@ void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, cons
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(k_lvc_compact, dim3(blocks), dim3(256), 0, s, scratch, core_counts, core_offsets, core_count,
                        core_padding, lvc, keys, vals, weights, sampler_counts);
+}
+void launch_lvc_compact_batch(const LightVertex* scratch, const int* core_counts, const int* core_offsets, const int* path_counts, int core_count,
+                              int core_padding, int n, const CompactBatch& dst, hipStream_t s) {
+    const long long total = (long long)core_count * core_padding;
+    hipLaunchKernelGGL(k_lvc_compact_batch, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, s, scratch, core_counts, core_offsets,
+                       path_counts, core_count, core_padding, dst);
 }
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
     if (n <= 0) return;

@@ -110,6 +110,8 @@ struct FrameDesc {  // 64 B
     uint32_t pad[3];
 };
 static const int kMaxBatchFrames = 8;   // fid travels in 4 bits next to the pixel coordinates
+static_assert(kMaxBatchFrames <= 16, "the frame id of a batched launch is packed into 4 bits (kernels.hip: published eye vertex)");
+
 
 struct KParams {  // passed by value as the kernel argument block (the MyParams analogue)
     DeviceScene scene;
@@ -139,6 +141,9 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     LightVertex* lvc_scratch;   // core_count * core_padding padded slots
     int32_t* core_counts;       // vertices stored per core
     int32_t* path_counter;      // number of light paths started (= depth-0 vertices) by this launch
+    int32_t n_lframes;          // > 0: batched light pass -- the passes of launch frames launch_frame .. launch_frame + n_lframes - 1 share
+                                // one core queue (core t of the queue = local core t % core_count of frame t / core_count); frame k stores
+                                // to lvc_scratch + k * core_count * core_padding, counts to core_counts + k * (core_count + 1) and paths to path_counter[k]
     // instrumentation / traversal scratch
     uint32_t* work_counter;        // tile queue head of the persistent megakernel (zeroed before each launch)
     uint32_t n_tiles;              // 8x8 pixel tiles in the selected bands

@@ -472,3 +472,62 @@ def test_cached_vertex_labels_are_the_labels_the_reference_derives(gpu, pkg, ob)
     assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2, s
     with pytest.raises(pkg.SpcbptError, match="direction"):
         r.launch_eye_batch([0])
+
+
+def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkeypatch):
+    """spcbpt_launch_light_batch: n light passes as one persistent launch whose core queue spans the frames.  Every pass must leave
+    the cache (vertices in (core, slot) order, vertex and path counts), the sampler tables and finally the image that the n single
+    "light trace" launches leave -- bit for bit, for a shard of the cores (core_begin > 0) and a batch that wraps around the ring
+    of buffer sets."""
+    import torch
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    W, H, NF = 96, 96, 5
+    monkeypatch.setenv("SPCBPT_EYE_BATCH", str(NF))
+    monkeypatch.setenv("SPCBPT_SETS", "7")          # 5 sets per batch in a ring of 7: the second batch wraps
+    r = pkg.Renderer(scene, 0)
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+    r.resize(W, H)
+    r.set_light_trace(4000, 52, 1, core_begin=700, core_count=1900)
+    r.set_subspace()
+    with pytest.raises(pkg.SpcbptError, match="light_ahead"):
+        r.launch_light_batch(1, NF)                  # the passes must queue up
+    dev = torch.device("cuda", 0)
+
+    def cache_of_oldest_pass():
+        r.sync_light()
+        dv, dc, cap = r.lvc_export()
+        n, paths = pkg.dist.device_view(dc, 8, dev).view(torch.int32).cpu().numpy()
+        v = pkg.dist.device_view(dv, int(n) * 96, dev).cpu().numpy().view(pkg.api.LIGHT_VERTEX_DTYPE).copy()
+        return int(n), int(paths), v
+
+    want = []
+    for rnd in range(2):
+        for f in range(NF):
+            r.launch("light trace", 10 * rnd + f + 1)
+            n, paths, v = cache_of_oldest_pass()
+            r.build_sampler()
+            want.append((n, paths, v, r.sampler_read()))
+        r.launch_eye_batch([NF * rnd + f for f in range(NF)])
+    r.sync()
+    img = r.read_accum().copy()
+    assert all(w[0] > 1900 and w[1] == 1900 for w in want)
+    r.clear_accum()
+    r.set_light_ahead(True)
+    k = 0
+    for rnd in range(2):
+        r.launch_light_batch(10 * rnd + 1, NF)
+        for f in range(NF):
+            n, paths, v = cache_of_oldest_pass()
+            wn, wp, wv, ws = want[k]; k += 1
+            assert (n, paths) == (wn, wp)
+            assert v.tobytes() == wv.tobytes()
+            r.build_sampler()
+            sub, cmfs, jump, vc, pc = r.sampler_read()
+            assert (vc, pc) == (ws[3], ws[4])
+            assert np.array_equal(sub, ws[0]) and np.array_equal(cmfs, ws[1]) and np.array_equal(jump, ws[2])
+        r.launch_eye_batch([NF * rnd + f for f in range(NF)])
+    r.sync()
+    assert np.array_equal(r.read_accum(), img)
+    with pytest.raises(pkg.SpcbptError):
+        r.launch_light_batch(1, 9)

@@ -51,8 +51,9 @@ def _single(pkg, scene, nf, lt=(3000, 64, 1)):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,batch,lt", [(2, 2, (3000, 64, 1)), (3, 1, (3000, 64, 1)), (2, 2, (40, 200, 60))])
-def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt):
+@pytest.mark.parametrize("world,batch,lt,lbatch", [(2, 2, (3000, 64, 1), False), (3, 1, (3000, 64, 1), False), (2, 2, (40, 200, 60), False),
+                                                   (3, 3, (3000, 64, 1), True)])   # lbatch: a batch's light passes as one launch too
+def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, lbatch):
     scene = pkg.scenes.cornell_box()
     NF = 6
     single, want = _single(pkg, scene, NF, lt)
@@ -72,11 +73,13 @@ def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt):
     assert all(c.shard_capacity == cap for c in comms) and cap < lt[0] * lt[1]
     for r in ranks:
         r.set_light_ahead(True)
-        r.launch("light trace", 1)                            # the pass running ahead
+        if lbatch: r.launch_light_batch(1, batch)             # the passes running ahead: one batch
+        else: r.launch("light trace", 1)
     queued = []
     for f in range(NF):
         for r in ranks:
-            r.launch("light trace", f + 2)
+            if not lbatch: r.launch("light trace", f + 2)
+            elif f % batch == 0: r.launch_light_batch(f + 1 + batch, batch)
         for c in comms:
             c.exchange_lvc()                                  # no host wait; completes when the last rank has posted
         for r in ranks:

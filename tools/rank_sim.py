@@ -1,6 +1,7 @@
 """What one rank of an N-GPU job does per frame, on one GPU: 1/N of the light cores, every N-th 8-row band.  Shows how the
 step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS).
-  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead | --ahead=D] [--batch=F] [--trained]
+  python tools/rank_sim.py N streams [steps] [--exchange] [--ahead | --ahead=D] [--batch=F] [--lbatch] [--trained]
+--lbatch: the light passes of a batch of F frames as one launch too (spcbpt_launch_light_batch), one batch ahead.
 --exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
 all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
 rate when its share of the image is small."""
@@ -39,8 +40,13 @@ comm = None
 if native:
     comm = p.dist.Comm(r, 0, 1, p.dist.unique_id())
     print("shard capacity after calibration:", comm.calibrate(passes=2, slack=1.5))
+lbatch = "--lbatch" in sys.argv and batch > 1
 rows = (0, H, N)
-if ahead:
+if lbatch:
+    r.set_light_ahead(True)
+    r.launch_light_batch(1, batch)
+    depth = batch
+elif ahead:
     r.set_light_ahead(True)
     for k in range(depth): r.launch("light trace", 1 + k)
 queued = []
@@ -50,7 +56,9 @@ def eye(f):
     if len(queued) == batch:
         r.launch_eye_batch(queued, rows); queued.clear()
 def step(f):
-    r.launch("light trace", f + 1 + depth)
+    if lbatch:
+        if f % batch == 0: r.launch_light_batch(f + 1 + batch, batch)
+    else: r.launch("light trace", f + 1 + depth)
     if ex is not None: ex.allgather_lvc()
     if throttle: r.sync_light()
     if comm is not None: comm.exchange_lvc()
@@ -60,7 +68,10 @@ r.sync()
 t0 = time.perf_counter()
 host = {"light": 0.0, "exchange": 0.0, "build": 0.0, "eye": 0.0}
 def timed_step(f):
-    a = time.perf_counter(); r.launch("light trace", f + 1 + depth)
+    a = time.perf_counter()
+    if lbatch:
+        if f % batch == 0: r.launch_light_batch(f + 1 + batch, batch)
+    else: r.launch("light trace", f + 1 + depth)
     b = time.perf_counter()
     if ex is not None: ex.allgather_lvc()
     if throttle: r.sync_light()
@@ -74,7 +85,7 @@ t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
 print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' lbatch' if lbatch else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -24,7 +24,7 @@ struct Job {
     spcbpt_scene_desc desc;
     float eye[3], lookat[3], up[3], fov;
     int W = 640, H = 360, frames = 16, batch = 0, M = 100000;   // batch 0 = 4 for 1-2 ranks, 8 beyond
-    bool train = true;
+    bool train = true, lbatch = false;
 };
 struct Rank {
     spcbpt_ctx* ctx = nullptr;
@@ -67,13 +67,18 @@ static void rank_prime(const Job& J, Rank& R) {           // calibrated capacity
     hipSetDevice(R.device);
     RK(R, spcbpt_comm_calibrate(R.comm, 2, 900000u, 1.5f));
     RK(R, spcbpt_set_light_ahead(R.ctx, 1));
-    for (int k = 0; k < J.batch; k++) RK(R, spcbpt_launch(R.ctx, "light trace", (uint32_t)R.next_light++, 0, 0, 1));
+    if (J.lbatch) { RK(R, spcbpt_launch_light_batch(R.ctx, (uint32_t)R.next_light, J.batch)); R.next_light += J.batch; }
+    else for (int k = 0; k < J.batch; k++) RK(R, spcbpt_launch(R.ctx, "light trace", (uint32_t)R.next_light++, 0, 0, 1));
 }
 // the three phases of a frame; a threaded rank runs them back to back, the local driver runs each phase for every rank in turn
-static void frame_light(const Job&, Rank& R) { hipSetDevice(R.device); RK(R, spcbpt_launch(R.ctx, "light trace", (uint32_t)R.next_light++, 0, 0, 1)); }
-static void frame_exchange(const Job&, Rank& R) {
+static void frame_light(const Job& J, Rank& R, int f) {
     hipSetDevice(R.device);
-    RK(R, spcbpt_sync_light(R.ctx));   // back-pressure only (the pass was launched a batch ago): keeps the host from queueing dozens of frames ahead
+    if (!J.lbatch) RK(R, spcbpt_launch(R.ctx, "light trace", (uint32_t)R.next_light++, 0, 0, 1));
+    else if (f % J.batch == 0) { RK(R, spcbpt_launch_light_batch(R.ctx, (uint32_t)R.next_light, J.batch)); R.next_light += J.batch; }   // a batch's passes as one launch
+}
+static void frame_exchange(const Job& J, Rank& R) {
+    hipSetDevice(R.device);
+    if (!J.lbatch) RK(R, spcbpt_sync_light(R.ctx));   // back-pressure only (the pass was launched a batch ago): keeps the host from queueing dozens of frames ahead
     RK(R, spcbpt_comm_exchange_lvc(R.comm));
 }
 static void frame_render(const Job& J, Rank& R, int f) {
@@ -87,9 +92,9 @@ static void frame_render(const Job& J, Rank& R, int f) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s scene.{scene,gltf,glb} [--data-root DIR] [--gpus N | --local N] [--dim WxH] [--frames F] [--batch B] [--light-paths M] [--out image.ppm] [--no-train]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s scene.{scene,gltf,glb} [--data-root DIR] [--gpus N | --local N] [--dim WxH] [--frames F] [--batch B] [--light-batch 0|1] [--light-paths M] [--out image.ppm] [--no-train]\n", argv[0]); return 2; }
     std::string path = argv[1], root = ".", out = "mgpu.ppm";
-    int gpus = 0, local = 0;
+    int gpus = 0, local = 0, lbatch = -1;   // --light-batch 0|1: spcbpt_launch_light_batch for the passes of a batch (default: beyond 2 ranks)
     Job J;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -100,6 +105,7 @@ int main(int argc, char** argv) {
         else if (a == "--dim") { if (sscanf(next(), "%dx%d", &J.W, &J.H) != 2) { fprintf(stderr, "bad --dim\n"); return 2; } }
         else if (a == "--frames") J.frames = atoi(next());
         else if (a == "--batch") J.batch = std::max(1, std::min(8, atoi(next())));
+        else if (a == "--light-batch") lbatch = atoi(next());
         else if (a == "--light-paths") J.M = atoi(next());
         else if (a == "--out") out = next();
         else if (a == "--no-train") J.train = false;
@@ -116,6 +122,7 @@ int main(int argc, char** argv) {
     hipGetDeviceCount(&ndev);
     const int world = local > 0 ? local : (gpus > 0 ? gpus : std::max(1, ndev));
     if (J.batch == 0) J.batch = world <= 2 ? 4 : 8;
+    J.lbatch = J.batch > 1 && (lbatch < 0 ? world > 2 : lbatch != 0);
     if (!local && world > ndev) { fprintf(stderr, "%d GPUs asked for, %d present\n", world, ndev); return 1; }
     std::vector<Rank> R(world);
     for (int k = 0; k < world; k++) { R[k].id = k; R[k].world = world; R[k].device = local ? 0 : k; }
@@ -147,12 +154,12 @@ int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
     if (local) {
         for (int f = 0; f < J.frames && !failed(); f++) {
-            for (auto& r : R) frame_light(J, r);
+            for (auto& r : R) frame_light(J, r, f);
             for (auto& r : R) frame_exchange(J, r);       // completes when the last rank has posted
             for (auto& r : R) frame_render(J, r, f);
         }
     } else {
-        each([&](Rank& r) { for (int f = 0; f < J.frames && !r.rc; f++) { frame_light(J, r); if (!r.rc) frame_exchange(J, r); if (!r.rc) frame_render(J, r, f); } });
+        each([&](Rank& r) { for (int f = 0; f < J.frames && !r.rc; f++) { frame_light(J, r, f); if (!r.rc) frame_exchange(J, r); if (!r.rc) frame_render(J, r, f); } });
     }
     if (failed()) return 1;
     each([&](Rank& r) { hipSetDevice(r.device); RK(r, spcbpt_comm_gather_film(r.comm, nullptr)); });   // read-out: ends the timed region, as bench.py's does

@@ -16,6 +16,9 @@ rows.sort()
 t0 = rows[0][0]
 for s, e, n, st in rows[-220:]:
     print(f"{(s - t0) / 1e6:10.3f} -> {(e - t0) / 1e6:10.3f}  ({(e - s) / 1e6:7.3f} ms)  {n}  s{st}")
+print("---- eye / light kernels only")
+for s, e, n, st in [r for r in rows if "k_spcbpt" in r[2] or "k_light_trace" in r[2]][-40:]:
+    print(f"{(s - t0) / 1e6:10.3f} -> {(e - t0) / 1e6:10.3f}  ({(e - s) / 1e6:7.3f} ms)  {n}  s{st}")
 PY
 grep "N=" $R/gpurun_out/tl.log
 rm -rf $R/gpurun_out/tl

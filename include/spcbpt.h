@@ -297,8 +297,10 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
  * traversal, [4] connection + film (only ratios are meaningful); [5..8] lane utilisation of the traversal loops of all
  * kernels: node-loop slots (64 x wave iterations) and lanes, triangle-loop slots and lanes; [9] lane-clocks of the two-stage
  * resampling (part of [2], summed over the lanes that sample); [10..13] 100 MHz wall clock of the megakernel's waves: earliest
- * start, latest end, sum of ends, number of waves (how long the last waves run alone). */
-int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[14]);
+ * start, latest end, sum of ends, number of waves (how long the last waves run alone); [14..16] the tail of the pooled traversal
+ * pass, i.e. its node steps after the wave's ray pool ran dry: slots (64 x iterations), lanes still on a closest-hit ray, lanes on
+ * a shadow ray. */
+int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[17]);
 /* Hash of the sources this library was built from (csrc/source_hash.py); the Python mirror refuses a stale library. */
 const char* spcbpt_build_source_hash(void);
 /* Developer probe of the HBM part of the traversal stack.  The per-lane stack holds SPC_STACK_LDS (16) entries in LDS; deeper

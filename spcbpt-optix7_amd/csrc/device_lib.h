@@ -388,8 +388,13 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             }
         }
         if (!__any(node != kTravDone)) break;
+        const bool tail = COUNT && __any(done);   // (counting build) some lane found the pool empty: what follows is the pass's tail
         if (node != kTravDone) {
             bool finished = false, occluded = false;
+            if (COUNT && tail && node >= 0) {
+                cn.add(closest ? C_U_TAIL_CLOSEST : C_U_TAIL_SHADOW);
+                if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cn.add(C_U_TAIL_SLOTS, 64);
+            }
             if (node >= 0) { SPC_NODE_STEP(kEps, best_t); finished = node == kTravDone; }
             if (node < 0 && leaf_count <= 0) {
                 SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test

@@ -25,6 +25,9 @@ cnt = r.counters()
 print("resampling lane-clocks per vertex", ph["sample_lane_clocks"] / max(1, cnt["surface_vertices"]), "shade wave-clocks per wave-vertex (64 lanes)", ph["shade"] / max(1, cnt["surface_vertices"] / 64))
 print("node-loop lane utilisation", round(ph["node_lanes"] / max(1, ph["node_slots"]), 3), "tri-loop", round(ph["tri_lanes"] / max(1, ph["tri_slots"]), 3),
       "wave node iterations", ph["node_slots"] // 64, "wave tri iterations", ph["tri_slots"] // 64)
+print("pooled pass after its pool ran dry: share of the node-step slots", round(ph["tail_slots"] / max(1, ph["node_slots"]), 3),
+      "lanes active there: closest", round(ph["tail_closest_lanes"] / max(1, ph["tail_slots"]), 3), "shadow", round(ph["tail_shadow_lanes"] / max(1, ph["tail_slots"]), 3),
+      "| before the tail: utilisation", round((ph["node_lanes"] - ph["tail_closest_lanes"] - ph["tail_shadow_lanes"]) / max(1, ph["node_slots"] - ph["tail_slots"]), 3))
 
 if ph["waves"]:
     total = (ph["wave_end_max"] - ph["wave_start_min"]) / 100.0   # microseconds

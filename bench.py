@@ -105,7 +105,7 @@ def main():
                          "all drain); 1 = one launch per frame")
     ap.add_argument("--light-batch", type=int, default=-1,
                     help="1: the light passes of a batch of frames as ONE persistent launch too (spcbpt_launch_light_batch), a batch ahead; "
-                         "0: one launch per pass; -1 = 1 beyond 2 GPUs (a rank's 1/N pass is a ~1.2 ms chain whatever N, N of them cost more than one full pass)")
+                         "0: one launch per pass (a pass is a ~1.2 ms dependent chain however few paths a rank traces; a batch of them in one thin, long-lived grid costs the eye kernels beside it less)")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
@@ -208,7 +208,7 @@ def main():
     ahead = not args.no_light_ahead
     depth = args.light_ahead if args.light_ahead > 0 else (batch if batch > 1 else 1)
     state = {"next_light": 1, "primed": False, "lb_left": 0}
-    lbatch = ahead and batch > 1 and (args.light_batch == 1 or (args.light_batch < 0 and world > 2))
+    lbatch = ahead and batch > 1 and args.light_batch != 0
     if ahead:
         r.set_light_ahead(True)
 

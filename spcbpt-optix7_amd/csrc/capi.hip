@@ -294,6 +294,7 @@ int Context::launch_light(uint32_t frame) {
     float* weights = lane ? b_weights : d_weights;
     kp.num_core = lt.num_core; kp.core_padding = lt.core_padding; kp.m_per_core = lt.m_per_core;
     kp.core_begin = lt.core_begin; kp.core_count = lt.core_count; kp.launch_frame = frame;
+    kp.n_lframes = 0;   // one pass (a batched launch that failed half-way must not leave its mode behind)
     kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
     kp.lvc_scratch = scratch; kp.core_counts = core_counts;
     int rc = 0;
@@ -402,8 +403,10 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
     kp.lvc_scratch = lb_scratch; kp.core_counts = lb_core_counts; kp.path_counter = lb_path_counts;
     kp.n_lframes = n;
-    if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
-    const int blocks = light_trace_blocks(kp, light_blocks);
+    // a THIN grid: the batch runs beside the eye kernels of the frames before it, and few long-lived blocks take less from them than
+    // one block per CU that all want a slot at once (bench scene, one GPU: 6.08-6.15 ms per step with 32-64 blocks, 6.29 with 128)
+    if (light_batch_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BATCH_BLOCKS"); light_batch_blocks = lb ? std::max(1, atoi(lb)) : 48; }
+    const int blocks = light_trace_blocks(kp, light_batch_blocks);
     {   // traversal-stack spill area, indexed by blockIdx.x * 256 + threadIdx.x of the grid launched
         const int entries = spill_entries_needed();
         kp.spill_entries = entries;
@@ -431,7 +434,7 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     kp.work_counter = d_work_counter + kMaxRender + 1;   // the second lane's queue head
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
     time_begin("light_trace", ls);
-    launch_light_trace(kp, counting || tree_has_direction, light_blocks, ls);
+    launch_light_trace(kp, counting || tree_has_direction, light_batch_blocks, ls);
     time_end();
     kp.n_lframes = 0;
     HIP_TRY(this, hipGetLastError());

@@ -94,7 +94,7 @@ static void frame_render(const Job& J, Rank& R, int f) {
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s scene.{scene,gltf,glb} [--data-root DIR] [--gpus N | --local N] [--dim WxH] [--frames F] [--batch B] [--light-batch 0|1] [--light-paths M] [--out image.ppm] [--no-train]\n", argv[0]); return 2; }
     std::string path = argv[1], root = ".", out = "mgpu.ppm";
-    int gpus = 0, local = 0, lbatch = -1;   // --light-batch 0|1: spcbpt_launch_light_batch for the passes of a batch (default: beyond 2 ranks)
+    int gpus = 0, local = 0, lbatch = -1;   // --light-batch 0|1: spcbpt_launch_light_batch for the passes of a batch (default: on)
     Job J;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
@@ -122,7 +122,7 @@ int main(int argc, char** argv) {
     hipGetDeviceCount(&ndev);
     const int world = local > 0 ? local : (gpus > 0 ? gpus : std::max(1, ndev));
     if (J.batch == 0) J.batch = world <= 2 ? 4 : 8;
-    J.lbatch = J.batch > 1 && (lbatch < 0 ? world > 2 : lbatch != 0);
+    J.lbatch = J.batch > 1 && lbatch != 0;
     if (!local && world > ndev) { fprintf(stderr, "%d GPUs asked for, %d present\n", world, ndev); return 1; }
     std::vector<Rank> R(world);
     for (int k = 0; k < world; k++) { R[k].id = k; R[k].world = world; R[k].device = local ? 0 : k; }

@@ -180,22 +180,36 @@ def main():
     tup = r.get_subspace() if (rank == 0 or dist is None) else None
     begin, count = pkg.dist.core_range(ncore, rank, world)
     ex = comm = None
+    native_error = None
+    if dist is not None and args.exchange != "python":
+        # the C++ N-GPU host: its own RCCL communicator per rank (the unique id travels over torch.distributed, which otherwise only
+        # provides the barrier and the max-over-ranks of the timing contract)
+        try:
+            r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
+            uid = torch.tensor(list(pkg.dist.unique_id() if rank == 0 else bytes(pkg.dist.UNIQUE_ID_BYTES)), dtype=torch.uint8, device=device)
+            dist.broadcast(uid, 0)
+            comm = pkg.dist.Comm(r, rank, world, bytes(uid.cpu().tolist()))
+            comm.broadcast_subspace(0)             # rank 0 trained; ncclBroadcast of trees, Q, Gamma
+            comm.calibrate(passes=2, slack=1.5)    # shard capacity of exchange 1 from two light passes (host waits: start-up only)
+        except Exception as e:                     # noqa: BLE001 -- reported below, by every rank that saw it
+            native_error = e
+        # every rank must take the same road: if the native host could not be set up anywhere, all fall back to the torch harness
+        flag = torch.tensor([0 if native_error is not None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            print(f"rank {rank}: C++ N-GPU host unavailable ({native_error!r}); falling back to --exchange python", file=sys.stderr)
+            if comm is not None:
+                comm.close()
+            comm = None
+            args.exchange = "python"
+            r.set_light_trace(ncore, pad, mpc)
     if dist is not None and args.exchange == "python":
         tup = pkg.dist.broadcast_subspace(tup, 0, device)
         if rank != 0:
             r.set_subspace(*tup)
         r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
         ex = pkg.dist.FrameExchanger(r, rank, world, device)
-    elif dist is not None:
-        # the C++ N-GPU host: its own RCCL communicator per rank (the unique id travels over torch.distributed, which otherwise only
-        # provides the barrier and the max-over-ranks of the timing contract)
-        r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
-        uid = torch.tensor(list(pkg.dist.unique_id() if rank == 0 else bytes(pkg.dist.UNIQUE_ID_BYTES)), dtype=torch.uint8, device=device)
-        dist.broadcast(uid, 0)
-        comm = pkg.dist.Comm(r, rank, world, bytes(uid.cpu().tolist()))
-        comm.broadcast_subspace(0)             # rank 0 trained; ncclBroadcast of trees, Q, Gamma
-        comm.calibrate(passes=2, slack=1.5)    # shard capacity of exchange 1 from two light passes (host waits: start-up only)
-    else:
+    elif dist is None:
         r.set_light_trace(ncore, pad, mpc, core_begin=begin, core_count=count)
     t_pre = time.perf_counter() - t_pre
     rows = pkg.dist.band_rows(args.height, rank, world)
@@ -208,7 +222,7 @@ def main():
     ahead = not args.no_light_ahead
     depth = args.light_ahead if args.light_ahead > 0 else (batch if batch > 1 else 1)
     state = {"next_light": 1, "primed": False, "lb_left": 0}
-    lbatch = ahead and batch > 1 and args.light_batch != 0
+    lbatch = ahead and batch > 1 and args.light_batch != 0 and ex is None   # (the torch harness keeps its tested one-pass-per-launch loop)
     if ahead:
         r.set_light_ahead(True)
 

@@ -148,7 +148,7 @@ def main():
     # tuple, ms per rank-frame; 1 stream x 8 frames | 1 x 4 | 2 x 4 | 2 x 8): N = 8: 1.06 | 1.17 | 1.42 | 1.41, N = 4: 1.86 | 2.00 |
     # 2.05 | 2.00, N = 2: 3.60 | 3.76 | 3.42 | 3.47, N = 1 (16-step runs): 2 x 4.  A rank's share of a frame is mostly drain phase, so
     # small shares want ONE long tile queue; two persistent kernels side by side only pay when each fills the GPU by itself.
-    batch = args.eye_batch if args.eye_batch > 0 else (4 if world <= 2 else 8)
+    batch = args.eye_batch if args.eye_batch > 0 else (4 if world <= 2 and args.light_geometry != "reference" else 8)   # (the reference's light geometry: a batch of 8 passes is 8 000 lanes)
     streams = args.render_streams if args.render_streams > 0 else (2 if world <= 2 else 1)
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets

@@ -474,7 +474,8 @@ def test_cached_vertex_labels_are_the_labels_the_reference_derives(gpu, pkg, ob)
         r.launch_eye_batch([0])
 
 
-def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkeypatch):
+@pytest.mark.parametrize("lt,shard", [((4000, 52, 1), (700, 1900)), ((60, 400, 50), (0, 60))])   # lane-per-path / the reference's kind: many paths per core
+def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkeypatch, lt, shard):
     """spcbpt_launch_light_batch: n light passes as one persistent launch whose core queue spans the frames.  Every pass must leave
     the cache (vertices in (core, slot) order, vertex and path counts), the sampler tables and finally the image that the n single
     "light trace" launches leave -- bit for bit, for a shard of the cores (core_begin > 0) and a batch that wraps around the ring
@@ -488,7 +489,7 @@ def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkey
     r = pkg.Renderer(scene, 0)
     r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
     r.resize(W, H)
-    r.set_light_trace(4000, 52, 1, core_begin=700, core_count=1900)
+    r.set_light_trace(*lt, core_begin=shard[0], core_count=shard[1])
     r.set_subspace()
     with pytest.raises(pkg.SpcbptError, match="light_ahead"):
         r.launch_light_batch(1, NF)                  # the passes must queue up
@@ -511,7 +512,7 @@ def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkey
         r.launch_eye_batch([NF * rnd + f for f in range(NF)])
     r.sync()
     img = r.read_accum().copy()
-    assert all(w[0] > 1900 and w[1] == 1900 for w in want)
+    assert all(w[0] > w[1] and w[1] == shard[1] * lt[2] for w in want)
     r.clear_accum()
     r.set_light_ahead(True)
     k = 0

@@ -357,7 +357,7 @@ def main():
         if os.path.exists(tfile) and world == 1 and ex is None and comm is None and args.light_geometry == "lane" and args.tuple == "trained":
             try:
                 t = json.load(open(tfile))
-                if int(t.get("frames_per_launch", 1)) == batch and t.get("source_hash") == pkg.api.source_hash():
+                if int(t.get("frames_per_launch", 1)) == batch and t.get("kernel_hash") == pkg.api.kernel_hash():
                     traffic = t.get("spcbpt_render_hbm_bytes_per_launch")
                     traffic_low = t.get("spcbpt_render_hbm_bytes_per_launch_low")
                     valu_issue = t.get("valu_issue_frac")

@@ -103,6 +103,12 @@ def source_hash() -> str:
     return runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "source_hash.py"))["source_hash"]()
 
 
+def kernel_hash() -> str:
+    """csrc/source_hash.py: hash of the eye megakernel's device sources (what profiles/traffic_latest.json is valid for)."""
+    import runpy
+    return runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "source_hash.py"))["kernel_hash"]()
+
+
 def algorithmic_bytes(c: dict, table: Optional[dict] = None) -> int:
     """bytes = sum_e count_e * B_e  (SURVEY.md 8(d))."""
     b = table or BYTES

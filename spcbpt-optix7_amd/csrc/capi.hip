@@ -473,6 +473,7 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
 
 int Context::fetch_counts_of(int set) {
     int h[2] = {0, 0};
+    if (light_counts_valid[set] && light_lane_of_set[set] != 0) HIP_TRY(this, hipEventSynchronize(ev_light[set]));   // traced on the second lane: `stream` does not order it
     HIP_TRY(this, hipMemcpyAsync(h, set_counts[set], sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_TRY(this, hipStreamSynchronize(stream));
     lvc_count = h[0];

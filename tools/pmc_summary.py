@@ -56,7 +56,7 @@ if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[k
         # (SQ_BUSY_CYCLES is summed over the 32 shader engines: x 32 SIMDs per engine)
         valu = d["SQ_INSTS_VALU"]["avg_per_launch"] * 4.0 / (d["SQ_BUSY_CYCLES"]["avg_per_launch"] * 32.0)
     json.dump({"tag": tag, "kernel": key, "frames_per_launch": frames_per_launch, "spcbpt_render_hbm_bytes_per_launch": 2 * f + w,
-               "spcbpt_render_hbm_bytes_per_launch_low": f + w, "source_hash": g.load_package().api.source_hash(), "valu_issue_frac": valu,
+               "spcbpt_render_hbm_bytes_per_launch_low": f + w, "source_hash": g.load_package().api.source_hash(), "kernel_hash": g.load_package().api.kernel_hash(), "valu_issue_frac": valu,
                "definition": "2*FETCH_SIZE + WRITE_SIZE (KB*1024) per k_spcbpt<false> launch, gfx950 FETCH_SIZE half-count correction applied; "
                              "uncorrected lower bound = FETCH_SIZE + WRITE_SIZE = %.4g" % (f + w)},
               open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)

@@ -77,7 +77,7 @@ def cpu_baseline(pkg, scene, args, tup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="bedroom")
     ap.add_argument("--tris", type=int, default=1_000_000)
@@ -93,14 +93,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
     ap.add_argument("--render-streams", type=int, default=0,
-                    help="render streams per GPU, each with one (batched) eye launch in flight (0 = 2 for 1-2 GPUs, 1 beyond)")
+                    help="render streams per GPU, each with one (batched) eye launch in flight (0 = 1)")
     ap.add_argument("--light-geometry", default="lane", choices=["lane", "reference"],
                     help="lane (default): one light path per core, M cores of 52 slots, BSDF stream decorrelated (DESIGN.md d1); "
                          "reference: the reference's launch geometry lt_params_setup (optixPathTracer.cpp:462-477): 1000 cores x 100 paths, "
                          "800 slots per core, both random streams of a core start equal (q4)")
     ap.add_argument("--write-image", default="")
     ap.add_argument("--eye-batch", type=int, default=0,
-                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 4 for 1-2 GPUs, 8 beyond: several frames in one tile queue pay the "
+                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 16: several frames in one tile queue pay the "
                          "drain phase of the persistent kernel once (and a rank's share of a sharded frame is about one tile per resident wave: "
                          "all drain); 1 = one launch per frame")
     ap.add_argument("--light-batch", type=int, default=-1,
@@ -144,12 +144,13 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
 
-    # Frames per eye launch and render streams by rank count, measured with tools/rank_sim.py (a rank's share on one GPU, trained
-    # tuple, ms per rank-frame; 1 stream x 8 frames | 1 x 4 | 2 x 4 | 2 x 8): N = 8: 1.06 | 1.17 | 1.42 | 1.41, N = 4: 1.86 | 2.00 |
-    # 2.05 | 2.00, N = 2: 3.60 | 3.76 | 3.42 | 3.47, N = 1 (16-step runs): 2 x 4.  A rank's share of a frame is mostly drain phase, so
-    # small shares want ONE long tile queue; two persistent kernels side by side only pay when each fills the GPU by itself.
-    batch = args.eye_batch if args.eye_batch > 0 else (4 if world <= 2 and args.light_geometry != "reference" else 8)   # (the reference's light geometry: a batch of 8 passes is 8 000 lanes)
-    streams = args.render_streams if args.render_streams > 0 else (2 if world <= 2 else 1)
+    # One render stream, 16 frames per persistent eye launch (and per light launch): the kernel-end drain -- the last paths of a
+    # launch, up to 50 bounces with ever fewer live lanes -- is paid once per launch, and with the light passes in a thin grid of
+    # their own nothing else needs the second stream any more.  Measured on one GPU at the driver's 20 steps / in a 64-step run, ms
+    # per step: 2 streams x 4 frames 6.19 / 6.05, 1 x 8 6.00 / 6.01, 1 x 16 6.02 / 5.86 (kernel 5.98 -> 5.76 -> 5.62 ms per frame);
+    # a rank's share of a sharded frame gains more (N = 8 simulation: 0.94 -> 0.85 ms per rank-frame from 8 to 16 frames).
+    batch = args.eye_batch if args.eye_batch > 0 else 16
+    streams = args.render_streams if args.render_streams > 0 else 1
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets
     scene = make_scene(pkg, args.scene, args.tris)
@@ -221,23 +222,24 @@ def main():
     # and one eye pass; the light pass a step launches is consumed by the next step.
     ahead = not args.no_light_ahead
     depth = args.light_ahead if args.light_ahead > 0 else (batch if batch > 1 else 1)
-    state = {"next_light": 1, "primed": False, "lb_left": 0}
+    state = {"next_light": 1, "primed": False, "lb_left": 0, "phase_left": 0}
     lbatch = ahead and batch > 1 and args.light_batch != 0 and ex is None   # (the torch harness keeps its tested one-pass-per-launch loop)
     if ahead:
         r.set_light_ahead(True)
 
-    def light_batch():
-        r.launch_light_batch(state["next_light"], batch); state["next_light"] += batch
+    def light_batch(n):
+        r.launch_light_batch(state["next_light"], n); state["next_light"] += n
 
     def step(f, isolate=False):
         if not ahead:
             r.launch("light trace", f + 1)
         elif lbatch:                           # every `batch` steps: the passes of the batch after the one being built, as one launch
-            if state["lb_left"] == 0:
-                if not state["primed"]:
-                    light_batch(); state["primed"] = True
-                light_batch(); state["lb_left"] = batch
-            state["lb_left"] -= 1
+            if not state["primed"]:
+                light_batch(batch); state["primed"] = True    # the stock every phase draws from and refills: one batch
+            if state["lb_left"] == 0:                          # a phase of P steps launches exactly P passes (and consumes P of the stock)
+                n = max(1, min(batch, state["phase_left"]))
+                light_batch(n); state["lb_left"] = n
+            state["lb_left"] -= 1; state["phase_left"] -= 1
         else:
             if not state["primed"]:
                 for _ in range(depth):
@@ -277,6 +279,7 @@ def main():
         torch.cuda.synchronize()
 
     r.clear_accum()
+    state["phase_left"] = args.warmup
     for f in range(args.warmup):
         step(f)
     flush()
@@ -306,7 +309,9 @@ def main():
     # frame's kernel shares the GPU with it; HIP events on the kernel's own stream (spcbpt_kernel_time)
     r.enable_kernel_timing(True)
     r.reset_kernel_time()
-    for f in range(min(8, max(2, args.steps))):
+    n_iso = 8 if batch == 1 else 2 * batch   # whole launches only: every timed launch holds `batch` frames
+    state["phase_left"] = n_iso
+    for f in range(n_iso):
         step(1000 + f, isolate=True)
         if batch == 1 or not queued:      # batched: a sync after each launch = after every `batch` steps
             r.sync()
@@ -323,6 +328,7 @@ def main():
     r.reset_kernel_time()
     barrier()
     t0 = time.perf_counter()
+    state["phase_left"] = args.steps
     for f in range(args.steps):
         step(f)
     flush()

@@ -110,7 +110,7 @@ struct FrameDesc {  // 64 B
     uint32_t subframe;
     uint32_t pad[3];
 };
-static const int kMaxBatchFrames = 8;   // fid travels in 4 bits next to the pixel coordinates
+static const int kMaxBatchFrames = 16;  // fid travels in 4 bits next to the pixel coordinates
 static_assert(kMaxBatchFrames <= 16, "the frame id of a batched launch is packed into 4 bits (kernels.hip: published eye vertex)");
 
 

@@ -531,4 +531,4 @@ def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkey
     r.sync()
     assert np.array_equal(r.read_accum(), img)
     with pytest.raises(pkg.SpcbptError):
-        r.launch_light_batch(1, 9)
+        r.launch_light_batch(1, 17)

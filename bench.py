@@ -149,7 +149,7 @@ def main():
     # their own nothing else needs the second stream any more.  Measured on one GPU at the driver's 20 steps / in a 64-step run, ms
     # per step: 2 streams x 4 frames 6.19 / 6.05, 1 x 8 6.00 / 6.01, 1 x 16 6.02 / 5.86 (kernel 5.98 -> 5.76 -> 5.62 ms per frame);
     # a rank's share of a sharded frame gains more (N = 8 simulation: 0.94 -> 0.85 ms per rank-frame from 8 to 16 frames).
-    batch = args.eye_batch if args.eye_batch > 0 else 16
+    batch = args.eye_batch if args.eye_batch > 0 else (8 if args.light_geometry == "reference" and world == 1 else 16)   # (reference geometry: a batch is a 19 ms chain whatever its size; 8 frames keep two of them inside a 20-step run: 5.96 against 6.84 ms per step)
     streams = args.render_streams if args.render_streams > 0 else 1
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets

@@ -406,7 +406,10 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     // a THIN grid: the batch runs beside the eye kernels of the frames before it, and few long-lived blocks take less from them than
     // one block per CU that all want a slot at once (bench scene, one GPU: 6.08-6.15 ms per step with 32-64 blocks, 6.29 with 128)
     if (light_batch_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BATCH_BLOCKS"); light_batch_blocks = lb ? std::max(1, atoi(lb)) : 48; }
-    const int blocks = light_trace_blocks(kp, light_batch_blocks);
+    // (cores that trace many paths one after the other -- the reference's geometry -- are long jobs: never two of them per lane)
+    int grid_cap = light_batch_blocks;
+    if (lt.m_per_core >= 8) grid_cap = std::max(grid_cap, (int)(((long long)n * lt.core_count + 255) / 256));
+    const int blocks = light_trace_blocks(kp, grid_cap);
     {   // traversal-stack spill area, indexed by blockIdx.x * 256 + threadIdx.x of the grid launched
         const int entries = spill_entries_needed();
         kp.spill_entries = entries;
@@ -434,7 +437,7 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     kp.work_counter = d_work_counter + kMaxRender + 1;   // the second lane's queue head
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
     time_begin("light_trace", ls);
-    launch_light_trace(kp, counting || tree_has_direction, light_batch_blocks, ls);
+    launch_light_trace(kp, counting || tree_has_direction, grid_cap, ls);
     time_end();
     kp.n_lframes = 0;
     HIP_TRY(this, hipGetLastError());

@@ -149,7 +149,12 @@ def main():
     # their own nothing else needs the second stream any more.  Measured on one GPU at the driver's 20 steps / in a 64-step run, ms
     # per step: 2 streams x 4 frames 6.19 / 6.05, 1 x 8 6.00 / 6.01, 1 x 16 6.02 / 5.86 (kernel 5.98 -> 5.76 -> 5.62 ms per frame);
     # a rank's share of a sharded frame gains more (N = 8 simulation: 0.94 -> 0.85 ms per rank-frame from 8 to 16 frames).
-    batch = args.eye_batch if args.eye_batch > 0 else (8 if args.light_geometry == "reference" and world == 1 else 16)   # (reference geometry: a batch is a 19 ms chain whatever its size; 8 frames keep two of them inside a 20-step run: 5.96 against 6.84 ms per step)
+    # The run's launches are kept equal: 20 steps are two launches of 10, not 16 + 4 (5.93-6.01 against 6.00-6.04 ms per step: the
+    # short last launch pays a whole drain for 4 frames).  (Reference geometry: a light batch is a 19 ms chain whatever its size;
+    # at most 8 frames per batch keep two of them inside a 20-step run: 5.96 against 6.84 ms per step.)
+    max_batch = 8 if args.light_geometry == "reference" and world == 1 else 16
+    launches = max(1, -(-args.steps // max_batch))
+    batch = args.eye_batch if args.eye_batch > 0 else max(1, min(max_batch, -(-args.steps // launches)))
     streams = args.render_streams if args.render_streams > 0 else 1
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets
@@ -363,11 +368,14 @@ def main():
         if os.path.exists(tfile) and world == 1 and ex is None and comm is None and args.light_geometry == "lane" and args.tuple == "trained":
             try:
                 t = json.load(open(tfile))
-                if int(t.get("frames_per_launch", 1)) == batch and t.get("kernel_hash") == pkg.api.kernel_hash():
-                    traffic = t.get("spcbpt_render_hbm_bytes_per_launch")
-                    traffic_low = t.get("spcbpt_render_hbm_bytes_per_launch_low")
+                if t.get("kernel_hash") == pkg.api.kernel_hash():
+                    # measured per launch of `frames_per_launch` frames; the bytes go with the frames (r02d: 56.6 GB per 4, r02e: 224.4 GB per 16)
+                    per = batch / float(int(t.get("frames_per_launch", 1)))
+                    traffic = t.get("spcbpt_render_hbm_bytes_per_launch") * per
+                    traffic_low = t.get("spcbpt_render_hbm_bytes_per_launch_low") * per
                     valu_issue = t.get("valu_issue_frac")
-                    traffic_note = "rocprofv3 PMC passes of this code (" + str(t.get("tag")) + "): traffic = 2*FETCH_SIZE + WRITE_SIZE (upper bracket, gfx950 half-count correction for 128-B requests), traffic_low = FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are included in both"
+                    traffic_note = ("rocprofv3 PMC passes of this kernel code (" + str(t.get("tag")) + f", {t.get('frames_per_launch')} frames per launch, scaled to the {batch} of this run): "
+                                    "traffic = 2*FETCH_SIZE + WRITE_SIZE (upper bracket, gfx950 half-count correction for 128-B requests), traffic_low = FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are included in both")
             except Exception:
                 pass
         achieved_actual = bytes_actual_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0

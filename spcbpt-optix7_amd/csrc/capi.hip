@@ -507,6 +507,16 @@ int Context::build_sampler() {
     if (rc) { select_set(lset); return rc; }
     const int n = lvc_count;
     time_begin("sampler_build");
+    if (counting_build) {
+        // one stable counting sort over the 10-bit subspace ids: four launches (kernels.hip).  The path count is taken on the way
+        // unless the light pass (or the gathered import) has left it in the set already.
+        if (!d_hist) HIP_TRY(this, dev_alloc(&d_hist, sampler_build_hist_ints()));
+        const bool count_paths = !dev_count && !(keys_ready && keys_set == bset);
+        if (count_paths) HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
+        launch_sampler_build(d_lvc, n, dev_count ? d_sampler_counts : nullptr, d_keys, d_weights, d_hist, count_paths ? d_sampler_counts + 1 : nullptr,
+                             d_subspace, d_vals2, d_wsorted, d_cmfs, stream);
+        keys_ready = false;
+    } else {
     if (dev_count) {
         launch_fill_keys_devcount(d_lvc, n, d_keys, d_vals, d_weights, d_sampler_counts, stream);
     } else if (!(keys_ready && keys_set == bset)) {
@@ -526,6 +536,7 @@ int Context::build_sampler() {
         launch_gather_weights(d_weights, d_vals2, d_sampler_counts, d_wsorted, n, stream);
         HIP_TRY(this, hipcub::DeviceScan::InclusiveSum(d_temp, tb2, d_wsorted, d_prefix, n, stream));
         launch_cmf(d_prefix, d_keys2, d_sampler_counts, d_subspace, d_cmfs, n, stream);
+    }
     }
     time_end();
     HIP_TRY(this, hipGetLastError());
@@ -860,7 +871,7 @@ Context::~Context() {
     for (int g2 = 0; g2 < 2; g2++) if (ev_import[g2]) (void)hipEventDestroy(ev_import[g2]);
     for (int s2 = 0; s2 < kMaxRender; s2++) for (int g2 = 0; g2 < kDescRing; g2++) if (ev_desc[s2][g2]) (void)hipEventDestroy(ev_desc[s2][g2]);
     dev_free(b_scratch); dev_free(b_core_counts); dev_free(b_core_offsets); dev_free(b_keys); dev_free(b_vals); dev_free(b_weights); dev_free(b_temp); dev_free(b_spill);
-    if (lstream_b) (void)hipStreamDestroy(lstream_b); dev_free(d_spill); dev_free(d_temp);
+    if (lstream_b) (void)hipStreamDestroy(lstream_b); dev_free(d_spill); dev_free(d_temp); dev_free(d_hist);
     for (int s = 0; s < kMaxRender; s++) {
         if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
@@ -934,6 +945,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         if (const char* eb = getenv("SPCBPT_EYE_BATCH")) c->eye_batch = std::max(1, std::min((int)kMaxBatchFrames, atoi(eb)));
         // sets: one per frame of every eye launch in flight + the light passes ahead of them + the one being built
         c->n_sets = std::min((int)Context::kMaxSets, c->eye_batch > 1 ? c->eye_batch * (c->n_render + 2) + 3 : c->n_render + 4);   // batches in flight + one being built + a batch of light passes ahead
+        if (const char* sb = getenv("SPCBPT_SAMPLER_BUILD")) c->counting_build = std::string(sb) != "hipcub";
         if (const char* ns = getenv("SPCBPT_SETS")) c->n_sets = std::max(3, std::min((int)Context::kMaxSets, atoi(ns)));   // developer knob
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;

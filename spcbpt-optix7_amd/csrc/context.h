@@ -145,6 +145,8 @@ struct Context {
     float* d_cmfs = nullptr;
     DSubspace* d_subspace = nullptr;
     int* d_sampler_counts = nullptr;  // [0] vertex_count, [1] path_count
+    int* d_hist = nullptr;            // per-block histograms / offsets of the four-launch sampler build (kernels.hip)
+    bool counting_build = true;       // SPCBPT_SAMPLER_BUILD=hipcub selects the radix-sort form (same tables)
     int lvc_count = 0, path_count = 0;
     bool keys_ready = false, have_sampler = false;
     // scratch

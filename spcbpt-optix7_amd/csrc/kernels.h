@@ -25,6 +25,10 @@ void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys
 void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, LightVertex* lvc,
                            int* sampler_counts, int* overflow, hipStream_t s);
 void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s);
+// the sampler build as one stable counting sort (four launches): kernels.hip "sampler build in four launches"
+size_t sampler_build_hist_ints();
+void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
+                          uint32_t* jump, double* wsorted, float* cmfs, hipStream_t s);
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s);
 void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s);
 void launch_cmf(const double* prefix, const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, float* cmfs, int capacity, hipStream_t s);

@@ -879,6 +879,149 @@ __global__ void k_cmf(const double* __restrict__ prefix, const uint32_t* __restr
     cmfs[i] = c;
 }
 
+// ---- sampler build in four launches ------------------------------------------------------------------------------------------
+// The build above is ~14 dependent launches (hipcub's radix sort and scan are five and two of them): 0.3 ms of launch latency
+// however few vertices it sorts, and a batched eye launch waits for up to 16 of them.  Subspace ids are 10-bit keys, so one stable
+// counting sort does: SB_BLOCKS single-wave blocks each own a contiguous chunk of the cache,
+//   k_sb_hist     per-block histogram of the ids (LDS), keys + weights (+ the path count) on the way
+//   k_sb_scan     one block: per-id running offsets over the blocks, exclusive scan over the ids -> jump_bias / size
+//   k_sb_scatter  each block places its chunk in order (rank among equal ids inside a wave from ten ballots) -> jump buffer,
+//                 weights in sorted order
+//   k_sb_cmf      one block per subspace: double-precision scan of its weights -> CMF, sum_pmf
+// Same tables as the sort: the order inside a subspace is the cache order (stable), empty subspaces carry the running offset.
+// The CMF sums a subspace's weights by themselves (the scan above takes differences of a global prefix): equal to 1e-16 relative.
+static constexpr int SB_BLOCKS = 512;
+__global__ __launch_bounds__(64) void k_sb_hist(const LightVertex* __restrict__ lvc, int n_host, const int* __restrict__ n_dev, uint32_t* __restrict__ keys,
+                                                float* __restrict__ weights, int* __restrict__ hist, int* __restrict__ path_count) {
+    __shared__ uint32_t h[1024];
+    const int lane = threadIdx.x, b = blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < 16; t++) h[t * 64 + lane] = 0u;
+    __syncthreads();
+    const int n = n_dev ? n_dev[0] : n_host;
+    const int chunk = (n + SB_BLOCKS - 1) / SB_BLOCKS, i0 = b * chunk, i1 = min(n, i0 + chunk);
+    int starts = 0;
+    for (int i = i0 + lane; i < i1; i += 64) {
+        const LightVertex& v = lvc[i];
+        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;   // LVCSubspaceInfoCopy device_thrust.cu:191-212
+        if (isinf(w) || isnan(w)) w = 0.0f;
+        const uint32_t k = (uint32_t)v.subspace_id & 1023u;
+        keys[i] = k;
+        weights[i] = w;
+        atomicAdd(&h[k], 1u);
+        starts += v.depth == 0 ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) hist[(size_t)b * 1024 + t * 64 + lane] = (int)h[t * 64 + lane];
+    if (path_count) {
+        for (int o = 32; o > 0; o >>= 1) starts += __shfl_down(starts, o, 64);
+        if (lane == 0 && starts) atomicAdd(path_count, starts);
+    }
+}
+__global__ __launch_bounds__(1024) void k_sb_scan(int* __restrict__ hist, DSubspace* __restrict__ sub) {
+    // thread = subspace id.  hist[b][id] becomes the number of items with that id in the blocks before b; row SB_BLOCKS receives the
+    // position of the id's first item = items with smaller ids: for an empty subspace the end of the last non-empty one before it,
+    // the running offset of the reference's host loop (device_thrust.cu:301-309)
+    __shared__ int tot[1024];
+    const int k = threadIdx.x;
+    int run = 0;
+#pragma unroll 8
+    for (int b = 0; b < SB_BLOCKS; b++) {
+        const int c = hist[(size_t)b * 1024 + k];
+        hist[(size_t)b * 1024 + k] = run;
+        run += c;
+    }
+    tot[k] = run;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = k >= off ? tot[k - off] : 0;
+        __syncthreads();
+        tot[k] += v;
+        __syncthreads();
+    }
+    const int base = tot[k] - run;   // exclusive
+    hist[(size_t)SB_BLOCKS * 1024 + k] = base;
+    if (k < SPCBPT_NUM_SUBSPACE) { sub[k].jump_bias = base; sub[k].size = run; sub[k].sum_pmf = 0.0f; sub[k].pad = 0; }
+}
+__global__ __launch_bounds__(64) void k_sb_scatter(const uint32_t* __restrict__ keys, const float* __restrict__ weights, int n_host, const int* __restrict__ n_dev,
+                                                   const int* __restrict__ hist, uint32_t* __restrict__ jump, double* __restrict__ wsorted) {
+    __shared__ uint32_t next[1024];   // where this block's next item of each id goes
+    const int lane = threadIdx.x, b = blockIdx.x;
+#pragma unroll
+    for (int t = 0; t < 16; t++) next[t * 64 + lane] = (uint32_t)(hist[(size_t)SB_BLOCKS * 1024 + t * 64 + lane] + hist[(size_t)b * 1024 + t * 64 + lane]);
+    __syncthreads();
+    const int n = n_dev ? n_dev[0] : n_host;
+    const int chunk = (n + SB_BLOCKS - 1) / SB_BLOCKS, i0 = b * chunk, i1 = min(n, i0 + chunk);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int base = i0; base < i1; base += 64) {   // wave-uniform bounds: every lane takes part in the ballots
+        const int i = base + lane;
+        const bool valid = i < i1;
+        const uint32_t k = valid ? keys[i] : 0u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 10; bit++) {
+            const unsigned long long m = __ballot((k >> bit) & 1u);
+            peers &= ((k >> bit) & 1u) ? m : ~m;
+        }
+        uint32_t pos = 0u;
+        if (valid) pos = next[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt) == 0ull) next[k] = pos + (uint32_t)__popcll(peers);   // the first lane of each id moves the cursor on
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t dst = pos + (uint32_t)__popcll(peers & lt);
+            jump[dst] = (uint32_t)i;
+            wsorted[dst] = (double)weights[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_sb_cmf(DSubspace* __restrict__ sub, const double* __restrict__ wsorted, float* __restrict__ cmfs) {
+    __shared__ double sh[256];
+    const int k = blockIdx.x, t = threadIdx.x;
+    const int b = sub[k].jump_bias, sz = sub[k].size;
+    if (sz <= 0) return;
+    double acc = 0.0;
+    for (int j = t; j < sz; j += 256) acc += wsorted[b + j];
+    sh[t] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] += sh[t + off]; __syncthreads(); }
+    const double total = sh[0];
+    __syncthreads();
+    double carry = 0.0;
+    for (int j0 = 0; j0 < sz; j0 += 256) {
+        const int j = j0 + t;
+        const double w = j < sz ? wsorted[b + j] : 0.0;
+        sh[t] = w;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const double v = t >= off ? sh[t - off] : 0.0;
+            __syncthreads();
+            sh[t] += v;
+            __syncthreads();
+        }
+        if (j < sz) {
+            // sum_pmf == 0 gives NaN CMFs in the reference; guarded here: zero-weight subspaces sample uniformly
+            float c = total > 0.0 ? (float)((carry + sh[t]) / total) : (float)(j + 1) / (float)sz;
+            if (j == sz - 1) c = 1.0f;
+            cmfs[b + j] = c;
+        }
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (t == 0) sub[k].sum_pmf = (float)total;
+}
+size_t sampler_build_hist_ints() { return (size_t)(SB_BLOCKS + 1) * 1024; }
+void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
+                          uint32_t* jump, double* wsorted, float* cmfs, hipStream_t s) {
+    hipLaunchKernelGGL(k_sb_hist, dim3(SB_BLOCKS), dim3(64), 0, s, lvc, n_host, n_dev, keys, weights, hist, path_count);
+    hipLaunchKernelGGL(k_sb_scan, dim3(1), dim3(1024), 0, s, hist, sub);
+    hipLaunchKernelGGL(k_sb_scatter, dim3(SB_BLOCKS), dim3(64), 0, s, keys, weights, n_host, n_dev, hist, jump, wsorted);
+    hipLaunchKernelGGL(k_sb_cmf, dim3(SPCBPT_NUM_SUBSPACE), dim3(256), 0, s, sub, wsorted, cmfs);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Standalone traversal kernels (parity of the software LBVH against the oracle's BVH)
 __global__ __launch_bounds__(BLOCK) void k_trace_closest(const KParams p, const float* __restrict__ rays, int n, float* __restrict__ out_t,

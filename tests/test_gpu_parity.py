@@ -532,3 +532,38 @@ def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkey
     assert np.array_equal(r.read_accum(), img)
     with pytest.raises(pkg.SpcbptError):
         r.launch_light_batch(1, 17)
+
+
+def test_counting_sampler_build_gives_the_tables_of_the_radix_sort(gpu, pkg, monkeypatch):
+    """The four-launch sampler build (one stable counting sort over the subspace ids) against the hipcub form it replaces, on a
+    bedroom-class cache with hundreds of occupied subspaces: jump buffer, ranges and counts identical, CMFs to double rounding."""
+    scene = pkg.scenes.bedroom(target_tris=40000)
+    cam = scene.camera
+    out = {}
+    tup = None
+    for form in ("hipcub", "counting"):
+        monkeypatch.setenv("SPCBPT_SAMPLER_BUILD", form)
+        r = pkg.Renderer(scene, 0)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 4 / 3)
+        r.resize(64, 48)
+        r.set_light_trace(20000, 52, 1)
+        if tup is None:
+            r.preprocess(200_000, 200_000, False)      # many-leaf trees, initial Gamma
+            tup = r.get_subspace()
+        else:
+            r.set_subspace(*tup)
+        r.launch("light trace", 5); r.build_sampler()
+        out[form] = r.sampler_read()
+        # and through the path that refills the keys (an imported cache)
+        lvc = r.lvc_read()
+        r.lvc_import(lvc); r.build_sampler()
+        again = r.sampler_read()
+        assert np.array_equal(again[2], out[form][2]) and np.array_equal(again[0], out[form][0]) and again[3:] == out[form][3:]
+    a, b = out["hipcub"], out["counting"]
+    assert a[3:] == b[3:] and a[3] > 40000
+    assert (a[0]["size"] > 0).sum() > 100
+    np.testing.assert_array_equal(a[0]["size"], b[0]["size"])
+    np.testing.assert_array_equal(a[0]["jump_bias"], b[0]["jump_bias"])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1.5e-7)
+    np.testing.assert_allclose(a[0]["sum_pmf"], b[0]["sum_pmf"], rtol=1e-6)

@@ -100,7 +100,7 @@ def main():
                          "800 slots per core, both random streams of a core start equal (q4)")
     ap.add_argument("--write-image", default="")
     ap.add_argument("--eye-batch", type=int, default=0,
-                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = 16: several frames in one tile queue pay the "
+                    help="frames per eye launch (spcbpt_launch_eye_batch); 0 = up to 32, equal launches: several frames in one tile queue pay the "
                          "drain phase of the persistent kernel once (and a rank's share of a sharded frame is about one tile per resident wave: "
                          "all drain); 1 = one launch per frame")
     ap.add_argument("--light-batch", type=int, default=-1,
@@ -149,10 +149,9 @@ def main():
     # their own nothing else needs the second stream any more.  Measured on one GPU at the driver's 20 steps / in a 64-step run, ms
     # per step: 2 streams x 4 frames 6.19 / 6.05, 1 x 8 6.00 / 6.01, 1 x 16 6.02 / 5.86 (kernel 5.98 -> 5.76 -> 5.62 ms per frame);
     # a rank's share of a sharded frame gains more (N = 8 simulation: 0.94 -> 0.85 ms per rank-frame from 8 to 16 frames).
-    # The run's launches are kept equal: 20 steps are two launches of 10, not 16 + 4 (5.93-6.01 against 6.00-6.04 ms per step: the
-    # short last launch pays a whole drain for 4 frames).  (Reference geometry: a light batch is a 19 ms chain whatever its size;
-    # at most 8 frames per batch keep two of them inside a 20-step run: 5.96 against 6.84 ms per step.)
-    max_batch = 8 if args.light_geometry == "reference" and world == 1 else 16
+    # Up to 32 frames per launch, and a run's launches are kept equal (40 steps = 2 x 20, not 32 + 8: a short last launch pays a whole
+    # drain for a few frames).  Per frame the kernel takes 5.98 ms in launches of 4 frames, 5.76 of 8, 5.63 of 16, 5.59 of 20-32.
+    max_batch = 32
     launches = max(1, -(-args.steps // max_batch))
     batch = args.eye_batch if args.eye_batch > 0 else max(1, min(max_batch, -(-args.steps // launches)))
     streams = args.render_streams if args.render_streams > 0 else 1

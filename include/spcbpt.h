@@ -359,7 +359,7 @@ int spcbpt_sync_light(spcbpt_ctx* ctx);
  * frame each, oldest first, subframe index subframes[k] -- with ONE persistent kernel whose tile queue spans the frames, and
  * merges them into the film in that order.  The result is that of n_frames spcbpt_launch("SPCBPT_eye") calls; the point is the
  * drain phase of the megakernel, which is paid once per launch: a rank's eighth of a sharded frame is about one 8x8 tile per
- * resident wave, i.e. nothing but drain.  n_frames <= 16 and <= the number of samplers built since and still intact
+ * resident wave, i.e. nothing but drain.  n_frames <= 32 and <= the number of samplers built since and still intact
  * (SPCBPT_ERR_STATE otherwise).  SPCBPT_EYE_BATCH = F in the environment at spcbpt_create sizes the ring of sampler buffer
  * sets for batches of F, so that batches in flight, light passes ahead and builds never wait for a set. */
 int spcbpt_launch_eye_batch(spcbpt_ctx* ctx, int n_frames, const uint32_t* subframes, int row_begin, int row_end, int row_step);
@@ -369,7 +369,7 @@ int spcbpt_launch_eye_batch(spcbpt_ctx* ctx, int n_frames, const uint32_t* subfr
  * are bit-identical to those -- so the host goes on with n_frames x (export / import, spcbpt_build_sampler) and one
  * spcbpt_launch_eye_batch.  The point is again the dependent chain: a rank of an 8-GPU job traces 1/8 of the cores per frame, each
  * pass still takes the ~1.2 ms of its longest path, and beside the eye grid they run one after the other; in one queue they cost
- * about one full-size pass.  n_frames <= 16 (SPCBPT_ERR_INVALID_ARG), SPCBPT_ERR_STATE without light-ahead mode. */
+ * about one full-size pass.  n_frames <= 32 (SPCBPT_ERR_INVALID_ARG), SPCBPT_ERR_STATE without light-ahead mode. */
 int spcbpt_launch_light_batch(spcbpt_ctx* ctx, uint32_t first_frame, int n_frames);
 
 /* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain

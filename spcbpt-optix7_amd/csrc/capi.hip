@@ -376,7 +376,7 @@ int Context::launch_light(uint32_t frame) {
 // (same seeds per core, same (core, slot) order after compaction).
 int Context::launch_light_batch(uint32_t first_frame, int n) {
     if (!have_subspace) { error = "light trace needs a subspace tuple (spcbpt_set_subspace)"; return SPCBPT_ERR_STATE; }
-    if (n < 1 || n > kMaxBatchFrames || n > n_sets - 2) { error = "launch_light_batch: 1 .. min(16, sets - 2) frames per batch"; return SPCBPT_ERR_INVALID_ARG; }
+    if (n < 1 || n > kMaxBatchFrames || n > n_sets - 2) { error = "launch_light_batch: 1 .. min(32, sets - 2) frames per batch"; return SPCBPT_ERR_INVALID_ARG; }
     if (!light_ahead) { error = "launch_light_batch: the passes queue up for build_sampler -- enable spcbpt_set_light_ahead first"; return SPCBPT_ERR_STATE; }
     if (!d_scratch) {
         spcbpt_light_trace_params d = {100000, 52, 1, 0, 0, 1};
@@ -683,7 +683,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     if (!d_accum) { error = "render before spcbpt_resize"; return SPCBPT_ERR_STATE; }
     if (!have_camera) { error = "render before spcbpt_set_camera"; return SPCBPT_ERR_STATE; }
     if (!have_subspace) { error = "SPCBPT_eye needs a subspace tuple and a built sampler"; return SPCBPT_ERR_STATE; }
-    if (n < 1 || n > kMaxBatchFrames || !subframes) { error = "launch_eye_batch: 1..16 frames"; return SPCBPT_ERR_INVALID_ARG; }
+    if (n < 1 || n > kMaxBatchFrames || !subframes) { error = "launch_eye_batch: 1..32 frames"; return SPCBPT_ERR_INVALID_ARG; }
     if (n > (int)built_sets.size()) { error = "launch_eye_batch: fewer samplers have been built (and are still intact) than frames were asked for"; return SPCBPT_ERR_STATE; }
     // (SPCBPT_EYE_BATCH at spcbpt_create only sizes the ring of buffer sets so that batches, light passes ahead and builds do not
     // wait for each other; correctness rests on the per-set events and on `built_sets` naming intact samplers)

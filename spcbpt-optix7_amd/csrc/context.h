@@ -35,7 +35,7 @@ struct Context {
     // tone map from `result` into accum/frame) are chained, by ev_merge, so the image is the same as with one stream.
     // n_render streams are in use (default 2; SPCBPT_RENDER_STREAMS=1..8).  More frames in flight pay when one frame does not
     // fill the GPU -- a rank of an 8-GPU job renders 1/8 of the image but its frame still ends with the same 50-bounce chain.
-    static const int kMaxRender = 8, kMaxSets = 64;
+    static const int kMaxRender = 8, kMaxSets = 128;
     int n_render = 2, n_sets = 6;   // n_sets = n_render + 4: one set per eye kernel in flight + the light passes ahead of them
     hipStream_t rstreams[kMaxRender] = {};
     int rk = 0, last_merge_k = -1;

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     col[9 * BLOCK] = __float_as_uint(cur.flux.x); col[10 * BLOCK] = __float_as_uint(cur.flux.y); col[11 * BLOCK] = __float_as_uint(cur.flux.z);
                     col[12 * BLOCK] = __float_as_uint(cur.pdf); col[13 * BLOCK] = __float_as_uint(cur.singlePdf);
                     // the frame of the VERTEX: a lane that parked its pixel has already taken a tile of possibly another frame
-                    col[14 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | ((pend_valid ? pend_fid : fid) << 28);
+                    col[14 * BLOCK] = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20) | ((pend_valid ? pend_fid : fid) << 26);   // depth <= 51 (raygen.cu:361): 6 bits; frame id: 6 bits
                     col[15 * BLOCK] = (uint32_t)cur.c.mat | ((uint32_t)cur.lsub << 16);   // material ids are < 32768 (spcbpt_create)
                     // (RMIS_pointer_3 does not fit the 16 stack entries four resident blocks leave: it travels by ds_bpermute below)
                 }
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     a.R3 = ownerR3;
                     a.pdf = __uint_as_float(col[12 * BLOCK]); a.singlePdf = __uint_as_float(col[13 * BLOCK]);
                     const uint32_t ids = col[14 * BLOCK];
-                    a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)((ids >> 20) & 255u);
-                    const LightVertex* job_lvc = BATCH ? p.frames[ids >> 28].lvc : p.lvc;
+                    a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)((ids >> 20) & 63u);
+                    const LightVertex* job_lvc = BATCH ? p.frames[ids >> 26].lvc : p.lvc;
                     a.c.mat = (int)(col[15 * BLOCK] & 0xffffu); a.lsub = (int)(col[15 * BLOCK] >> 16);
                     LightVertex b;
                     const float4* src = reinterpret_cast<const float4*>(job_lvc + w_slot[slot]);

@@ -110,8 +110,8 @@ struct FrameDesc {  // 64 B
     uint32_t subframe;
     uint32_t pad[3];
 };
-static const int kMaxBatchFrames = 16;  // fid travels in 4 bits next to the pixel coordinates
-static_assert(kMaxBatchFrames <= 16, "the frame id of a batched launch is packed into 4 bits (kernels.hip: published eye vertex)");
+static const int kMaxBatchFrames = 32;  // the frame id of a published eye vertex travels in 6 bits next to its subspace ids and depth
+static_assert(kMaxBatchFrames <= 64, "the frame id of a batched launch is packed into 6 bits (kernels.hip: published eye vertex)");
 
 
 struct KParams {  // passed by value as the kernel argument block (the MyParams analogue)

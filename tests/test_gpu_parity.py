@@ -531,7 +531,7 @@ def test_batched_light_passes_leave_the_caches_of_single_passes(gpu, pkg, monkey
     r.sync()
     assert np.array_equal(r.read_accum(), img)
     with pytest.raises(pkg.SpcbptError):
-        r.launch_light_batch(1, 17)
+        r.launch_light_batch(1, 33)
 
 
 def test_counting_sampler_build_gives_the_tables_of_the_radix_sort(gpu, pkg, monkeypatch):

@@ -23,7 +23,7 @@ extern "C" int hipGetDeviceCount(int*);
 struct Job {
     spcbpt_scene_desc desc;
     float eye[3], lookat[3], up[3], fov;
-    int W = 640, H = 360, frames = 16, batch = 0, M = 100000;   // batch 0 = 16 frames per eye / light launch
+    int W = 640, H = 360, frames = 16, batch = 0, M = 100000;   // batch 0 = up to 32 frames per eye / light launch, equal launches
     bool train = true, lbatch = false;
 };
 struct Rank {
@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
         else if (a == "--local") local = atoi(next());
         else if (a == "--dim") { if (sscanf(next(), "%dx%d", &J.W, &J.H) != 2) { fprintf(stderr, "bad --dim\n"); return 2; } }
         else if (a == "--frames") J.frames = atoi(next());
-        else if (a == "--batch") J.batch = std::max(1, std::min(16, atoi(next())));
+        else if (a == "--batch") J.batch = std::max(1, std::min(32, atoi(next())));
         else if (a == "--light-batch") lbatch = atoi(next());
         else if (a == "--light-paths") J.M = atoi(next());
         else if (a == "--out") out = next();
@@ -121,7 +121,7 @@ int main(int argc, char** argv) {
     int ndev = 0;
     hipGetDeviceCount(&ndev);
     const int world = local > 0 ? local : (gpus > 0 ? gpus : std::max(1, ndev));
-    if (J.batch == 0) J.batch = 16;
+    if (J.batch == 0) { const int launches = std::max(1, (J.frames + 31) / 32); J.batch = std::max(1, std::min(32, (J.frames + launches - 1) / launches)); }   // up to 32 frames per launch, equal launches
     J.lbatch = J.batch > 1 && lbatch != 0;
     if (!local && world > ndev) { fprintf(stderr, "%d GPUs asked for, %d present\n", world, ndev); return 1; }
     std::vector<Rank> R(world);

@@ -45,7 +45,7 @@ static void core_range(int n, int rank, int world, int* begin, int* count) {
 static void rank_create(const Job& J, Rank& R) {
     hipSetDevice(R.device);
     setenv("SPCBPT_EYE_BATCH", std::to_string(J.batch).c_str(), 1);
-    if (R.world > 2) setenv("SPCBPT_RENDER_STREAMS", "1", 0);   // a small share of the frame wants one long tile queue (bench.py: measured)
+    setenv("SPCBPT_RENDER_STREAMS", "1", 0);   // one long tile queue per launch; the light passes run beside it in a thin grid (bench.py: measured)
     RK(R, spcbpt_create(&J.desc, R.device, &R.ctx));
     RK(R, spcbpt_set_camera_lookat(R.ctx, J.eye, J.lookat, J.up, J.fov, (float)J.W / (float)J.H));
     RK(R, spcbpt_resize(R.ctx, J.W, J.H));

@@ -724,8 +724,10 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
     if (!blocks_per_cu[0]) blocks_per_cu[0] = spcbpt_blocks_per_cu(false);
     int max_blocks = num_cus * blocks_per_cu[0];
-    // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile
-    const int percent = grid_percent > 0 ? grid_percent : 94;
+    // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile -- few,
+    // since they run as a thin grid (launch_light_batch): 97 % (64 steps on one GPU: 5.76 ms per step at 94 %, 5.69 at 97, 5.67 at 100;
+    // a rank's share of a sharded frame is indifferent: 0.81-0.82 ms per rank-frame at N = 8 with all three)
+    const int percent = grid_percent > 0 ? grid_percent : 97;
     if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
     // the spill area is indexed by the thread of the grid ACTUALLY launched: n frames' tiles, capped by the resident slots
     // (sizing it for one frame's tiles let the blocks beyond one frame's share write past its end whenever that share was below max_blocks)

@@ -403,11 +403,24 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
     kp.lvc_scratch = lb_scratch; kp.core_counts = lb_core_counts; kp.path_counter = lb_path_counts;
     kp.n_lframes = n;
-    // a THIN grid: the batch runs beside the eye kernels of the frames before it, and few long-lived blocks take less from them than
-    // one block per CU that all want a slot at once (bench scene, one GPU: 6.08-6.15 ms per step with 32-64 blocks, 6.29 with 128)
-    if (light_batch_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BATCH_BLOCKS"); light_batch_blocks = lb ? std::max(1, atoi(lb)) : 48; }
-    // (cores that trace many paths one after the other -- the reference's geometry -- are long jobs: never two of them per lane)
+    // a THIN grid: the batch runs beside the eye kernels of the frames before it and only has to be done before they are; few
+    // long-lived blocks take less from them than many (bench scene, one GPU, 20 / 64 steps, ms per step: 16 blocks 5.71 / 5.67,
+    // 24: 5.73 / 5.66, 32: 5.74 / 5.68, 48: 5.85 / 5.71, 64: 5.94 / 5.76 -- the 20-frame batch then takes 76 ms beside an eye launch
+    // of 110).  SPCBPT_LIGHT_BATCH_BLOCKS fixes the number; by default it goes ...
+    if (light_batch_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BATCH_BLOCKS"); light_batch_blocks = lb ? std::max(1, atoi(lb)) : 0; }
     int grid_cap = light_batch_blocks;
+    if (grid_cap == 0) {
+        // ... in proportion to the light paths per pixel of this context's share of the frame (kp.row_step: the band step of the last
+        // eye launch), so that the batch stays shorter than the eye launch it runs beside: 400 blocks per (path / pixel), i.e. 20 for
+        // 100 000 paths against 1920 x 1080 pixels -- or against an eighth of both
+        const double px = std::max(1.0, (double)kp.width * kp.height / std::max(1, (int)kp.row_step));
+        const double ratio = (double)lt.core_count * std::max(1, lt.m_per_core) / px;
+        // (a rank's share of a sharded frame wants more lanes for the same ratio: its eye launches are short, and the chain of a
+        // batch -- passes, then one exchange and build per frame -- has to fit under them: N = 8 simulation 0.80-0.81 ms per
+        // rank-frame with 48 blocks, 0.83-0.87 with 20)
+        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, std::ceil(400.0 * ratio)));
+    }
+    // (cores that trace many paths one after the other -- the reference's geometry -- are long jobs: never two of them per lane)
     if (lt.m_per_core >= 8) grid_cap = std::max(grid_cap, (int)(((long long)n * lt.core_count + 255) / 256));
     const int blocks = light_trace_blocks(kp, grid_cap);
     {   // traversal-stack spill area, indexed by blockIdx.x * 256 + threadIdx.x of the grid launched

@@ -4,8 +4,11 @@ configs[2] at N=1, configs[3] at N>1).
 
 One "step" = one subframe of the reference's render loop (optixPathTracer.cpp:791-822): light trace (M = 100 000 light
 paths) -> device sampler build -> [N>1: RCCL all-gather of the LVC shards] -> SPCBPT eye megakernel over the image
-(N>1: every N-th band of 8 rows per rank); N>1 ends the timed region with the RCCL framebuffer sum.
+(N>1: every N-th band of 8 rows per rank); N>1 ends the timed region with the RCCL film exchange (band all-gather).
 value = (eye paths + light paths) of all ranks / wall time.  Inputs are resident in HBM before the timed region.
+The K steps of a run are issued as few, equal launches: the light passes of up to 32 frames in one thin persistent grid a batch
+ahead, then per frame its exchange and sampler build, then ONE persistent eye launch over those frames -- every
+step still traces its own light pass, builds its own sampler and renders its own subframe inside the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W

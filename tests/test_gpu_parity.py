@@ -567,3 +567,35 @@ def test_counting_sampler_build_gives_the_tables_of_the_radix_sort(gpu, pkg, mon
     np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_allclose(a[1], b[1], rtol=0, atol=1.5e-7)
     np.testing.assert_allclose(a[0]["sum_pmf"], b[0]["sum_pmf"], rtol=1e-6)
+
+
+def test_a_batch_of_twenty_frames_equals_twenty_launches(gpu, pkg, monkeypatch):
+    """Frame ids beyond 15 (the id of a published eye vertex travels in 6 bits since launches hold up to 32 frames): 20 light passes
+    in one launch, 20 frames in one eye launch, against 20 x (light pass, build, eye launch) -- the same film bit for bit."""
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    W, H, NF = 64, 64, 20
+    def make(batch):
+        monkeypatch.setenv("SPCBPT_EYE_BATCH", str(batch))
+        monkeypatch.setenv("SPCBPT_RENDER_STREAMS", "1")
+        r = pkg.Renderer(scene, 0)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+        r.resize(W, H)
+        r.set_light_trace(3000, 52, 1)
+        r.set_subspace()
+        return r
+    a = make(1)
+    for f in range(NF):
+        a.launch("light trace", f + 1); a.build_sampler(); a.launch("SPCBPT_eye", f)
+    a.sync()
+    want = a.read_accum().copy()
+    b = make(NF)
+    b.set_light_ahead(True)
+    b.launch_light_batch(1, NF)
+    for f in range(NF):
+        b.build_sampler()
+    b.launch_eye_batch(list(range(NF)))
+    b.sync()
+    assert np.array_equal(b.read_accum(), want)
+    with pytest.raises(pkg.SpcbptError):
+        b.launch_eye_batch(list(range(33)))

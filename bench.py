@@ -77,6 +77,12 @@ def cpu_baseline(pkg, scene, args, tup):
                       f"band ({rows * args.width} eye paths) each, {dt:.1f} s with {threads} threads"}
 
 
+def frames_per_launch(steps: int, max_batch: int = 32) -> int:
+    """Frames per eye / light launch for a run of `steps` steps: as few launches as `max_batch` allows, all of (nearly) the same size."""
+    launches = max(1, -(-steps // max_batch))
+    return max(1, min(max_batch, -(-steps // launches)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,9 +160,7 @@ def main():
     # a rank's share of a sharded frame gains more (N = 8 simulation: 0.94 -> 0.85 ms per rank-frame from 8 to 16 frames).
     # Up to 32 frames per launch, and a run's launches are kept equal (40 steps = 2 x 20, not 32 + 8: a short last launch pays a whole
     # drain for a few frames).  Per frame the kernel takes 5.98 ms in launches of 4 frames, 5.76 of 8, 5.63 of 16, 5.59 of 20-32.
-    max_batch = 32
-    launches = max(1, -(-args.steps // max_batch))
-    batch = args.eye_batch if args.eye_batch > 0 else max(1, min(max_batch, -(-args.steps // launches)))
+    batch = args.eye_batch if args.eye_batch > 0 else frames_per_launch(args.steps)
     streams = args.render_streams if args.render_streams > 0 else 1
     os.environ["SPCBPT_RENDER_STREAMS"] = str(streams)   # read by spcbpt_create
     os.environ["SPCBPT_EYE_BATCH"] = str(batch)          # sizes the ring of sampler buffer sets

@@ -10,7 +10,8 @@ The K steps of a run are issued as few, equal launches: the light passes of up t
 ahead, then per frame its exchange and sampler build, then ONE persistent eye launch over those frames -- every
 step still traces its own light pass, builds its own sampler and renders its own subframe inside the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]      N > 1 started the plain way: this process only spawns the N ranks
+                                                            (python -m torch.distributed.run ... as a child, before any GPU call) and relays rank 0's line
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 from __future__ import annotations
@@ -18,6 +19,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,6 +51,50 @@ def light_geometry(args):
     return (args.light_paths, 52, 1)
 
 
+def spawn_command(n: int, argv, port: int, script: str = None):
+    """The child that runs N ranks of this script: one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, script: str = None, out=None) -> int:
+    """`python bench.py --gpus N` without a launcher: start the ranks as FRESH child processes and relay rank 0's JSON line.
+    Runs before torch is imported or the GPU is touched (the parent never initialises HIP; nothing is exec'ed).  Returns the exit
+    code: the children's, or 1 when they ended well without printing a result line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = spawn_command(n, argv, free_port(), script)
+    print("bench.py: starting", n, "ranks:", " ".join(cmd), file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for raw in proc.stdout:        # rank 0 prints exactly one JSON line on stdout; anything else is passed on to stderr
+        t = raw.strip()
+        if t.startswith("{") and '"metric"' in t:
+            try:
+                json.loads(t)
+                line = t
+                continue
+            except ValueError:
+                pass
+        sys.stderr.write(raw)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        (out or sys.stdout).write(line + "\n")
+        (out or sys.stdout).flush()
+    return rc
+
+
 def cpu_baseline(pkg, scene, args, tup):
     """The oracle (scalar CPU restatement, `kind: port`) timed on this host's cores on a bounded sample of the same
     workload: the full light pass + sampler build + every `stride`-th band of the eye pass."""
@@ -72,9 +119,31 @@ def cpu_baseline(pkg, scene, args, tup):
         frames += 1
         dt = time.perf_counter() - t0
     paths = frames * (rows * args.width + args.light_paths)
-    return {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "sample": f"{frames} subframe(s): {args.light_paths} light paths + sampler build + eye pass on every {stride}-th 8-row "
-                      f"band ({rows * args.width} eye paths) each, {dt:.1f} s with {threads} threads"}
+    out = {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+           "sample": f"{frames} subframe(s): {args.light_paths} light paths + sampler build + eye pass on every {stride}-th 8-row "
+                     f"band ({rows * args.width} eye paths) each, {dt:.1f} s with {threads} threads"}
+    # (i) of SURVEY 8(d): the same port on ONE thread.  A whole subframe would take minutes, so its two halves are sampled and put
+    # together: the eye pass on every s1-th band over the sampler the run above left (~5 s), then 1/16 of the light pass's cores
+    # with their sampler build (~5 s); value = paths of one subframe / (eye time scaled to all bands + light time x 16)
+    if threads > 1:
+        bands = (args.height + 7) // 8
+        s1 = max(stride, bands // 2)             # two bands or so
+        rows1 = sum(1 for y in range(args.height) if (y // 8) % s1 == 0)
+        t0 = time.perf_counter()
+        o.launch("SPCBPT_eye", frames, rows=(0, args.height, s1), nthreads=1)
+        t_eye = time.perf_counter() - t0
+        nc, pad, mpc = light_geometry(args)
+        frac = 16
+        o.set_light_trace(max(1, nc // frac), pad, mpc)
+        t0 = time.perf_counter()
+        o.launch("light trace", frames + 1, nthreads=1)
+        o.build_sampler()
+        t_light = time.perf_counter() - t0
+        t_frame = t_eye * (args.height / rows1) + t_light * frac
+        out["single_thread"] = {"value": (args.width * args.height + args.light_paths) / t_frame / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
+                                "sample": f"eye pass on every {s1}-th band ({rows1 * args.width} eye paths, {t_eye:.1f} s) + 1/{frac} of the light pass's cores with "
+                                          f"their sampler build ({t_light:.1f} s), scaled to one whole subframe ({t_frame:.0f} s)"}
+    return out
 
 
 def frames_per_launch(steps: int, max_batch: int = 32) -> int:
@@ -100,6 +169,9 @@ def main():
     ap.add_argument("--scene-route", default="gltf", choices=["gltf", "memory"],
                     help="gltf: write the generated scene as glTF 2.0 and read it back with the C++ reader (default); memory: hand the arrays over directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--long-steps", type=int, default=256, help="steps of the extra steady-state run reported as ms_per_step_long (0 = skip)")
+    ap.add_argument("--sync-each-frames", type=int, default=16, help="frames of the extra pass in the reference's loop form -- one light pass, one build, one eye "
+                    "launch and a device sync per frame (optixPathTracer.cpp:791-822) -- reported as ms_per_frame_sync_each (0 = skip)")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
     ap.add_argument("--render-streams", type=int, default=0,
                     help="render streams per GPU, each with one (batched) eye launch in flight (0 = 1)")
@@ -117,12 +189,17 @@ def main():
                          "0: one launch per pass (a pass is a ~1.2 ms dependent chain however few paths a rank traces; a batch of them in one thin, long-lived grid costs the eye kernels beside it less)")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
+    ap.add_argument("--exchange-batch", type=int, default=1, help="1 (default): ONE all-gather per light batch (spcbpt_comm_exchange_lvc_batch); 0: one exchange per frame")
     ap.add_argument("--force-exchange", action="store_true", help="run the RCCL exchange path even at world size 1 (self-test)")
     ap.add_argument("--exchange", default="native", choices=["native", "python"],
                     help="native (default): the C++ RCCL host (libspcbpt_mgpu.so: all-gather of fixed-capacity shards + device counts, "
                          "device-side compaction, no host wait per frame, film band gather); python: the torch.distributed harness of "
                          "dist.FrameExchanger (per-frame host syncs; kept for comparison)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the plain way: the ranks are fresh children (one per GPU); this process never touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     # exactly ONE line on stdout: native libraries (RCCL prints a version banner) write to fd 1 too, so fd 1 is pointed
     # at stderr for the run and the JSON line goes to the saved descriptor at the end
@@ -134,8 +211,6 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         args.gpus = world
 
     import torch
@@ -205,16 +280,17 @@ def main():
             comm.calibrate(passes=2, slack=1.5)    # shard capacity of exchange 1 from two light passes (host waits: start-up only)
         except Exception as e:                     # noqa: BLE001 -- reported below, by every rank that saw it
             native_error = e
-        # every rank must take the same road: if the native host could not be set up anywhere, all fall back to the torch harness
+        # no silent fallback: a scaling number from the torch harness must not pass for the native host's.  If the C++ host could
+        # not be set up on ANY rank, every rank ends non-zero (--exchange python selects the harness on purpose)
         flag = torch.tensor([0 if native_error is not None else 1], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            print(f"rank {rank}: C++ N-GPU host unavailable ({native_error!r}); falling back to --exchange python", file=sys.stderr)
-            if comm is not None:
-                comm.close()
-            comm = None
-            args.exchange = "python"
-            r.set_light_trace(ncore, pad, mpc)
+            print(f"rank {rank}: C++ N-GPU host (libspcbpt_mgpu) failed: {native_error!r}", file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        comm_rank, comm_world, comm_transport = comm.info()
+        if comm_world != world or comm_rank != rank:
+            raise SystemExit(f"rank {rank}: RCCL reports rank {comm_rank} of {comm_world}, the launcher said {rank} of {world}")
     if dist is not None and args.exchange == "python":
         tup = pkg.dist.broadcast_subspace(tup, 0, device)
         if rank != 0:
@@ -235,6 +311,7 @@ def main():
     depth = args.light_ahead if args.light_ahead > 0 else (batch if batch > 1 else 1)
     state = {"next_light": 1, "primed": False, "lb_left": 0, "phase_left": 0}
     lbatch = ahead and batch > 1 and args.light_batch != 0 and ex is None   # (the torch harness keeps its tested one-pass-per-launch loop)
+    xbatch = lbatch and args.exchange_batch != 0     # one LVC exchange per light batch (spcbpt_comm_exchange_lvc_batch)
     if ahead:
         r.set_light_ahead(True)
 
@@ -250,6 +327,9 @@ def main():
             if state["lb_left"] == 0:                          # a phase of P steps launches exactly P passes (and consumes P of the stock)
                 n = max(1, min(batch, state["phase_left"]))
                 light_batch(n); state["lb_left"] = n
+                if comm is not None and xbatch:
+                    # ... and exchanges the n OLDEST pending passes (launched a batch ago) as ONE all-gather + one compaction
+                    comm.exchange_lvc_batch(n)
             state["lb_left"] -= 1; state["phase_left"] -= 1
         else:
             if not state["primed"]:
@@ -265,7 +345,8 @@ def main():
             # `depth` steps ago, so the wait is normally over before it starts
             if not lbatch:                     # (batched passes pace themselves: a batch waits for the eye launch that last read its sets)
                 r.sync_light()
-            comm.exchange_lvc()                # queues the all-gather + compaction on the communicator's stream; no host wait
+            if not (lbatch and xbatch):
+                comm.exchange_lvc()            # queues the all-gather + compaction on the communicator's stream; no host wait
         r.build_sampler()
         if isolate and (batch == 1 or len(queued) == batch - 1):
             r.sync()                           # roofline pass: the light pass launched above must not share the GPU with the eye kernel
@@ -356,6 +437,46 @@ def main():
     k_ms_overlapped, _ = r.kernel_time("spcbpt_render")   # span of the same kernel while frames overlap (timed region)
     r.enable_kernel_timing(False)
 
+    # ---- beside the contract's K steps: a long steady-state run of the same loop, and the reference's own loop form
+    ms_long = None
+    if args.long_steps > 0:
+        nl = -(-args.long_steps // batch) * batch      # whole launches
+        barrier()
+        t1 = time.perf_counter()
+        state["phase_left"] = nl
+        for f in range(nl):
+            step(2000 + f)
+        flush()
+        barrier()
+        ms_long = (time.perf_counter() - t1) / nl * 1e3
+        if dist is not None:
+            t = torch.tensor([ms_long], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_long = float(t.item())
+    ms_sync_each = None
+    if args.sync_each_frames > 0 and ex is None:
+        # optixPathTracer.cpp:791-822: launchLVCTrace (light pass + LVC_Process) then launchSubframe, a device sync after each
+        # (513, 634) -- one frame in flight, nothing batched, nothing ahead
+        r.sync()
+        r.set_light_ahead(False)
+        for f in range(2):                             # warm-up of this loop form
+            r.launch("light trace", 5000 + f)
+            if comm is not None: comm.exchange_lvc()
+            r.build_sampler(); r.launch("SPCBPT_eye", 5000 + f, rows); r.sync()
+        barrier()
+        t1 = time.perf_counter()
+        for f in range(args.sync_each_frames):
+            r.launch("light trace", 5100 + f)
+            if comm is not None: comm.exchange_lvc()
+            r.build_sampler()
+            r.launch("SPCBPT_eye", 5100 + f, rows)
+            r.sync()
+        ms_sync_each = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
+        if dist is not None:
+            t = torch.tensor([ms_sync_each], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_sync_each = float(t.item())
+
     eye_paths = args.width * args.height
     total_paths = (eye_paths + M) * args.steps
     value = total_paths / dt / 1e6
@@ -389,12 +510,17 @@ def main():
             "metric": "Mpaths/sec (whole node), SPCBPT, 1920x1080",
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step_long": None if ms_long is None else round(ms_long, 3),
+            "ms_per_frame_sync_each": None if ms_sync_each is None else round(ms_sync_each, 3),
+            "notes": {"ms_per_step_long": f"the same loop over {args.long_steps} more steps (steady state; value / ms_per_step are the contract's {args.steps} steps)",
+                      "ms_per_frame_sync_each": "the reference's loop form (optixPathTracer.cpp:791-822): one light pass, one sampler build, one eye launch and a device sync per frame"},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}, light pass geometry "
                                    f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu' if comm is not None else 'torch.distributed harness'}" + (f", shard capacity {comm.shard_capacity} vertices" if comm is not None else "") + ")"},
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "parallelism": "1 GPU" if world == 1 and comm is None else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu: ' + comm_transport + ' transport, ' + str(comm_world) + ' ranks seen by the communicator' if comm is not None else 'torch.distributed harness (--exchange python)'}" + (f", shard capacity {comm.shard_capacity} vertices, {'one exchange per light batch' if xbatch else 'one exchange per frame'}" if comm is not None else "") + ")",
+                       "host": "single context" if dist is None else ("libspcbpt_mgpu" if comm is not None else "torch.distributed harness"), "rccl_ranks": comm_world if comm is not None else (world if dist is not None else 0)},
             "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -153,6 +153,11 @@ typedef struct spcbpt_light_vertex {
     int16_t depth;
     int16_t last_zone_id;
     uint32_t path_id;  /* global light path index = core * m_per_core + k */
+    /* Cached classification: the vertex's label under the EYE tree + 1, written by the light pass for surface
+     * vertices; 0 = not computed (an emitter vertex, or a cache the caller assembled: write 0).  The connection code uses
+     * pad - 1 when 1 <= pad <= SPCBPT_NUM_SUBSPACE and re-derives the label by a tree descent for any other value, so a
+     * cache imported with a stale or uninitialised word costs time, never a wrong row of Gamma.  The label belongs to the
+     * trees the cache was traced under (like subspace_id): trace a new cache after spcbpt_set_subspace. */
     uint32_t pad;
 } spcbpt_light_vertex;
 
@@ -254,6 +259,15 @@ int spcbpt_build_sampler(spcbpt_ctx* ctx);
  * vertices from a device (is_device != 0) or host buffer. */
 int spcbpt_lvc_export(spcbpt_ctx* ctx, void** d_vertices, void** d_count, int* capacity);
 int spcbpt_lvc_import(spcbpt_ctx* ctx, const void* vertices, int count, int is_device);
+/* Capacity, in vertices, of the context's compact light-vertex caches (the reference allocates LVC_MAX_NUM padded slots once,
+ * optixPathTracer.cpp:470-475; here the cache exists once per frame in flight -- `sets` buffer sets of capacity x 104 B each --
+ * so it is sized from the cache a pass really produces).  Default (0): the first light pass after spcbpt_set_light_trace is
+ * traced once more as a probe (host wait, start-up) and the sets hold 2 x its vertex count (scaled to num_core for a rank's
+ * share), at most num_core x core_padding.  A later pass that does not fit is cut off and the next spcbpt_sync returns
+ * SPCBPT_ERR_CAPACITY.  set_capacity(vertices > 0) fixes the size by hand (allocates at once; the sets never shrink);
+ * environment: SPCBPT_LVC_CAPACITY.  INTEGRATION.md lists the resulting HBM footprint. */
+int spcbpt_lvc_set_capacity(spcbpt_ctx* ctx, int vertices);
+int spcbpt_lvc_get_capacity(spcbpt_ctx* ctx, int* vertices, int* sets);
 /* The same exchange without host round trips (libspcbpt_mgpu's RCCL host, include/spcbpt_mgpu.h):
  *   spcbpt_lvc_export_on        hands out the oldest pending shard like spcbpt_lvc_export and makes `hip_stream` (the caller's
  *                               exchange stream) wait for the light pass that fills it -- the host does not.
@@ -269,6 +283,14 @@ int spcbpt_lvc_import(spcbpt_ctx* ctx, const void* vertices, int count, int is_d
  *                               world x that block into a full width x height float4 image (`out_image`, device). */
 int spcbpt_lvc_export_on(spcbpt_ctx* ctx, void* hip_stream, void** d_vertices, void** d_count, int* capacity);
 int spcbpt_lvc_import_gathered(spcbpt_ctx* ctx, const void* shards, const void* counts_all, int world, int shard_capacity, void* hip_stream);
+/* One exchange per light BATCH (spcbpt_launch_light_batch): export_batch_on packs the shards of the n_frames oldest pending passes
+ * (only their filled part) and their count pairs into the caller's contiguous send buffer `send` (n_frames x shard_capacity
+ * vertices) / `send_counts` (n_frames x 2 int32) on `hip_stream`, which waits on the device for those passes; after ONE all-gather
+ * of each, import_gathered_batch concatenates every frame's shards into that frame's set with one kernel (rank q's block holds its
+ * frames one after the other: frame k at (q n_frames + k) x shard_capacity, counts at 2 (q n_frames + k)) and leaves the sets as
+ * n_frames single spcbpt_lvc_import_gathered calls would: n_frames spcbpt_build_sampler calls follow. */
+int spcbpt_lvc_export_batch_on(spcbpt_ctx* ctx, void* hip_stream, int n_frames, void* send, void* send_counts, int shard_capacity);
+int spcbpt_lvc_import_gathered_batch(spcbpt_ctx* ctx, const void* shards, const void* counts_all, int world, int n_frames, int shard_capacity, void* hip_stream);
 int spcbpt_film_pack_bands(spcbpt_ctx* ctx, int rank, int world, void* packed, void* hip_stream);
 int spcbpt_film_unpack_bands(spcbpt_ctx* ctx, int world, const void* packed_all, void* out_image, void* hip_stream);
 int spcbpt_image_size(spcbpt_ctx* ctx, int* width, int* height);

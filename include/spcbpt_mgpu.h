@@ -39,7 +39,9 @@ int spcbpt_comm_unique_id(char id[SPCBPT_UNIQUE_ID_BYTES]);
 
 /* ncclCommInitRank for `ctx` (its device must be current for the calling thread; every rank calls this, it synchronises with
  * the others).  The context must have its light pass configured (spcbpt_set_light_trace) -- the default shard capacity is the
- * rank's own scratch capacity core_count x core_padding; spcbpt_comm_calibrate tightens it. */
+ * largest scratch capacity core_count x core_padding of any rank (agreed with an all-reduce: the ranks' core ranges differ when
+ * num_core is not a multiple of world); spcbpt_comm_calibrate tightens it and should be called by every job: the context's caches
+ * are sized from a measured pass (spcbpt_lvc_set_capacity), and an exchange whose shard capacity exceeds them is refused. */
 int spcbpt_comm_create(spcbpt_ctx* ctx, int rank, int world, const char id[SPCBPT_UNIQUE_ID_BYTES], spcbpt_comm** out);
 
 /* `world` ranks on ONE device, in one process: out[r] is the communicator of ctxs[r].  Same call sequence as the RCCL form; the
@@ -60,6 +62,17 @@ int spcbpt_comm_calibrate(spcbpt_comm* comm, int passes, uint32_t first_frame, f
 /* Exchange 1 for the OLDEST pending light pass of the rank's context (spcbpt_set_light_ahead order), to be followed by
  * spcbpt_build_sampler.  Queues work only. */
 int spcbpt_comm_exchange_lvc(spcbpt_comm* comm);
+
+/* The same for the n OLDEST pending passes at once -- the passes of one spcbpt_launch_light_batch: ONE all-gather of the n packed
+ * shards (n x capacity vertices per rank) and one of the n count pairs, ONE compaction kernel (grid.y = frame); the sets are left
+ * as n calls of spcbpt_comm_exchange_lvc would leave them, bit for bit, and n calls of spcbpt_build_sampler follow.  1 <= n <= 32. */
+int spcbpt_comm_exchange_lvc_batch(spcbpt_comm* comm, int n_frames);
+
+/* What the communicator is: rank and size as the transport itself reports them (ncclCommUserRank / ncclCommCount), and the
+ * transport. */
+#define SPCBPT_COMM_RCCL 0
+#define SPCBPT_COMM_LOCAL 1
+int spcbpt_comm_info(const spcbpt_comm* comm, int* rank, int* world, int* transport);
 
 /* Exchange 2: the full width x height float4 film, gathered from every rank's bands, into `out_device` (device pointer of the
  * calling rank, width x height x 4 floats) or, when out_device is null, into the rank's own accum buffer.  Waits for the

@@ -460,6 +460,8 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_launch_light_batch": [vp, u32, i32],
         "spcbpt_lvc_export": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)],
         "spcbpt_lvc_import": [vp, vp, i32, i32],
+        "spcbpt_lvc_set_capacity": [vp, i32],
+        "spcbpt_lvc_get_capacity": [vp, C.POINTER(i32), C.POINTER(i32)],
         "spcbpt_lvc_read": [vp, vp, i32, C.POINTER(i32)],
         "spcbpt_sampler_read": [vp, vp, vp, vp, i32, C.POINTER(i32), C.POINTER(i32)],
         "spcbpt_read_accum": [vp, vp],
@@ -535,10 +537,10 @@ def load_library(path: str = LIB_PATH):
 EXPORTED_SYMBOLS = [
     "spcbpt_create", "spcbpt_destroy", "spcbpt_last_error", "spcbpt_set_camera", "spcbpt_set_camera_lookat",
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_launch_light_batch", "spcbpt_build_sampler",
-    "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
+    "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit",
-    "spcbpt_build_source_hash", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_build_source_hash", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -718,6 +720,16 @@ class Renderer:
 
     def lvc_import_device(self, d_ptr: int, count: int):
         self._chk(self.lib.spcbpt_lvc_import(self.h, C.c_void_p(d_ptr), count, 1), "lvc_import")
+
+    def lvc_set_capacity(self, vertices: int):
+        """Vertices per buffer set, fixed by hand (0 = sized from a probe pass: spcbpt_lvc_set_capacity)."""
+        self._chk(self.lib.spcbpt_lvc_set_capacity(self.h, int(vertices)), "lvc_set_capacity")
+
+    def lvc_capacity(self):
+        """(vertices per buffer set, number of sets) as allocated now."""
+        v, n = C.c_int(), C.c_int()
+        self._chk(self.lib.spcbpt_lvc_get_capacity(self.h, C.byref(v), C.byref(n)), "lvc_get_capacity")
+        return v.value, n.value
 
     def lvc_export(self):
         dv, dc, cap = C.c_void_p(), C.c_void_p(), C.c_int()

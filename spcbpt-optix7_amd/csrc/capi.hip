@@ -94,8 +94,13 @@ int Context::check_diag() {
     if (!d_diag) return 0;
     uint32_t h[4] = {0, 0, 0, 0};
     HIP_TRY(this, hipMemcpy(h, d_diag, sizeof(h), hipMemcpyDeviceToHost));
-    if (h[0] == 0 && h[1] == 0) return 0;
+    if (h[0] == 0 && h[1] == 0 && h[2] == 0) return 0;
     HIP_TRY(this, hipMemset(d_diag, 0, sizeof(h)));
+    if (h[0] == 0 && h[1] == 0) {
+        error = "light-vertex cache overflow: a light pass produced more vertices than a buffer set holds (" + std::to_string(lvc_capacity) +
+                ", sized from a probe pass); frames since the last sync are invalid -- fix the capacity with spcbpt_lvc_set_capacity";
+        return SPCBPT_ERR_CAPACITY;
+    }
     if (h[0] == 0) {
         error = "LVC exchange: a rank's shard did not fit the agreed shard capacity (or the gathered cache did not fit the LVC); frames since the last sync are invalid -- raise the capacity (spcbpt_comm_set_shard_capacity)";
         return SPCBPT_ERR_CAPACITY;
@@ -217,8 +222,51 @@ int Context::set_light_trace(const spcbpt_light_trace_params& p) {
         HIP_TRY(this, dev_alloc(&d_core_offsets, (size_t)count + 1));
         counts_capacity = (size_t)count + 1;
     }
-    // the compact LVC must hold every rank's shard after an all-gather: full num_core * core_padding
-    return ensure_lvc_capacity((size_t)p.num_core * p.core_padding);
+    // the compact LVC holds the whole job's cache (every rank's shard after an all-gather): sized by hand, or from a probe pass
+    // at the next light pass (context.h: lvc_capacity)
+    if (lvc_fixed) return ensure_lvc_capacity(lvc_fixed);
+    lvc_probe_needed = true;
+    return 0;
+}
+
+// Sizes the buffer sets from one pass of this context's cores, traced into the padded scratch and counted on the host.
+int Context::probe_lvc_capacity() {
+    lvc_probe_needed = false;
+    const size_t worst = (size_t)lt.num_core * lt.core_padding;
+    if (sync_all()) return SPCBPT_ERR_HIP;
+    kp.num_core = lt.num_core; kp.core_padding = lt.core_padding; kp.m_per_core = lt.m_per_core;
+    kp.core_begin = lt.core_begin; kp.core_count = lt.core_count; kp.launch_frame = 0x7f000001u;
+    kp.n_lframes = 0;
+    kp.lt_decorrelate = lt.decorrelate_bsdf_stream;
+    kp.lvc_scratch = d_scratch; kp.core_counts = d_core_counts;
+    {
+        const int entries = spill_entries_needed();
+        kp.spill_entries = entries;
+        const size_t need = (((size_t)lt.core_count + 255) / 256 * 256) * (size_t)entries;
+        if (entries == 0) kp.spill = nullptr;
+        else {
+            if (need > spill_capacity) { dev_free(d_spill); HIP_TRY(this, dev_alloc(&d_spill, need)); spill_capacity = need; }
+            kp.spill = d_spill;
+        }
+    }
+    kp.counters = nullptr;
+    HIP_TRY(this, hipMemsetAsync(d_core_counts, 0, ((size_t)lt.core_count + 1) * sizeof(int), stream));
+    kp.path_counter = d_set_counts_all + 2 * kMaxSets;   // a spare word behind the sets' counts
+    kp.work_counter = d_work_counter + kMaxRender;
+    HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), stream));
+    if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
+    launch_light_trace(kp, tree_has_direction, light_blocks, stream);
+    HIP_TRY(this, hipGetLastError());
+    std::vector<int> h((size_t)lt.core_count);
+    HIP_TRY(this, hipMemcpyAsync(h.data(), d_core_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(this, hipStreamSynchronize(stream));
+    double total = 0.0;
+    for (int v : h) total += (double)v;
+    total *= (double)lt.num_core / (double)std::max(1, lt.core_count);   // a rank's share of a sharded job -> the gathered cache
+    size_t cap = (size_t)std::max(2.0 * total, total + 65536.0);
+    cap = (cap + 4095) / 4096 * 4096;
+    cap = std::max<size_t>(1, std::min(cap, worst));
+    return ensure_lvc_capacity(cap);
 }
 
 int Context::ensure_lvc_capacity(size_t n) {
@@ -281,6 +329,7 @@ int Context::launch_light(uint32_t frame) {
         int rc = set_light_trace(d);
         if (rc) return rc;
     }
+    if (lvc_probe_needed) { int rcp = probe_lvc_capacity(); if (rcp) return rcp; }
     // lane: passes running ahead alternate between the light stream and a second one (context.h); everything else uses lane 0
     int lane = 0;
     if (light_ahead && !counting && getenv("SPCBPT_LIGHT_LANES") == nullptr) { light_toggle ^= 1; lane = light_toggle; }
@@ -350,7 +399,7 @@ int Context::launch_light(uint32_t frame) {
     HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(temp, tb, core_counts, core_offsets, lt.core_count + 1, ls));
     HIP_TRY(this, hipMemcpyAsync(d_sampler_counts, core_offsets + lt.core_count, sizeof(int), hipMemcpyDeviceToDevice, ls));
     launch_lvc_compact(scratch, core_counts, core_offsets, lt.core_count, lt.core_padding, d_lvc, keys, vals, weights,
-                       d_sampler_counts, ls);
+                       d_sampler_counts, (int)std::min<size_t>(lvc_capacity, 0x7fffffff), d_diag + 2, ls);
     time_end();
     HIP_TRY(this, hipGetLastError());
     if (lane == 0) { keys_ready = true; keys_set = lset; }
@@ -383,6 +432,7 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
         int rc = set_light_trace(d);
         if (rc) return rc;
     }
+    if (lvc_probe_needed) { int rcp = probe_lvc_capacity(); if (rcp) return rcp; }
     int rc = ensure_lane_b();
     if (rc) return rc;
     hipStream_t ls = lstream_b;
@@ -460,7 +510,8 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(nullptr, tb, lb_core_counts, lb_core_offsets, items, ls));
     if (tb > b_temp_capacity) { if (sync_all()) return SPCBPT_ERR_HIP; dev_free(b_temp); HIP_TRY(this, dev_alloc(&b_temp, tb)); b_temp_capacity = tb; }
     HIP_TRY(this, hipcub::DeviceScan::ExclusiveSum(b_temp, tb, lb_core_counts, lb_core_offsets, items, ls));
-    launch_lvc_compact_batch(lb_scratch, lb_core_counts, lb_core_offsets, lb_path_counts, lt.core_count, lt.core_padding, n, dst, ls);
+    launch_lvc_compact_batch(lb_scratch, lb_core_counts, lb_core_offsets, lb_path_counts, lt.core_count, lt.core_padding, n, dst,
+                             (int)std::min<size_t>(lvc_capacity, 0x7fffffff), d_diag + 2, ls);
     time_end();
     HIP_TRY(this, hipGetLastError());
     // (vertex_count, path_count) of the sets to pinned host memory: the sets are consecutive modulo n_sets -> at most two ranges
@@ -589,25 +640,53 @@ int Context::export_on(hipStream_t xs, void** dv, void** dc, int* cap) {
 // Receiving side of exchange 1 (k_gather_compact): `shards` = world x shard_cap vertices as the all-gather left them, `counts_all`
 // = world x (vertex_count, path_count), both device memory that `xs` has finished writing by the time this is queued.  Everything
 // is queued on `xs`; nothing here waits on the host.
-int Context::import_gathered(const void* shards, const int* counts_all, int world, int shard_cap, hipStream_t xs) {
-    if (!shards || !counts_all || world < 1 || shard_cap < 1) { error = "lvc_import_gathered: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
+int Context::import_gathered(const void* shards, const int* counts_all, int world, int shard_cap, hipStream_t xs, int nf) {
+    if (!shards || !counts_all || world < 1 || shard_cap < 1 || nf < 1 || nf > kMaxBatchFrames) { error = "lvc_import_gathered: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
     if (!d_lvc) { error = "no LVC allocated"; return SPCBPT_ERR_STATE; }
-    const int b = build_set();
-    // the set's previous readers: eye kernels (ev_render) were waited for by the light pass that refilled it; its own light pass
-    // and the all-gather that read it as the send buffer precede this call on `xs` (export_on)
+    if (nf > 1 && (int)pending.size() < nf) { error = "lvc_import_gathered_batch: fewer light passes are pending than frames were gathered"; return SPCBPT_ERR_STATE; }
+    // the sets' previous readers: eye kernels (ev_render) were waited for by the light pass that refilled them; their own light
+    // passes and the all-gather that read them as (or packed them into) the send buffer precede this call on `xs` (export_on)
+    CompactBatch dst = {};
+    int sets[kMaxBatchFrames];
+    for (int k = 0; k < nf; k++) { sets[k] = nf == 1 ? build_set() : pending[(size_t)k]; dst.lvc[k] = set_lvc[sets[k]]; dst.counts[k] = set_counts[sets[k]]; }
     launch_gather_compact(reinterpret_cast<const LightVertex*>(shards), counts_all, world, shard_cap, (int)std::min<size_t>(lvc_capacity, 0x7fffffff),
-                          set_lvc[b], set_counts[b], reinterpret_cast<int*>(d_diag + 1), xs);
+                          dst, nf, reinterpret_cast<int*>(d_diag + 1), xs);
     HIP_TRY(this, hipGetLastError());
-    HIP_TRY(this, hipEventRecord(ev_exch[b], xs));
-    ev_exch_set[b] = true;
-    set_bound[b] = (int)std::min<size_t>((size_t)world * (size_t)shard_cap, lvc_capacity);
-    set_count_host[b] = -1;
-    light_counts_valid[b] = false;
-    light_lane_of_set[b] = 0;
-    for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == b) ? built_sets.erase(it) : it + 1;
-    if (b == lset) lvc_count = -1;
-    if (keys_set == b) keys_ready = false;
+    for (int k = 0; k < nf; k++) {
+        const int b = sets[k];
+        HIP_TRY(this, hipEventRecord(ev_exch[b], xs));
+        ev_exch_set[b] = true;
+        set_bound[b] = (int)std::min<size_t>((size_t)world * (size_t)shard_cap, lvc_capacity);
+        set_count_host[b] = -1;
+        light_counts_valid[b] = false;
+        light_lane_of_set[b] = 0;
+        for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == b) ? built_sets.erase(it) : it + 1;
+        if (b == lset) lvc_count = -1;
+        if (keys_set == b) keys_ready = false;
+    }
     have_sampler = false;
+    return 0;
+}
+
+// Sending side of one exchange per light batch: the shards of the `nf` oldest pending passes packed into the caller's contiguous
+// send buffer (nf x shard_cap vertices, nf count pairs) on `xs`, which waits on the device for the passes that fill them.
+int Context::export_batch_on(hipStream_t xs, int nf, void* send, int* send_counts, int shard_cap) {
+    if (!d_lvc) { error = "no LVC allocated"; return SPCBPT_ERR_STATE; }
+    if (!send || !send_counts || nf < 1 || nf > kMaxBatchFrames || shard_cap < 1) { error = "lvc_export_batch_on: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
+    if ((int)pending.size() < nf) { error = "lvc_export_batch_on: fewer light passes are pending than frames were asked for (launch the batch's passes first)"; return SPCBPT_ERR_STATE; }
+    CompactBatch src = {};
+    for (int k = 0; k < nf; k++) {
+        const int b = pending[(size_t)k];
+        if (light_counts_valid[b]) HIP_TRY(this, hipStreamWaitEvent(xs, ev_light[b], 0));
+        else {
+            HIP_TRY(this, hipEventRecord(ev_set_stream[b], stream));
+            ev_set_touched[b] = true;
+            HIP_TRY(this, hipStreamWaitEvent(xs, ev_set_stream[b], 0));
+        }
+        src.lvc[k] = set_lvc[b]; src.counts[k] = set_counts[b];
+    }
+    launch_pack_shards(src, nf, shard_cap, reinterpret_cast<LightVertex*>(send), send_counts, xs);
+    HIP_TRY(this, hipGetLastError());
     return 0;
 }
 
@@ -961,6 +1040,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         // sets: one per frame of every eye launch in flight + the light passes ahead of them + the one being built
         c->n_sets = std::min((int)Context::kMaxSets, c->eye_batch > 1 ? c->eye_batch * (c->n_render + 2) + 3 : c->n_render + 4);   // batches in flight + one being built + a batch of light passes ahead
         if (const char* sb = getenv("SPCBPT_SAMPLER_BUILD")) c->counting_build = std::string(sb) != "hipcub";
+        if (const char* lc = getenv("SPCBPT_LVC_CAPACITY")) c->lvc_fixed = (size_t)std::max(0ll, atoll(lc));   // vertices per buffer set (0 = probe)
         if (const char* ns = getenv("SPCBPT_SETS")) c->n_sets = std::max(3, std::min((int)Context::kMaxSets, atoi(ns)));   // developer knob
         for (int s = 0; s < c->n_render; s++) {
             if (ov && std::string(ov) == "0") c->rstreams[s] = c->stream;
@@ -1063,8 +1143,8 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     }
     CREATE_TRY(dev_alloc(&c->d_tex, texs.size()));
     if (!texs.empty()) CREATE_TRY(hipMemcpy(c->d_tex, texs.data(), texs.size() * sizeof(DTexture), hipMemcpyHostToDevice));
-    CREATE_TRY(dev_alloc(&c->d_set_counts_all, (size_t)2 * Context::kMaxSets));
-    CREATE_TRY(hipMemset(c->d_set_counts_all, 0, 2 * Context::kMaxSets * sizeof(int)));
+    CREATE_TRY(dev_alloc(&c->d_set_counts_all, (size_t)2 * Context::kMaxSets + 2));   // + a spare pair (probe_lvc_capacity)
+    CREATE_TRY(hipMemset(c->d_set_counts_all, 0, (2 * Context::kMaxSets + 2) * sizeof(int)));
     for (int s = 0; s < c->n_sets; s++) {
         CREATE_TRY(dev_alloc(&c->set_subspace[s], (size_t)SPCBPT_NUM_SUBSPACE));
         c->set_counts[s] = c->d_set_counts_all + 2 * s;
@@ -1169,6 +1249,21 @@ int spcbpt_set_light_trace(spcbpt_ctx* c, const spcbpt_light_trace_params* p) {
     return c->set_light_trace(*p);
 }
 
+int spcbpt_lvc_set_capacity(spcbpt_ctx* c, int vertices) {
+    CTX_CHECK(c);
+    if (vertices < 0) { c->error = "lvc_set_capacity: negative capacity"; return SPCBPT_ERR_INVALID_ARG; }
+    c->lvc_fixed = (size_t)vertices;
+    if (vertices == 0) { c->lvc_probe_needed = true; return SPCBPT_OK; }   // back to the probe pass (the sets only ever grow)
+    c->lvc_probe_needed = false;
+    return c->ensure_lvc_capacity((size_t)vertices);
+}
+int spcbpt_lvc_get_capacity(spcbpt_ctx* c, int* vertices, int* sets) {
+    CTX_CHECK(c);
+    if (vertices) *vertices = (int)std::min<size_t>(c->lvc_capacity, 0x7fffffff);
+    if (sets) *sets = c->n_sets;
+    return SPCBPT_OK;
+}
+
 int spcbpt_launch(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r1, int rs) {
     CTX_CHECK(c);
     if (!name) { c->error = "null algorithm name"; return SPCBPT_ERR_INVALID_ARG; }
@@ -1210,7 +1305,7 @@ int spcbpt_lvc_import(spcbpt_ctx* c, const void* verts, int count, int is_device
     CTX_CHECK(c);
     if (!verts || count < 0) { c->error = "bad LVC import"; return SPCBPT_ERR_INVALID_ARG; }
     if ((size_t)std::max(count, 1) > c->lvc_capacity && c->pending.size() > 1) {
-        c->error = "lvc_import: the cache does not fit and cannot grow while a later light pass is in flight (capacity = num_core * core_padding of spcbpt_set_light_trace)";
+        c->error = "lvc_import: the cache does not fit and cannot grow while a later light pass is in flight (spcbpt_lvc_set_capacity before the first pass)";
         return SPCBPT_ERR_CAPACITY;
     }
     int rc = c->ensure_lvc_capacity((size_t)std::max(count, 1));
@@ -1253,7 +1348,15 @@ int spcbpt_lvc_export_on(spcbpt_ctx* c, void* hip_stream, void** dv, void** dc, 
 }
 int spcbpt_lvc_import_gathered(spcbpt_ctx* c, const void* shards, const void* counts_all, int world, int shard_capacity, void* hip_stream) {
     CTX_CHECK(c);
-    return c->import_gathered(shards, reinterpret_cast<const int*>(counts_all), world, shard_capacity, reinterpret_cast<hipStream_t>(hip_stream));
+    return c->import_gathered(shards, reinterpret_cast<const int*>(counts_all), world, shard_capacity, reinterpret_cast<hipStream_t>(hip_stream), 1);
+}
+int spcbpt_lvc_export_batch_on(spcbpt_ctx* c, void* hip_stream, int n_frames, void* send, void* send_counts, int shard_capacity) {
+    CTX_CHECK(c);
+    return c->export_batch_on(reinterpret_cast<hipStream_t>(hip_stream), n_frames, send, reinterpret_cast<int*>(send_counts), shard_capacity);
+}
+int spcbpt_lvc_import_gathered_batch(spcbpt_ctx* c, const void* shards, const void* counts_all, int world, int n_frames, int shard_capacity, void* hip_stream) {
+    CTX_CHECK(c);
+    return c->import_gathered(shards, reinterpret_cast<const int*>(counts_all), world, shard_capacity, reinterpret_cast<hipStream_t>(hip_stream), n_frames);
 }
 // film exchange helpers of a sharded job (exchange 2, once per read-out): pack this rank's 8-row bands contiguously / scatter
 // every rank's packed bands back into the full image.  Queued on `hip_stream` after the render streams' merges.

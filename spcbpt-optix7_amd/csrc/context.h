@@ -64,7 +64,8 @@ struct Context {
     hipEvent_t ev_exch[kMaxSets] = {};       // gathered compaction of the set done (recorded on the caller's exchange stream)
     bool ev_exch_set[kMaxSets] = {};
     int export_on(hipStream_t xs, void** dv, void** dc, int* cap);
-    int import_gathered(const void* shards, const int* counts_all, int world, int shard_cap, hipStream_t xs);
+    int import_gathered(const void* shards, const int* counts_all, int world, int shard_cap, hipStream_t xs, int nf);
+    int export_batch_on(hipStream_t xs, int nf, void* send, int* send_counts, int shard_cap);   // one exchange per light batch
     hipEvent_t ev_import[2] = {};            // device-to-device import copies done (alternating: the caller alternates two staging buffers)
     long long import_gen = 0;
     int* h_import_counts = nullptr;          // pinned [kMaxSets][2]: source of the counts upload of an import (no host wait)
@@ -138,7 +139,17 @@ struct Context {
     int* d_core_offsets = nullptr;
     size_t counts_capacity = 0;
     LightVertex* d_lvc = nullptr;
+    // Vertices every buffer set (compact LVC, jump buffer, CMFs) holds.  NOT the padded worst case num_core x core_padding (5.2 M
+    // vertices = 541 MB per set at the bench geometry, 53 GB for the 99 sets of a 32-frame pipeline): a light pass fills ~5 % of
+    // its padded slots, so the sets are sized from a PROBE pass -- the first light pass after spcbpt_set_light_trace is traced
+    // once more into the padded scratch and counted on the host (start-up) -- as 2 x that count (scaled to the whole job's cores
+    // for a rank of a sharded job), at most the worst case.  The compaction kernels cut a pass off at the capacity and raise
+    // diag[2] (SPCBPT_ERR_CAPACITY at the next sync): the vertex count of 100 000 paths varies by a fraction of a per cent, so
+    // the flag means a changed scene or tuple, and spcbpt_lvc_set_capacity fixes the size by hand.
     size_t lvc_capacity = 0;
+    size_t lvc_fixed = 0;            // spcbpt_lvc_set_capacity / SPCBPT_LVC_CAPACITY: explicit capacity (0 = from the probe pass)
+    bool lvc_probe_needed = false;   // set by set_light_trace, consumed by the next light pass
+    int probe_lvc_capacity();
     uint32_t *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
     float* d_weights = nullptr;
     double *d_wsorted = nullptr, *d_prefix = nullptr;
@@ -154,7 +165,7 @@ struct Context {
     size_t temp_capacity = 0;
     uint32_t* d_spill = nullptr;
     size_t spill_capacity = 0;
-    uint32_t* d_diag = nullptr;        // KParams::diag: [0] dropped traversal-stack entries
+    uint32_t* d_diag = nullptr;        // KParams::diag: [0] dropped traversal-stack entries, [1] shard / gathered-cache overflow of exchange 1, [2] a light pass outgrew the set capacity
     int spill_entries_debug = -1;      // SPCBPT_DEBUG_SPILL_ENTRIES: caps the spill entries per thread (tests of the overflow report)
     int spill_entries_needed() const;  // 3 * bvh_depth - kStackLds (a 4-wide node pushes up to 3 children per level)
     int check_diag();                  // after a sync: SPCBPT_ERR_STATE if a kernel dropped stack entries since the last check

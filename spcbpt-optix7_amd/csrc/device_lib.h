@@ -844,7 +844,8 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
     if (CACHE) {
         light_label = a.lsub;                    // unused at depth 1, like the descent it replaces
         eye_label = (int)b.pad - 1;              // unused for an emitter vertex
-        if (b.pad == 0u && b.depth != 0) eye_label = tree_label(p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), cn);   // imported cache without labels
+        // imported cache without labels (0), or a word that is not a label at all (spcbpt.h: never used as a row index unchecked)
+        if (b.pad - 1u >= (uint32_t)SPCBPT_NUM_SUBSPACE && b.depth != 0) eye_label = tree_label(p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), cn);
     } else {
         tree_label2(p.light_tree, a.c.pos, a.c.n, normalize(bpos - a.c.pos), a.depth != 1,
                     p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), b.depth != 0, light_label, eye_label, cn);

@@ -16,14 +16,16 @@ void launch_film_merge(const KParams& p, hipStream_t s);
 void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s);
 struct CompactBatch { LightVertex* lvc[kMaxBatchFrames]; int* counts[kMaxBatchFrames]; };   // per frame of a batched light pass: compact LVC + (vertex_count, path_count) of its set
 void launch_lvc_compact_batch(const LightVertex* scratch, const int* core_counts, const int* core_offsets, const int* path_counts, int core_count,
-                              int core_padding, int n, const CompactBatch& dst, hipStream_t s);
+                              int core_padding, int n, const CompactBatch& dst, int capacity, uint32_t* overflow, hipStream_t s);
 int light_trace_blocks(const KParams& p, int max_blocks);   // grid of the (batched) light pass: the spill area is sized for it
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
-                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
+                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, int capacity, uint32_t* overflow,
+                        hipStream_t s);
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s);
 void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys, uint32_t* vals, float* weights, const int* sampler_counts, hipStream_t s);
-void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, LightVertex* lvc,
-                           int* sampler_counts, int* overflow, hipStream_t s);
+void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, const CompactBatch& dst, int nf,
+                           int* overflow, hipStream_t s);
+void launch_pack_shards(const CompactBatch& src, int nf, int cap, LightVertex* send, int* send_counts, hipStream_t s);
 void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s);
 // the sampler build as one stable counting sort (four launches): kernels.hip "sampler build in four launches"
 size_t sampler_build_hist_ints();

@@ -684,12 +684,15 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
 __global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int* __restrict__ core_counts,
                               const int* __restrict__ core_offsets, int core_count, int core_padding, LightVertex* __restrict__ lvc,
                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float* __restrict__ weights,
-                              int* __restrict__ sampler_counts) {
-    // one thread per padded slot; only the filled slots (slot < count of its core) copy their 96-B record
+                              int* __restrict__ sampler_counts, int capacity, uint32_t* __restrict__ overflow) {
+    // one thread per padded slot; only the filled slots (slot < count of its core) copy their 96-B record.  The compact cache holds
+    // `capacity` vertices (sized from a measured pass with slack, not from the padded worst case: context.h); a pass that outgrows
+    // it is cut off at the capacity and reported through *overflow (SPCBPT_ERR_CAPACITY at the next sync), never written past the end.
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && core_offsets[core_count] > capacity) { sampler_counts[0] = capacity; *overflow = 1u; }
     if (t < (long long)core_count * core_padding) {
         const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
-        if (slot < core_counts[core]) {
+        if (slot < core_counts[core] && core_offsets[core] + slot < capacity) {
             const int dst_i = core_offsets[core] + slot;
             const float4* src = reinterpret_cast<const float4*>(scratch + t);
             float4* dst = reinterpret_cast<float4*>(lvc + dst_i);
@@ -706,23 +709,27 @@ __global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int
             weights[dst_i] = w;
         }
     }
-    (void)sampler_counts;
 }
 
 // Compaction of a batched light pass: grid.y = frame of the batch.  core_offsets is ONE exclusive scan over the n * (core_count + 1)
 // counts (each frame's segment ends in a zero sentinel), so frame k's offsets are relative to its first entry and its total is the
 // sentinel's offset minus that.  Keys are left to the sampler build (k_fill_keys_from_lvc), which also counts the paths again.
 __global__ void k_lvc_compact_batch(const LightVertex* __restrict__ scratch, const int* __restrict__ core_counts, const int* __restrict__ core_offsets,
-                                    const int* __restrict__ path_counts, int core_count, int core_padding, CompactBatch dst) {
+                                    const int* __restrict__ path_counts, int core_count, int core_padding, CompactBatch dst, int capacity,
+                                    uint32_t* __restrict__ overflow) {
     const int k = blockIdx.y;
     const int* counts = core_counts + (size_t)k * (core_count + 1);
     const int* offs = core_offsets + (size_t)k * (core_count + 1);
     const int base = offs[0];
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) { dst.counts[k][0] = offs[core_count] - base; dst.counts[k][1] = path_counts[k]; }
+    if (t == 0) {
+        const int total = offs[core_count] - base;
+        if (total > capacity) *overflow = 1u;   // k_lvc_compact: cut off at the set's capacity and reported
+        dst.counts[k][0] = min(total, capacity); dst.counts[k][1] = path_counts[k];
+    }
     if (t < (long long)core_count * core_padding) {
         const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
-        if (slot < counts[core]) {
+        if (slot < counts[core] && offs[core] - base + slot < capacity) {
             const float4* src = reinterpret_cast<const float4*>(scratch + (size_t)k * core_count * core_padding + t);
             float4* out = reinterpret_cast<float4*>(dst.lvc[k] + (offs[core] - base + slot));
             float4 q[6];
@@ -776,18 +783,22 @@ __global__ void k_fill_keys_devcount(const LightVertex* __restrict__ lvc, int bo
 // compact shard, padded to the agreed capacity), counts_all[2 r] / [2 r + 1] the vertex / path count of rank r.  The shards are
 // concatenated in rank order = global (path, depth) order into the set's LVC; the totals go to sampler_counts (device-resident:
 // the sampler build sizes itself from them, no host round trip).  A shard that did not fit `cap` raises *overflow.
+// Batched form (one exchange per light batch): grid.y = frame k of `nf`; rank q's block of the all-gather holds its nf shards one
+// after the other, so frame k of rank q sits at (q nf + k) cap and its counts at 2 (q nf + k); every frame goes to its own set (dst).
 __global__ void k_gather_compact(const LightVertex* __restrict__ gathered, const int* __restrict__ counts_all, int world, int cap, int lvc_capacity,
-                                 LightVertex* __restrict__ lvc, int* __restrict__ sampler_counts, int* __restrict__ overflow) {
+                                 CompactBatch dst, int nf, int* __restrict__ overflow) {
     const int chunks = (cap + 255) / 256;
-    const int r = blockIdx.x / chunks, c = blockIdx.x % chunks;
+    const int r = blockIdx.x / chunks, c = blockIdx.x % chunks, k = blockIdx.y;
+    LightVertex* __restrict__ lvc = dst.lvc[k];
+    int* __restrict__ sampler_counts = dst.counts[k];
     int base = 0, total = 0, paths = 0;
     bool over = false;
     for (int q = 0; q < world; q++) {
-        const int n = counts_all[2 * q];
+        const int n = counts_all[2 * (q * nf + k)];
         if (n > cap) over = true;
         if (q < r) base += min(n, cap);
         total += min(n, cap);
-        paths += counts_all[2 * q + 1];
+        paths += counts_all[2 * (q * nf + k) + 1];
     }
     if (total > lvc_capacity) over = true;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -795,16 +806,32 @@ __global__ void k_gather_compact(const LightVertex* __restrict__ gathered, const
         sampler_counts[1] = paths;
         if (over) *overflow = 1;
     }
-    const int n_r = min(counts_all[2 * r], cap);
+    const int n_r = min(counts_all[2 * (r * nf + k)], cap);
     const int i = c * 256 + (int)threadIdx.x;
     if (i >= n_r || base + i >= lvc_capacity) return;
-    const float4* src = reinterpret_cast<const float4*>(gathered + (size_t)r * cap + i);
-    float4* dst = reinterpret_cast<float4*>(lvc + base + i);
+    const float4* src = reinterpret_cast<const float4*>(gathered + ((size_t)r * nf + k) * cap + i);
+    float4* dst_q = reinterpret_cast<float4*>(lvc + base + i);
     float4 q[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) q[k] = src[k];
+    for (int j = 0; j < 6; j++) q[j] = src[j];
 #pragma unroll
-    for (int k = 0; k < 6; k++) dst[k] = q[k];
+    for (int j = 0; j < 6; j++) dst_q[j] = q[j];
+}
+// Sending side of the batched exchange: the first min(count, cap) vertices of nf sets and their count pairs into one contiguous
+// send buffer of nf x cap vertices (grid.y = frame).  The padding behind a shard is not copied (nobody reads it).
+__global__ void k_pack_shards(CompactBatch src, int cap, LightVertex* __restrict__ send, int* __restrict__ send_counts) {
+    const int k = blockIdx.y;
+    const int n = src.counts[k][0];
+    const int i = blockIdx.x * 256 + (int)threadIdx.x;
+    if (i == 0) { send_counts[2 * k] = n; send_counts[2 * k + 1] = src.counts[k][1]; }
+    if (i >= min(n, cap)) return;
+    const float4* in = reinterpret_cast<const float4*>(src.lvc[k] + i);
+    float4* out = reinterpret_cast<float4*>(send + (size_t)k * cap + i);
+    float4 q[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) q[j] = in[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) out[j] = q[j];
 }
 
 // film exchange of a sharded job: the 8-row bands of rank `rank` (band b with b % world == rank) packed contiguously / unpacked
@@ -1317,17 +1344,18 @@ void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_
     else hipLaunchKernelGGL(k_light_trace<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
-                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
+                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, int capacity, uint32_t* overflow,
+                        hipStream_t s) {
     const long long total = (long long)core_count * core_padding;
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(k_lvc_compact, dim3(blocks), dim3(256), 0, s, scratch, core_counts, core_offsets, core_count,
-                       core_padding, lvc, keys, vals, weights, sampler_counts);
+                       core_padding, lvc, keys, vals, weights, sampler_counts, capacity, overflow);
 }
 void launch_lvc_compact_batch(const LightVertex* scratch, const int* core_counts, const int* core_offsets, const int* path_counts, int core_count,
-                              int core_padding, int n, const CompactBatch& dst, hipStream_t s) {
+                              int core_padding, int n, const CompactBatch& dst, int capacity, uint32_t* overflow, hipStream_t s) {
     const long long total = (long long)core_count * core_padding;
     hipLaunchKernelGGL(k_lvc_compact_batch, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, s, scratch, core_counts, core_offsets,
-                       path_counts, core_count, core_padding, dst);
+                       path_counts, core_count, core_padding, dst, capacity, overflow);
 }
 void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
     if (n <= 0) return;
@@ -1337,11 +1365,14 @@ void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys
     if (bound <= 0) return;
     hipLaunchKernelGGL(k_fill_keys_devcount, dim3((bound + 255) / 256), dim3(256), 0, s, lvc, bound, keys, vals, weights, sampler_counts);
 }
-void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, LightVertex* lvc,
-                           int* sampler_counts, int* overflow, hipStream_t s) {
+void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, const CompactBatch& dst, int nf,
+                           int* overflow, hipStream_t s) {
     const int chunks = (cap + 255) / 256;
-    hipLaunchKernelGGL(k_gather_compact, dim3((unsigned)(world * chunks)), dim3(256), 0, s, gathered, counts_all, world, cap, lvc_capacity, lvc,
-                       sampler_counts, overflow);
+    hipLaunchKernelGGL(k_gather_compact, dim3((unsigned)(world * chunks), (unsigned)nf), dim3(256), 0, s, gathered, counts_all, world, cap, lvc_capacity, dst,
+                       nf, overflow);
+}
+void launch_pack_shards(const CompactBatch& src, int nf, int cap, LightVertex* send, int* send_counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_shards, dim3((unsigned)((cap + 255) / 256), (unsigned)nf), dim3(256), 0, s, src, cap, send, send_counts);
 }
 void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s) {
     const int bands = (height + 7) / 8, per_rank = (bands + world - 1) / world;

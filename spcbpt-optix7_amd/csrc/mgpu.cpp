@@ -30,8 +30,10 @@ struct spcbpt_comm {
     hipStream_t xs = nullptr;       // exchange stream (high priority: small transfers next to persistent render kernels)
     int shard_cap = 0;              // vertices per shard in exchange 1 (agreed by all ranks)
     int scratch_cap = 0;            // upper limit of shard_cap: what a light pass of this rank can produce at most
-    void* d_gather = nullptr; size_t gather_bytes = 0;      // world x shard_cap vertices
-    int* d_counts_all = nullptr;                            // world x {vertex_count, path_count}
+    void* d_gather = nullptr; size_t gather_bytes = 0;      // world x frames x shard_cap vertices
+    int* d_counts_all = nullptr;                            // world x frames x {vertex_count, path_count}
+    void* d_send = nullptr; size_t send_bytes = 0;          // batched exchange: frames x shard_cap vertices, packed
+    int* d_send_counts = nullptr;                           // frames x {vertex_count, path_count}
     int* h_counts_all = nullptr;                            // pinned mirror (calibration only)
     float* d_pack = nullptr; float* d_pack_all = nullptr; size_t pack_floats = 0;   // film bands: own block / every rank's
     void* d_stage = nullptr; size_t stage_bytes = 0;        // broadcast staging
@@ -40,6 +42,7 @@ struct spcbpt_comm {
     // local transport: what this rank contributed to the collective in flight
     void* l_send = nullptr; void* l_counts = nullptr; hipEvent_t l_ready = nullptr; bool l_posted = false;
     bool l_film_posted = false; void* l_film_out = nullptr;
+    int l_frames = 1;
 };
 
 namespace {
@@ -54,7 +57,7 @@ struct LocalGroup {
     std::vector<float> q, g;
     std::vector<bool> wants_tuple;
     double running_max = 0.0; int max_calls = 0;
-    int calib_max = 0;
+    int calib_max = 0, calib_min_lvc = 0;
 };
 
 int fail(spcbpt_comm* c, int code, const std::string& msg) {
@@ -77,8 +80,8 @@ int fail(spcbpt_comm* c, int code, const std::string& msg) {
         if (r__ != 0) return fail(c, r__, std::string(#expr) + ": " + spcbpt_last_error((c)->ctx));          \
     } while (0)
 
-int ensure_gather(spcbpt_comm* c) {
-    const size_t need = (size_t)c->world * (size_t)c->shard_cap * kVertexBytes;
+int ensure_gather(spcbpt_comm* c, int frames = 1) {
+    const size_t need = (size_t)c->world * (size_t)frames * (size_t)c->shard_cap * kVertexBytes;
     if (need > c->gather_bytes) {
         HIPX(c, hipStreamSynchronize(c->xs));
         if (c->d_gather) (void)hipFree(c->d_gather);
@@ -89,17 +92,33 @@ int ensure_gather(spcbpt_comm* c) {
     return 0;
 }
 
+int ensure_send(spcbpt_comm* c, int frames) {
+    const size_t need = (size_t)frames * (size_t)c->shard_cap * kVertexBytes;
+    if (need > c->send_bytes) {
+        HIPX(c, hipStreamSynchronize(c->xs));
+        if (c->d_send) (void)hipFree(c->d_send);
+        c->d_send = nullptr;
+        HIPX(c, hipMalloc(&c->d_send, need));
+        c->send_bytes = need;
+    }
+    return 0;
+}
+
+constexpr int kMaxFrames = 32;   // = kMaxBatchFrames of the core library (spcbpt_launch_light_batch)
+
 int common_init(spcbpt_comm* c) {
     HIPX(c, hipGetDevice(&c->device));
     int least = 0, greatest = 0;
     HIPX(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIPX(c, hipStreamCreateWithPriority(&c->xs, hipStreamNonBlocking, greatest));
-    HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts_all), (size_t)c->world * 2 * sizeof(int)));
+    HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_counts_all), (size_t)c->world * kMaxFrames * 2 * sizeof(int)));
+    HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_send_counts), (size_t)kMaxFrames * 2 * sizeof(int)));
     HIPX(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_counts_all), (size_t)c->world * 2 * sizeof(int)));
     HIPX(c, hipMalloc(reinterpret_cast<void**>(&c->d_scalar), 2 * sizeof(double)));
     HIPX(c, hipEventCreateWithFlags(&c->l_ready, hipEventDisableTiming));
-    // default shard capacity: whatever this rank's light pass can produce (export hands out the LVC capacity = the whole job's
-    // num_core x core_padding; a rank's own scratch is its core_count x core_padding <= that).  Tightened by calibrate.
+    // default shard capacity: whatever a rank's light pass can produce (its padded scratch core_count x core_padding; the ranks
+    // agree on the largest: the last rank of core_range takes the remainder).  Tightened by calibrate -- which a job should call:
+    // the context sizes its caches from a measured pass (spcbpt_lvc_set_capacity), not from this worst case.
     spcbpt_light_trace_params lt;
     CTXX(c, spcbpt_get_light_trace(c->ctx, &lt));
     c->scratch_cap = (int)std::min<long long>((long long)lt.core_count * lt.core_padding, 0x7fffffff);
@@ -138,6 +157,18 @@ int ensure_stage(spcbpt_comm* c, size_t bytes) {
     return 0;
 }
 
+// all-reduce (max) of the ranks' scratch capacities over RCCL; every rank stores the agreed value
+int agree_scratch_cap(spcbpt_comm* c) {
+    int* d = reinterpret_cast<int*>(c->d_scalar);
+    int own = c->scratch_cap, agreed = 0;
+    HIPX(c, hipMemcpyAsync(d, &own, sizeof(int), hipMemcpyHostToDevice, c->xs));
+    NCCLX(c, ncclAllReduce(d, d + 1, 1, ncclInt32, ncclMax, c->nccl, c->xs));
+    HIPX(c, hipMemcpyAsync(&agreed, d + 1, sizeof(int), hipMemcpyDeviceToHost, c->xs));
+    HIPX(c, hipStreamSynchronize(c->xs));
+    c->scratch_cap = c->shard_cap = agreed;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -162,6 +193,10 @@ int spcbpt_comm_create(spcbpt_ctx* ctx, int rank, int world, const char id[SPCBP
     memcpy(u.internal, id, SPCBPT_UNIQUE_ID_BYTES);
     ncclResult_t r = ncclCommInitRank(&c->nccl, world, u, rank);
     if (r != ncclSuccess) { fprintf(stderr, "spcbpt_comm_create: ncclCommInitRank: %s\n", ncclGetErrorString(r)); delete c; return SPCBPT_ERR_HIP; }
+    // ONE capacity for every rank: ncclAllGather needs equal send counts, and core_range gives the last rank the remainder
+    // (1000 cores on 3 ranks: 333 / 333 / 334), so the ranks' own scratch sizes differ whenever num_core % world != 0
+    rc = agree_scratch_cap(c);
+    if (rc) { fprintf(stderr, "spcbpt_comm_create: %s\n", c->error.c_str()); (void)ncclCommDestroy(c->nccl); delete c; return rc; }
     *out = c;
     return SPCBPT_OK;
 }
@@ -193,6 +228,8 @@ int spcbpt_comm_destroy(spcbpt_comm* c) {
     if (c->nccl) (void)ncclCommDestroy(c->nccl);
     if (c->d_gather) (void)hipFree(c->d_gather);
     if (c->d_counts_all) (void)hipFree(c->d_counts_all);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_send_counts) (void)hipFree(c->d_send_counts);
     if (c->h_counts_all) (void)hipHostFree(c->h_counts_all);
     if (c->d_pack) (void)hipFree(c->d_pack);
     if (c->d_pack_all) (void)hipFree(c->d_pack_all);
@@ -226,7 +263,8 @@ int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
     void *dv = nullptr, *dc = nullptr;
     int cap = 0;
     CTXX(c, spcbpt_lvc_export_on(c->ctx, c->xs, &dv, &dc, &cap));   // xs waits for the light pass on the device
-    if (cap < c->shard_cap) return fail(c, SPCBPT_ERR_CAPACITY, "exchange_lvc: the LVC is smaller than the shard capacity");
+    if (cap < c->shard_cap) return fail(c, SPCBPT_ERR_CAPACITY, "exchange_lvc: the context's light-vertex cache (" + std::to_string(cap) + " vertices) is smaller than the shard capacity (" +
+                                        std::to_string(c->shard_cap) + "): call spcbpt_comm_calibrate (or spcbpt_comm_set_shard_capacity / spcbpt_lvc_set_capacity) at start-up");
     if (c->nccl) {
         NCCLX(c, ncclGroupStart());
         NCCLX(c, ncclAllGather(dc, c->d_counts_all, 2, ncclInt32, c->nccl, c->xs));
@@ -267,6 +305,73 @@ int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
     return result;
 }
 
+// One exchange per light batch: the shards of the n oldest pending passes travel as ONE all-gather (plus one of the count pairs),
+// and ONE kernel concatenates every frame's shards into that frame's set.  Per-frame exchanges put 2 n small collectives in front of
+// an n-frame eye launch; the batch's passes are one launch already (spcbpt_launch_light_batch), so their shards are ready together.
+int spcbpt_comm_exchange_lvc_batch(spcbpt_comm* c, int n) {
+    if (!c || n < 1 || n > kMaxFrames) return SPCBPT_ERR_INVALID_ARG;
+    HIPX(c, hipSetDevice(c->device));
+    int rc = ensure_gather(c, n);
+    if (!rc) rc = ensure_send(c, n);
+    if (rc) return rc;
+    int lvc_cap = 0;
+    CTXX(c, spcbpt_lvc_get_capacity(c->ctx, &lvc_cap, nullptr));
+    if (lvc_cap < 1) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc_batch: no light pass has been traced");
+    CTXX(c, spcbpt_lvc_export_batch_on(c->ctx, c->xs, n, c->d_send, c->d_send_counts, c->shard_cap));   // xs waits for the passes on the device, then packs
+    if (c->nccl) {
+        NCCLX(c, ncclGroupStart());
+        NCCLX(c, ncclAllGather(c->d_send_counts, c->d_counts_all, (size_t)2 * n, ncclInt32, c->nccl, c->xs));
+        NCCLX(c, ncclAllGather(c->d_send, c->d_gather, (size_t)n * c->shard_cap * kVertexBytes, ncclUint8, c->nccl, c->xs));
+        NCCLX(c, ncclGroupEnd());
+        CTXX(c, spcbpt_lvc_import_gathered_batch(c->ctx, c->d_gather, c->d_counts_all, c->world, n, c->shard_cap, c->xs));
+        return SPCBPT_OK;
+    }
+    LocalGroup* g = c->grp;
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (c->l_posted) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc_batch (local): this rank already posted; every rank must call before any calls again");
+    c->l_send = c->d_send; c->l_counts = c->d_send_counts; c->l_posted = true; c->l_frames = n;
+    HIPX(c, hipEventRecord(c->l_ready, c->xs));
+    for (spcbpt_comm* s : g->ranks) if (!s->l_posted) return SPCBPT_OK;    // completed by the last rank to post
+    for (spcbpt_comm* s : g->ranks) if (s->l_frames != n) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc_batch (local): the ranks posted different frame counts");
+    for (spcbpt_comm* s : g->ranks) { int r2 = ensure_gather(s, n); if (r2) return r2; }
+    const size_t block = (size_t)n * c->shard_cap * kVertexBytes;
+    for (spcbpt_comm* d : g->ranks) {
+        for (spcbpt_comm* s : g->ranks) {
+            HIPX(d, hipStreamWaitEvent(d->xs, s->l_ready, 0));
+            HIPX(d, hipMemcpyAsync(reinterpret_cast<char*>(d->d_gather) + (size_t)s->rank * block, s->l_send, block, hipMemcpyDeviceToDevice, d->xs));
+            HIPX(d, hipMemcpyAsync(d->d_counts_all + (size_t)2 * n * s->rank, s->l_counts, (size_t)2 * n * sizeof(int), hipMemcpyDeviceToDevice, d->xs));
+        }
+    }
+    // (the send buffers are the communicators' own: a rank's next pack waits on its own stream behind these copies only if it is
+    // the destination too, so every destination records an event the senders' streams wait for)
+    std::vector<hipEvent_t> copied(g->ranks.size());
+    for (size_t k = 0; k < g->ranks.size(); k++) {
+        HIPX(c, hipEventCreateWithFlags(&copied[k], hipEventDisableTiming));
+        HIPX(c, hipEventRecord(copied[k], g->ranks[k]->xs));
+    }
+    int result = SPCBPT_OK;
+    for (spcbpt_comm* d : g->ranks) {
+        for (size_t k = 0; k < copied.size(); k++) (void)hipStreamWaitEvent(d->xs, copied[k], 0);
+        int r2 = spcbpt_lvc_import_gathered_batch(d->ctx, d->d_gather, d->d_counts_all, d->world, n, d->shard_cap, d->xs);
+        if (r2 && !result) result = fail(c, r2, std::string("spcbpt_lvc_import_gathered_batch: ") + spcbpt_last_error(d->ctx));
+        d->l_posted = false;
+    }
+    for (hipEvent_t e : copied) (void)hipEventDestroy(e);
+    return result;
+}
+
+int spcbpt_comm_info(const spcbpt_comm* c, int* rank, int* world, int* transport) {
+    if (!c) return SPCBPT_ERR_INVALID_ARG;
+    int r = c->rank, w = c->world;
+    if (c->nccl) {   // what RCCL itself says (bench.py reports it: a scaling number must come from the ranks RCCL really connected)
+        if (ncclCommUserRank(c->nccl, &r) != ncclSuccess || ncclCommCount(c->nccl, &w) != ncclSuccess) return SPCBPT_ERR_HIP;
+    }
+    if (rank) *rank = r;
+    if (world) *world = w;
+    if (transport) *transport = c->nccl ? SPCBPT_COMM_RCCL : SPCBPT_COMM_LOCAL;
+    return SPCBPT_OK;
+}
+
 int spcbpt_comm_calibrate(spcbpt_comm* c, int passes, uint32_t first_frame, float slack) {
     if (!c || passes < 1 || !(slack >= 1.0f)) return SPCBPT_ERR_INVALID_ARG;
     HIPX(c, hipSetDevice(c->device));
@@ -277,24 +382,33 @@ int spcbpt_comm_calibrate(spcbpt_comm* c, int passes, uint32_t first_frame, floa
         CTXX(c, spcbpt_lvc_read(c->ctx, nullptr, 0, &n));   // host wait: start-up only
         own_max = std::max(own_max, n);
     }
-    int global_max = own_max;
+    // a shard is SENT out of the rank's cache, so it can be no larger than the smallest cache of any rank (the caches are sized
+    // from each rank's own probe pass: spcbpt_lvc_set_capacity) -- agreed together with the largest shard
+    int own_lvc = 0;
+    CTXX(c, spcbpt_lvc_get_capacity(c->ctx, &own_lvc, nullptr));
+    int global_max = own_max, min_lvc = own_lvc;
     if (c->nccl) {
-        int* d = reinterpret_cast<int*>(c->d_scalar);
-        HIPX(c, hipMemcpyAsync(d, &own_max, sizeof(int), hipMemcpyHostToDevice, c->xs));
-        NCCLX(c, ncclAllReduce(d, d + 1, 1, ncclInt32, ncclMax, c->nccl, c->xs));
-        HIPX(c, hipMemcpyAsync(&global_max, d + 1, sizeof(int), hipMemcpyDeviceToHost, c->xs));
+        int* d = reinterpret_cast<int*>(c->d_scalar);   // 2 doubles = 4 ints: {max shard, -cache} -> max
+        const int in[2] = {own_max, -own_lvc};
+        int outv[2] = {0, 0};
+        HIPX(c, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, c->xs));
+        NCCLX(c, ncclAllReduce(d, d + 2, 2, ncclInt32, ncclMax, c->nccl, c->xs));
+        HIPX(c, hipMemcpyAsync(outv, d + 2, sizeof(outv), hipMemcpyDeviceToHost, c->xs));
         HIPX(c, hipStreamSynchronize(c->xs));
+        global_max = outv[0]; min_lvc = -outv[1];
     } else {   // local: the ranks calibrate one after the other; the agreed capacity follows the largest shard seen so far
         std::lock_guard<std::mutex> lk(c->grp->mu);
         c->grp->calib_max = std::max(c->grp->calib_max, own_max);
-        global_max = c->grp->calib_max;
+        c->grp->calib_min_lvc = c->grp->calib_min_lvc == 0 ? own_lvc : std::min(c->grp->calib_min_lvc, own_lvc);
+        global_max = c->grp->calib_max; min_lvc = c->grp->calib_min_lvc;
     }
     int cap = (int)((double)global_max * slack) + 1;
     cap = (cap + 1023) / 1024 * 1024;
-    if (c->nccl) c->shard_cap = std::max(1024, std::min(cap, c->scratch_cap));
+    cap = std::max(1, std::min(std::max(1024, std::min(cap, c->scratch_cap)), min_lvc));
+    if (c->nccl) c->shard_cap = cap;
     else {
         std::lock_guard<std::mutex> lk(c->grp->mu);
-        for (spcbpt_comm* s : c->grp->ranks) s->shard_cap = std::max(1024, std::min(cap, s->scratch_cap));
+        for (spcbpt_comm* s : c->grp->ranks) s->shard_cap = cap;
     }
     return SPCBPT_OK;
 }

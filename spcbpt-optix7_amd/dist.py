@@ -183,7 +183,7 @@ import os as _os
 MGPU_LIB_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "csrc", "libspcbpt_mgpu.so")
 UNIQUE_ID_BYTES = 128
 MGPU_SYMBOLS = ["spcbpt_comm_unique_id", "spcbpt_comm_create", "spcbpt_comm_create_local", "spcbpt_comm_destroy", "spcbpt_comm_last_error",
-                "spcbpt_comm_set_shard_capacity", "spcbpt_comm_get_shard_capacity", "spcbpt_comm_calibrate", "spcbpt_comm_exchange_lvc",
+                "spcbpt_comm_set_shard_capacity", "spcbpt_comm_get_shard_capacity", "spcbpt_comm_calibrate", "spcbpt_comm_exchange_lvc", "spcbpt_comm_exchange_lvc_batch", "spcbpt_comm_info",
                 "spcbpt_comm_gather_film", "spcbpt_comm_broadcast_subspace", "spcbpt_comm_barrier", "spcbpt_comm_max_double"]
 _mgpu = None
 
@@ -202,6 +202,7 @@ def load_mgpu():
                "spcbpt_comm_create_local": [_C.POINTER(vp), i32, _C.POINTER(vp)], "spcbpt_comm_destroy": [vp],
                "spcbpt_comm_set_shard_capacity": [vp, i32], "spcbpt_comm_get_shard_capacity": [vp, _C.POINTER(i32)],
                "spcbpt_comm_calibrate": [vp, i32, _C.c_uint32, _C.c_float], "spcbpt_comm_exchange_lvc": [vp],
+               "spcbpt_comm_exchange_lvc_batch": [vp, i32], "spcbpt_comm_info": [vp, _C.POINTER(i32), _C.POINTER(i32), _C.POINTER(i32)],
                "spcbpt_comm_gather_film": [vp, vp], "spcbpt_comm_broadcast_subspace": [vp, i32], "spcbpt_comm_barrier": [vp],
                "spcbpt_comm_max_double": [vp, _C.POINTER(_C.c_double)]}
         for name, args in sig.items():
@@ -273,6 +274,16 @@ class Comm:
 
     def exchange_lvc(self):
         self._chk(self.lib.spcbpt_comm_exchange_lvc(self.h), "comm_exchange_lvc")
+
+    def exchange_lvc_batch(self, n: int):
+        """One exchange for the n oldest pending light passes (the passes of one launch_light_batch)."""
+        self._chk(self.lib.spcbpt_comm_exchange_lvc_batch(self.h, int(n)), "comm_exchange_lvc_batch")
+
+    def info(self):
+        """(rank, world, transport) as the transport reports them; transport "rccl" or "local"."""
+        r, w, t = _C.c_int32(), _C.c_int32(), _C.c_int32()
+        self._chk(self.lib.spcbpt_comm_info(self.h, _C.byref(r), _C.byref(w), _C.byref(t)), "comm_info")
+        return int(r.value), int(w.value), "rccl" if t.value == 0 else "local"
 
     def gather_film(self, out_device_ptr=None):
         self._chk(self.lib.spcbpt_comm_gather_film(self.h, out_device_ptr), "comm_gather_film")

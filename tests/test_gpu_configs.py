@@ -10,8 +10,13 @@
   C5' the comparator of config 5, "plain BDPT" = SubspaceSampler_device::uniformSample (cuProg.h:283-289): parity with the
       oracle's restatement and unbiasedness.
 
-Tolerances are written next to each assertion.  (C1, C2 and the reduced C3 live in test_gpu_parity.py; C4, the 8-GPU run, is
-the driver's: its host loop is covered by test_gpu_pipeline.py, test_distributed_cpu.py and tests/test_mgpu_host.py.)
+  C4  the 8-rank partition of C3 (and of the reduced C5 scene) at full size WITHOUT an 8-GPU node: eight (context,
+      communicator) pairs of the C++ N-GPU host on the one GPU of the test box (spcbpt_comm_create_local: the same sharding,
+      calibrated shard capacity, one exchange per light batch, device-count sampler build, band gather -- device copies stand in
+      for RCCL): the gathered film equals the film ONE context renders, bit for bit.  What stays the driver's is hardware N > 1.
+
+Tolerances are written next to each assertion.  (C1, C2 and the reduced C3 live in test_gpu_parity.py; the N-GPU host loop is
+also covered by test_gpu_pipeline.py, test_distributed_cpu.py and tests/test_mgpu_host.py.)
 """
 import os
 import tempfile
@@ -277,6 +282,120 @@ def test_c3_reference_light_trace_geometry_at_full_size(bench_scene, pkg, ob):
     np.testing.assert_array_equal(sg[2], so[2])
     assert np.abs(sg[1] - so[1]).max() < 3e-5
     assert (sg[0]["size"] > 0).sum() > 300                                      # hundreds of populated light subspaces
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def _local_ranks_film(pkg, scene, W, H, lt, world, batch, NF, tup, xbatch=True):
+    """NF frames on `world` local ranks exactly as bench.py drives the C++ host: batched light passes a batch ahead, ONE
+    exchange per light batch, a sampler build per frame, one batched eye launch per `batch` frames on the rank's bands, band
+    gather at the end.  Returns (film on every rank, sampler of the last frame on rank 0, shard capacity, band counts)."""
+    ranks = []
+    for k in range(world):
+        r = _renderer(pkg, scene, W, H, lt, batch=batch)
+        b, c = pkg.dist.core_range(lt[0], k, world)
+        r.set_light_trace(*lt, core_begin=b, core_count=c)
+        ranks.append(r)
+    ranks[0].set_subspace(*tup)                                  # "rank 0 trained"
+    comms = pkg.dist.Comm.local(ranks)
+    for c in reversed(comms):
+        c.broadcast_subspace(0)
+    for c in comms:
+        c.calibrate(passes=2, slack=1.5)
+    cap = comms[0].shard_capacity
+    assert all(c.shard_capacity == cap for c in comms)
+    for r in ranks:
+        r.set_light_ahead(True)
+        r.launch_light_batch(1, batch)                           # the stock: one batch ahead
+    queued = []
+    for f in range(NF):
+        if f % batch == 0:
+            n = min(batch, NF - f)
+            for r in ranks:
+                r.launch_light_batch(f + 1 + batch, n)
+            if xbatch:
+                for c in comms:
+                    c.exchange_lvc_batch(n)                      # the n oldest pending passes: one all-gather, one compaction
+        if not xbatch:
+            for c in comms:
+                c.exchange_lvc()
+        for r in ranks:
+            r.build_sampler()
+        queued.append(f)
+        if len(queued) == batch or f == NF - 1:
+            for k, r in enumerate(ranks):
+                r.launch_eye_batch(queued, pkg.dist.band_rows(H, k, world))
+            queued = []
+    for r in ranks:
+        r.sync()
+    for c in comms:
+        c.gather_film()
+    films = [r.read_accum().copy() for r in ranks]
+    sampler = ranks[0].sampler_read()
+    caps = [r.lvc_capacity() for r in ranks]
+    for c in comms:
+        c.close()
+    for r in ranks:
+        r.close()
+    return films, sampler, cap, caps
+
+
+def test_c4_eight_local_ranks_render_the_bench_frame_bit_for_bit(bench_scene, pkg):
+    """BASELINE config 4 minus the hardware: 1920 x 1080, 986 k triangles, trained tuple, 100 000 light paths in 8 shards of
+    12 500 cores, 135 bands over 8 ranks (17 / 17 / ... / 16), 32 frames per eye launch and per light launch, one exchange per
+    light batch."""
+    scene = bench_scene
+    W, H, M, NF, batch, world = 1920, 1080, 100000, 32, 32, 8
+    lt = (M, 52, 1)
+    single = _renderer(pkg, scene, W, H, lt, batch=batch)
+    single.preprocess(target_paths=2_000_000, target_q_paths=2_000_000, train=True)
+    tup = single.get_subspace()
+    single.set_light_ahead(True)
+    for f in range(NF):
+        single.launch("light trace", f + 1)
+    for f in range(NF):
+        single.build_sampler()
+    single.launch_eye_batch(list(range(NF)))
+    single.sync()
+    want = single.read_accum().copy()
+    want_sampler = single.sampler_read()
+    vcap, nsets = single.lvc_capacity()
+    # ADVICE r2: the sets are sized from the compacted cache, not from num_core x core_padding (5.2 M vertices x 99 sets = 53 GB)
+    assert nsets >= 3 * batch and want_sampler[3] < vcap <= 4 * want_sampler[3] and vcap < M * 52 // 4, (vcap, nsets, want_sampler[3])
+    single.close()
+    assert (want[..., 3] == 1.0).all() and np.isfinite(want).all()
+
+    films, sampler, cap, caps = _local_ranks_film(pkg, scene, W, H, lt, world, batch, NF, tup)
+    bands = [len(range(k, (H + 7) // 8, world)) for k in range(world)]
+    assert bands == [17] * 7 + [16]                               # the uneven split really happened
+    assert cap < (M // world) * 52 // 4, cap                       # calibrated: far below a rank's padded scratch (650 000)
+    assert all(v < M * 52 // 4 for v, _ in caps), caps
+    for k, film in enumerate(films):
+        assert np.array_equal(film, want), (k, int((np.abs(film - want).max(axis=2) > 0).sum()))
+    # the gathered cache of the last frame is the single context's, table for table
+    assert (sampler[3], sampler[4]) == (want_sampler[3], want_sampler[4])
+    assert np.array_equal(sampler[2], want_sampler[2]) and np.array_equal(sampler[1], want_sampler[1])
+    for a, b in zip(sampler[0], want_sampler[0]):
+        assert a["jump_bias"] == b["jump_bias"] and a["size"] == b["size"]
+
+
+def test_c5_eight_local_ranks_render_the_hallway_bit_for_bit(hallway_trained, pkg):
+    """The reduced C5 scene (trained 1000-subspace tuple) on 8 local ranks: 18 bands over 8 ranks (3 / 3 / 2 / ...), 2 500 cores
+    per rank, per-batch and per-frame exchanges against ONE context."""
+    scene, _, tup = hallway_trained
+    W, H, NF, batch, world = 256, 144, 16, 8, 8
+    lt = (20000, 52, 1)
+    single = _renderer(pkg, scene, W, H, lt, batch=batch)
+    single.set_subspace(*tup)
+    for f in range(NF):
+        single.launch("light trace", f + 1); single.build_sampler(); single.launch("SPCBPT_eye", f)
+    single.sync()
+    want = single.read_accum().copy()
+    single.close()
+    for xbatch in (True, False):
+        films, _, cap, _ = _local_ranks_film(pkg, scene, W, H, lt, world, batch, NF, tup, xbatch=xbatch)
+        assert cap < 2500 * 52
+        for film in films:
+            assert np.array_equal(film, want), xbatch
 
 
 # ------------------------------------------------------------------------------------------------------------------------

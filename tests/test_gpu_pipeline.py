@@ -261,3 +261,30 @@ def test_batched_eye_launch_where_waves_cross_frame_boundaries(gpu, pkg):
         b.sync()
         got = b.read_accum()
         assert np.array_equal(got, want), (rep, int((np.abs(got - want).max(axis=2) > 0).sum()))
+
+
+def test_cache_sets_are_sized_from_a_probe_pass_and_an_overflow_is_reported(gpu, pkg):
+    """The compact light-vertex caches exist once per frame in flight, so they are sized from the cache a pass really produces
+    (probe pass at the first light pass: 2 x its vertex count), not from num_core x core_padding; a pass that outgrows a
+    hand-set capacity is cut off and reported at the next sync (SPCBPT_ERR_CAPACITY), never written past the end."""
+    want, lvcs = _plain(pkg)
+    r = _renderer(pkg)
+    assert r.lvc_capacity()[0] == 0                      # nothing allocated before the first pass
+    r.launch("light trace", 1)
+    n = len(r.lvc_read())
+    v, sets = r.lvc_capacity()
+    assert n == len(lvcs[0]) and n < v <= max(2 * n, n + 65536) + 4096 and v <= 3000 * 64 and sets >= 3
+    # by hand: too small -> reported, images invalid; large enough -> the plain frames again
+    r2 = _renderer(pkg)
+    r2.lvc_set_capacity(n // 2)
+    r2.launch("light trace", 1); r2.build_sampler(); r2.launch("SPCBPT_eye", 0)
+    with pytest.raises(pkg.SpcbptError, match="cache overflow"):
+        r2.sync()
+    assert len(r2.lvc_read()) == n // 2                  # cut off at the capacity
+    r2.lvc_set_capacity(n + 100)
+    r2.clear_accum()
+    for f in range(FRAMES):
+        r2.launch("light trace", f + 1); r2.build_sampler(); r2.launch("SPCBPT_eye", f)
+    r2.sync()
+    assert np.array_equal(r2.read_accum(), want)
+    assert r2.lvc_capacity()[0] == n + 100

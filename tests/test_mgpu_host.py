@@ -21,7 +21,7 @@ def test_every_declared_symbol_is_exported(hip_lib, pkg):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = sorted(set(re.findall(r"\b(spcbpt_comm_[a-z_0-9]+)\s*\(", src)))
     lib = pkg.dist.load_mgpu()
-    assert sorted(pkg.dist.MGPU_SYMBOLS) == names and len(names) >= 12
+    assert sorted(pkg.dist.MGPU_SYMBOLS) == names and len(names) >= 14
     for n in names:
         assert hasattr(lib, n), n
     assert lib.spcbpt_comm_exchange_lvc(None) == -1 and lib.spcbpt_comm_gather_film(None, None) == -1   # null communicator: an error, not a crash
@@ -51,9 +51,12 @@ def _single(pkg, scene, nf, lt=(3000, 64, 1)):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,batch,lt,lbatch", [(2, 2, (3000, 64, 1), False), (3, 1, (3000, 64, 1), False), (2, 2, (40, 200, 60), False),
-                                                   (3, 3, (3000, 64, 1), True)])   # lbatch: a batch's light passes as one launch too
-def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, lbatch):
+@pytest.mark.parametrize("world,batch,lt,lbatch,xbatch", [(2, 2, (3000, 64, 1), False, False), (3, 1, (3000, 64, 1), False, False), (2, 2, (40, 200, 60), False, False),
+                                                          (3, 3, (3000, 64, 1), True, False),   # lbatch: a batch's light passes as one launch too
+                                                          (3, 3, (3000, 64, 1), True, True),    # xbatch: ... and their shards as ONE exchange
+                                                          (3, 2, (1000, 64, 1), True, True),    # 1000 cores on 3 ranks: 333 / 333 / 334 (uneven scratch sizes)
+                                                          (7, 3, (1000, 64, 1), True, True)])
+def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, lbatch, xbatch):
     scene = pkg.scenes.cornell_box()
     NF = 6
     single, want = _single(pkg, scene, NF, lt)
@@ -71,6 +74,7 @@ def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, l
         c.calibrate(passes=2, slack=1.5)
     cap = comms[0].shard_capacity
     assert all(c.shard_capacity == cap for c in comms) and cap < lt[0] * lt[1]
+    assert all(c.info() == (k, world, "local") for k, c in enumerate(comms))
     for r in ranks:
         r.set_light_ahead(True)
         if lbatch: r.launch_light_batch(1, batch)             # the passes running ahead: one batch
@@ -80,8 +84,13 @@ def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, l
         for r in ranks:
             if not lbatch: r.launch("light trace", f + 2)
             elif f % batch == 0: r.launch_light_batch(f + 1 + batch, batch)
-        for c in comms:
-            c.exchange_lvc()                                  # no host wait; completes when the last rank has posted
+        if xbatch:
+            if f % batch == 0:
+                for c in comms:
+                    c.exchange_lvc_batch(batch)               # the batch's oldest pending passes: one gather, one compaction kernel
+        else:
+            for c in comms:
+                c.exchange_lvc()                              # no host wait; completes when the last rank has posted
         for r in ranks:
             r.build_sampler()                                 # item count stays on the device
         queued.append(f)
@@ -122,6 +131,7 @@ def test_rccl_transport_at_world_size_one(gpu, pkg):
     r.set_subspace(*single.get_subspace())
     c.broadcast_subspace(0)
     c.calibrate(passes=1)
+    assert c.info() == (0, 1, "rccl")                         # ncclCommUserRank / ncclCommCount
     r.set_light_ahead(True)
     r.launch("light trace", 1)
     q = []
@@ -137,6 +147,63 @@ def test_rccl_transport_at_world_size_one(gpu, pkg):
     assert np.array_equal(r.read_accum(), want)
     assert c.max_double(3.5) == 3.5
     c.close()
+
+
+@pytest.mark.gpu
+def test_rccl_batched_exchange_at_world_size_one(gpu, pkg):
+    """spcbpt_comm_exchange_lvc_batch over the RCCL transport: pack -> ncclAllGather of 2 n counts and n x capacity vertices (one
+    group) -> one compaction kernel with grid.y = frame."""
+    scene = pkg.scenes.cornell_box()
+    NF, B = 6, 3
+    single, want = _single(pkg, scene, NF)
+    r = _make(pkg, scene, B)
+    c = pkg.dist.Comm(r, 0, 1, pkg.dist.unique_id())
+    r.set_subspace(*single.get_subspace())
+    c.broadcast_subspace(0)
+    c.calibrate(passes=1)
+    r.set_light_ahead(True)
+    r.launch_light_batch(1, B)
+    q = []
+    for f in range(NF):
+        if f % B == 0:
+            r.launch_light_batch(f + 1 + B, B)
+            c.exchange_lvc_batch(B)
+        r.build_sampler()
+        q.append(f)
+        if len(q) == B:
+            r.launch_eye_batch(q); q = []
+    c.barrier()
+    c.gather_film()
+    assert np.array_equal(r.read_accum(), want)
+    c.exchange_lvc_batch(B)                                   # the batch still ahead
+    for _ in range(B):
+        r.build_sampler()
+    with pytest.raises(pkg.SpcbptError, match="pending"):     # nothing left to exchange: an error, not a stale gather
+        c.exchange_lvc_batch(B)
+    c.close()
+
+
+@pytest.mark.gpu
+def test_an_uncalibrated_shard_capacity_beyond_the_cache_is_refused(gpu, pkg):
+    """The caches are sized from a probe pass (spcbpt_lvc_set_capacity), the default shard capacity is a rank's padded scratch:
+    an exchange that would send more than a cache holds is an error that names the remedy, not an out-of-bounds read."""
+    scene = pkg.scenes.cornell_box()
+    ranks = []
+    for k in range(2):
+        r = _make(pkg, scene, 1, (3000, 400, 1))              # 400 padded slots per core: scratch 600 000 per rank
+        b, c = pkg.dist.core_range(3000, k, 2)
+        r.set_light_trace(3000, 400, 1, core_begin=b, core_count=c)
+        ranks.append(r)
+    ranks[0].set_subspace(); ranks[1].set_subspace(*ranks[0].get_subspace())
+    comms = pkg.dist.Comm.local(ranks)
+    for r in ranks:
+        r.launch("light trace", 1)
+    v, _ = ranks[0].lvc_capacity()
+    assert 0 < v < 600000
+    with pytest.raises(pkg.SpcbptError, match="calibrate"):
+        comms[0].exchange_lvc()
+    for c in comms:
+        c.close()
 
 
 @pytest.mark.gpu

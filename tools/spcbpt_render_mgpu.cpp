@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../include/spcbpt_mgpu.h"
@@ -44,8 +45,6 @@ static void core_range(int n, int rank, int world, int* begin, int* count) {
 // one rank's start-up up to (not including) the communicator
 static void rank_create(const Job& J, Rank& R) {
     hipSetDevice(R.device);
-    setenv("SPCBPT_EYE_BATCH", std::to_string(J.batch).c_str(), 1);
-    setenv("SPCBPT_RENDER_STREAMS", "1", 0);   // one long tile queue per launch; the light passes run beside it in a thin grid (bench.py: measured)
     RK(R, spcbpt_create(&J.desc, R.device, &R.ctx));
     RK(R, spcbpt_set_camera_lookat(R.ctx, J.eye, J.lookat, J.up, J.fov, (float)J.W / (float)J.H));
     RK(R, spcbpt_resize(R.ctx, J.W, J.H));
@@ -127,9 +126,17 @@ int main(int argc, char** argv) {
     std::vector<Rank> R(world);
     for (int k = 0; k < world; k++) { R[k].id = k; R[k].world = world; R[k].device = local ? 0 : k; }
     auto failed = [&]() { for (auto& r : R) if (r.rc) { fprintf(stderr, "rank %d: %s (%d)\n", r.id, r.err.c_str(), r.rc); return true; } return false; };
+    // spcbpt_create reads these: set ONCE, before any rank thread exists (setenv racing with another thread's getenv may move environ)
+    setenv("SPCBPT_EYE_BATCH", std::to_string(J.batch).c_str(), 1);
+    setenv("SPCBPT_RENDER_STREAMS", "1", 0);   // one long tile queue per launch; the light passes run beside it in a thin grid (bench.py: measured)
     auto each = [&](auto fn) {   // RCCL ranks: one host thread per GPU; local ranks: one thread, rank after rank
         if (local) { for (auto& r : R) fn(r); }
-        else { std::vector<std::thread> th; for (auto& r : R) th.emplace_back([&fn, &r]() { fn(r); }); for (auto& t : th) t.join(); }
+        else {
+            // a rank that fails stops issuing collectives and its peers would wait in RCCL for ever: the job ends there, non-zero
+            std::vector<std::thread> th;
+            for (auto& r : R) th.emplace_back([&fn, &r]() { fn(r); if (r.rc) { fprintf(stderr, "rank %d: %s (%d) -- aborting the job\n", r.id, r.err.c_str(), r.rc); fflush(stderr); _exit(1); } });
+            for (auto& t : th) t.join();
+        }
     };
     each([&](Rank& r) { rank_create(J, r); });
     if (failed()) return 1;

@@ -269,14 +269,19 @@ def test_cache_sets_are_sized_from_a_probe_pass_and_an_overflow_is_reported(gpu,
     hand-set capacity is cut off and reported at the next sync (SPCBPT_ERR_CAPACITY), never written past the end."""
     want, lvcs = _plain(pkg)
     r = _renderer(pkg)
-    assert r.lvc_capacity()[0] == 0                      # nothing allocated before the first pass
     r.launch("light trace", 1)
     n = len(r.lvc_read())
     v, sets = r.lvc_capacity()
     assert n == len(lvcs[0]) and n < v <= max(2 * n, n + 65536) + 4096 and v <= 3000 * 64 and sets >= 3
     # by hand: too small -> reported, images invalid; large enough -> the plain frames again
-    r2 = _renderer(pkg)
-    r2.lvc_set_capacity(n // 2)
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    r2 = pkg.Renderer(scene, 0)
+    r2.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+    r2.resize(W, H)
+    r2.set_light_trace(3000, 64, 1)
+    r2.lvc_set_capacity(n // 2)                          # before anything is allocated (the sets never shrink)
+    r2.set_subspace(*r.get_subspace())
     r2.launch("light trace", 1); r2.build_sampler(); r2.launch("SPCBPT_eye", 0)
     with pytest.raises(pkg.SpcbptError, match="cache overflow"):
         r2.sync()

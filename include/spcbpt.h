@@ -366,7 +366,10 @@ enum spcbpt_unit_op { SPCBPT_UNIT_BSDF = 0, SPCBPT_UNIT_TREE = 1, SPCBPT_UNIT_ST
                       SPCBPT_UNIT_UNIFORM = 5, SPCBPT_UNIT_CONNECT = 6, SPCBPT_UNIT_EYE_STEP = 7 };
 int spcbpt_debug_unit(spcbpt_ctx* ctx, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n,
                       const float* aux, int aux_floats);
-/* Enable/disable event counting in the kernels (off for timed runs). */
+/* Event counting in the kernels (off for timed runs).  1: the counting instantiations evaluate in the REFERENCE's order and charge
+ * its events (two relabels per connection and one per RMIS update, a ten-probe bisection per first sampling stage): the contract's
+ * byte table of SURVEY.md 8(d).  2: the instantiations the timed runs use, with counters -- the events that really execute (labels
+ * cached per vertex; 2 x 32 + 2 CMF values per first stage): what the roofline fraction is computed from. */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 
 /* Streams.  A context owns two non-blocking HIP streams: the one returned here (hipStream_t as void*) carries "light trace",

@@ -168,6 +168,11 @@ class Oracle:
         image is the same either way; only the event counts change."""
         self.l.orc_set_skip_null_connections(self.h, int(on))
 
+    def set_count_as_executed(self, on):
+        """Test knob, counters only: charge the classification and first-stage-sampling events the product's timed kernels execute
+        (labels cached per vertex, two counting passes per first stage) instead of the reference's."""
+        self.l.orc_set_count_as_executed(self.h, int(on))
+
     def enable_counters(self, on):
         self.l.orc_enable_counters(self.h, int(on))
 

@@ -104,6 +104,7 @@ int orc_set_light_trace(orc_ctx* c, int num_core, int core_padding, int m_per_co
 }
 int orc_set_cmf_double(orc_ctx* c, int on) { c->P.cmf_double = on != 0; return 0; }
 int orc_set_skip_null_connections(orc_ctx* c, int on) { c->P.skip_null_connections = on != 0; return 0; }
+int orc_set_count_as_executed(orc_ctx* c, int on) { c->P.count_as_executed = on != 0; return 0; }
 int orc_set_uniform_lvc(orc_ctx* c, int on) { c->P.uniform_lvc = on != 0; return 0; }
 int orc_enable_counters(orc_ctx* c, int on) { c->count_events = on != 0; return 0; }
 

@@ -125,6 +125,11 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
     // "plain BDPT", the comparator of BASELINE config 5: draw the light vertex with SubspaceSampler_device::uniformSample
     // (cuProg.h:283-289; defined in the reference, never called there) instead of the two-stage subspace sampler
     bool uniform_lvc = false;
+    // test knob, COUNTERS ONLY (values are untouched): charge the classification and first-stage events the product's timed
+    // kernels execute instead of the reference's -- every vertex is classified once under both trees when it is created and the
+    // relabels of rmis.h:58-79 / 131-151 read those labels (DIR_JUDGE 0 makes a label a property of the vertex), and
+    // the first sampling stage reads 2 x 32 CMF values + the bin's two instead of bisecting (device_lib.h: sample_first_stage)
+    bool count_as_executed = false;
 
     float Gamma(int eye_id, int light_id) const {
         if (CMFGamma && Q) {
@@ -145,11 +150,12 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
 };
 
 // labelUnit::getLabel (cuProg.h:1109-1123)
-inline int getLabel(const Params& P, float3 position, float3 normal, float3 dir, bool light_side) {
+inline int getLabel(const Params& P, float3 position, float3 normal, float3 dir, bool light_side, bool count = true) {
+    Counters* c = count ? P.counters : nullptr;
     if (light_side) {
-        if (P.light_tree) return tree_index(P.light_tree, position, normal, dir, P.counters);
+        if (P.light_tree) return tree_index(P.light_tree, position, normal, dir, c);
     } else {
-        if (P.eye_tree) return tree_index(P.eye_tree, position, normal, dir, P.counters);
+        if (P.eye_tree) return tree_index(P.eye_tree, position, normal, dir, c);
     }
     return 0;
 }
@@ -260,7 +266,7 @@ inline float getLL_pdf(const Params& P, const BDPTVertex& Mid, const BDPTVertex&
 }
 inline float tracing_weight_light(const Params& P, const BDPTVertex& Mid, const BDPTVertex& Last) {  // 58-79
     float3 inver_dir = normalize(Mid.position - Last.position);
-    int eye_label = getLabel(P, Last.position, Last.normal, inver_dir, false);
+    int eye_label = getLabel(P, Last.position, Last.normal, inver_dir, false, !P.count_as_executed);
     int light_label = Last.lastZoneId;
     float lum_sum = Last.last_lum;
     return connectRate_SOL(P, eye_label, light_label, lum_sum);
@@ -288,7 +294,7 @@ inline float3 tracing_weight_eye(const Params& P, const BDPTVertex& Mid, const B
     if (Last.depth == 1) return make_float3(0.0f);
     float3 inver_dir = normalize(Mid.position - Last.position);
     int eye_label = Last.lastZoneId;
-    int light_label = getLabel(P, Last.position, Last.normal, inver_dir, true);
+    int light_label = getLabel(P, Last.position, Last.normal, inver_dir, true, !P.count_as_executed);
     float3 lum = make_float3(1.0f);
     return connectRate_SOL(P, eye_label, light_label, lum);
 }
@@ -435,6 +441,8 @@ inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const Hi
     Mid.lastNormalProjection = fabsf(dot(Last.normal, ray_direction));
     Mid.materialId = (short)S.tri_mat[h.tri];
     Mid.subspaceId = (short)getLabel(P, Mid.position, Mid.normal, -ray_direction, light_side);
+    // (counters only) the product classifies the new vertex under the other tree at once too; an eye vertex of depth 1 never needs it
+    if (P.count_as_executed && P.counters && (light_side || Last.depth + 1 != 1)) (void)getLabel(P, Mid.position, Mid.normal, -ray_direction, !light_side);
     Mid.lastZoneId = Last.subspaceId;
     Mid.isOrigin = false;
     Mid.depth = Last.depth + 1;
@@ -728,11 +736,11 @@ inline void trace_subpath(const Params& P, float3 o, float3 d, PayloadBDPTVertex
 }
 
 // binary_sample (cuProg.h:245-264) — bespoke bisection, restated exactly (q9)
-inline int binary_sample(const Params& P, const float* cmf, int size, uint32_t& seed, float& pmf) {
+inline int binary_sample(const Params& P, const float* cmf, int size, uint32_t& seed, float& pmf, bool count = true) {
     float index = rnd(seed) * 1.0f;
     int mid = size / 2 - 1, l = 0, r = size;
     while (r - l > 1) {
-        if (P.counters) P.counters->cmf_probes++;
+        if (P.counters && count) P.counters->cmf_probes++;
         if (index < cmf[mid]) r = mid + 1;
         else l = mid + 1;
         mid = (l + r) / 2 - 1;
@@ -755,7 +763,8 @@ inline const BDPTVertex& uniformSample(const Params& P, uint32_t& seed, float& s
 }
 inline int sampleFirstStage(const Params& P, int eye_subspace, uint32_t& seed, float& sample_pmf) {  // cuProg.h:290-301
     int begin_index = eye_subspace * SPCBPT_NUM_SUBSPACE;
-    return binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf);
+    if (P.count_as_executed && P.counters) P.counters->cmf_probes += 66;   // two counting passes over 32 values + the bin's two
+    return binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf, !P.count_as_executed);
 }
 
 // connectVertex_SPCBPT (raygen.cu:253-303)

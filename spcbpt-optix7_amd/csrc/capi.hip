@@ -255,7 +255,7 @@ int Context::probe_lvc_capacity() {
     kp.work_counter = d_work_counter + kMaxRender;
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), stream));
     if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
-    launch_light_trace(kp, tree_has_direction, light_blocks, stream);
+    launch_light_trace(kp, tree_has_direction ? 1 : 0, light_blocks, stream);
     HIP_TRY(this, hipGetLastError());
     std::vector<int> h((size_t)lt.core_count);
     HIP_TRY(this, hipMemcpyAsync(h.data(), d_core_counts, h.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -380,7 +380,7 @@ int Context::launch_light(uint32_t frame) {
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
     if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
     time_begin("light_trace", ls);
-    launch_light_trace(kp, counting || tree_has_direction, light_blocks, ls);   // direction trees: the generic instantiation (no label caching)
+    launch_light_trace(kp, kernel_variant(), light_blocks, ls);   // direction trees: the generic instantiation (no label caching)
     time_end();
     HIP_TRY(this, hipGetLastError());
     // compaction: exclusive scan of per-core counts (+1 sentinel gives the total) -> offsets
@@ -500,7 +500,7 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     kp.work_counter = d_work_counter + kMaxRender + 1;   // the second lane's queue head
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
     time_begin("light_trace", ls);
-    launch_light_trace(kp, counting || tree_has_direction, grid_cap, ls);
+    launch_light_trace(kp, kernel_variant(), grid_cap, ls);
     time_end();
     kp.n_lframes = 0;
     HIP_TRY(this, hipGetLastError());
@@ -734,7 +734,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         kp.n_tiles = (uint32_t)render_tile_count(kp);
         kp.work_counter = d_work_counter + rk;
         HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
-        const bool generic = counting || tree_has_direction;
+        const int generic = kernel_variant();
         if (!blocks_per_cu[generic]) {
             blocks_per_cu[generic] = spcbpt_blocks_per_cu(generic);
             // developer knob (occupancy experiments): fewer resident blocks per CU than the kernel's resources allow
@@ -754,7 +754,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         // 8.15 / 8.19 / 8.43 ms at those shares, so 94 % it is.  A policy that looks whether the previous eye kernel is still running does
         // not work: by the time the host has the vertex count it waited for, that kernel has drained.
         // SPCBPT_GRID_PERCENT fixes the share; SPCBPT_TILES_PER_WAVE bounds the waves by the tile count (experiments).
-        const bool generic = counting || tree_has_direction;
+        const int generic = kernel_variant();
         int max_blocks = num_cus * blocks_per_cu[generic];
         if (tiles_per_wave > 1) max_blocks = std::max(1, std::min(max_blocks, (int)(kp.n_tiles / (uint32_t)(4 * tiles_per_wave))));
         const int percent = grid_percent > 0 ? grid_percent : (n_render > 1 ? 94 : 100);
@@ -814,7 +814,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     kp.work_counter = d_work_counter + rk;
     kp.result = nullptr; kp.subframe = subframes[0];
     HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
-    if (!blocks_per_cu[0]) blocks_per_cu[0] = spcbpt_blocks_per_cu(false);
+    if (!blocks_per_cu[0]) blocks_per_cu[0] = spcbpt_blocks_per_cu(0);
     int max_blocks = num_cus * blocks_per_cu[0];
     // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile -- few,
     // since they run as a thin grid (launch_light_batch): 97 % (64 steps on one GPU: 5.76 ms per step at 94 %, 5.69 at 97, 5.67 at 100;
@@ -1482,7 +1482,7 @@ int spcbpt_reset_counters(spcbpt_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->d_counters + C_W_START_MIN, 0xff, sizeof(unsigned long long), c->stream));
     return SPCBPT_OK;
 }
-int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; return SPCBPT_OK; }
+int spcbpt_enable_counters(spcbpt_ctx* c, int on) { CTX_CHECK(c); c->counting = on != 0; c->count_executed = on == 2; return SPCBPT_OK; }
 
 int spcbpt_stream(spcbpt_ctx* c, void** s) { CTX_CHECK(c); if (!s) return SPCBPT_ERR_INVALID_ARG; *s = (void*)c->stream; return SPCBPT_OK; }
 // Light passes may run ahead of the exchange / sampler build (a sharded job launches frame f + 1's light pass before it

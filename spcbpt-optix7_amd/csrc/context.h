@@ -178,13 +178,15 @@ struct Context {
     uint32_t* h_wf_counts = nullptr;   // pinned mirror of wf.counts for the early-exit probe
     bool eye_megakernel = true;        // SPCBPT_EYE_PASS=wavefront selects the per-phase kernels of wavefront.hip instead
     int wf_bounces_last = 0;           // bounces launched by the last wavefront frame (diagnostics)
-    int num_cus = 0, blocks_per_cu[2] = {0, 0};
+    int num_cus = 0, blocks_per_cu[3] = {0, 0, 0};   // per kernel variant
     int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 94 with several render streams, else 100 (launch_render)
     int light_blocks = -1;             // persistent grid of the light pass (SPCBPT_LIGHT_BLOCKS; default: one block per CU)
     int light_batch_blocks = -1;       // ... of a batched light pass (SPCBPT_LIGHT_BATCH_BLOCKS; 0 = in proportion to the light paths per pixel, >= 16: launch_light_batch)
     int tiles_per_wave = 1;            // lower bound of 8x8 tiles per persistent wave (SPCBPT_TILES_PER_WAVE)
     unsigned long long* d_counters = nullptr;
     bool counting = false, timing = false;
+    bool count_executed = false;       // spcbpt_enable_counters(ctx, 2): count with the TIMED kernels' instantiations (label caching) instead of the reference's order
+    int kernel_variant() const { return tree_has_direction ? 1 : (counting ? (count_executed ? 2 : 1) : 0); }   // kernels.h: launch_spcbpt
     std::vector<TimedSpan> spans;
     std::map<std::string, std::pair<double, int>> times;
 

@@ -698,7 +698,7 @@ SPC_DEV int uniform_sample(const int32_t* jump, int vertex_count, uint32_t& seed
 // counting passes over 32 values each find in two round trips (coarse: every 32nd entry; fine: the 32 entries of that
 // segment; 8 independent 16-B loads per pass), plus one for the two CMF values of the pmf.  Same bin, same pmf, same random
 // number; the probe counter (algorithmic bytes) is charged what the bisection would have probed.
-template <bool COUNT>
+template <bool COUNT, bool EXEC = false>   // EXEC: charge the 2 x 32 + 2 values the counting form really reads, not the bisection's probes
 SPC_DEV int sample_first_stage(const KParams& p, int eye_subspace, uint32_t& seed, float& pmf, Counts<COUNT>& cn) {
     // a caller-supplied matrix with a decreasing row (not a CMF) keeps the bisection, whose answer is then its own definition
     if (!p.cmf_gamma2) return binary_sample(p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, seed, pmf, cn);
@@ -719,7 +719,8 @@ SPC_DEV int sample_first_stage(const KParams& p, int eye_subspace, uint32_t& see
     const float* row = p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE;
     const float hi = row[l], lo = l == 0 ? 0.0f : row[l - 1];
     pmf = l == 0 ? hi : hi - lo;
-    if (COUNT) {  // the probes of the reference's bisection on its way to bin l
+    if (COUNT && EXEC) cn.add(C_CMF, 66);
+    if (COUNT && !EXEC) {  // the probes of the reference's bisection on its way to bin l
         int mid = SPCBPT_NUM_SUBSPACE / 2 - 1, a = 0, b = SPCBPT_NUM_SUBSPACE;
         while (b - a > 1) {
             cn.add(C_CMF);

@@ -8,12 +8,12 @@
 namespace spc {
 
 int render_thread_count(const KParams& p);
-void launch_spcbpt(const KParams& p, bool count, int max_blocks, hipStream_t s);
-int spcbpt_blocks_per_cu(bool count);
+void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s);   // 0 timed, 1 reference order + counters (generic), 2 timed + counters
+int spcbpt_blocks_per_cu(int variant);
 int render_tile_count(const KParams& p);
 void launch_pt(const KParams& p, bool count, hipStream_t s);
 void launch_film_merge(const KParams& p, hipStream_t s);
-void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s);
+void launch_light_trace(const KParams& p, int variant, int max_blocks, hipStream_t s);
 struct CompactBatch { LightVertex* lvc[kMaxBatchFrames]; int* counts[kMaxBatchFrames]; };   // per frame of a batched light pass: compact LVC + (vertex_count, path_count) of its set
 void launch_lvc_compact_batch(const LightVertex* scratch, const int* core_counts, const int* core_offsets, const int* path_counts, int core_count,
                               int core_padding, int n, const CompactBatch& dst, int capacity, uint32_t* overflow, hipStream_t s);

@@ -46,7 +46,10 @@ static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye
 // buffer: p.frames) share one queue, so a wave keeps regenerating across frame boundaries and the drain phase is paid once per
 // batch instead of once per frame -- what a rank's small share of a sharded frame needs.  Every pixel-sample is computed exactly
 // as in a launch of its own frame; BATCH = false compiles to the single-frame kernel unchanged.
-template <bool COUNT, bool BATCH>
+// CACHE: label caching (device_lib.h).  <false, *, true> are the timed kernels; <true, false, false> evaluates in the reference's
+// order and charges its events (the contract's byte table, and the generic form for classifier trees with direction nodes);
+// <true, false, true> counts the events the TIMED kernels execute (roofline.frac: what runs, not what the reference would run).
+template <bool COUNT, bool BATCH, bool CACHE>
 __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     // everything else a wave keeps in LDS sits in ONE record per wave: every field is then the wave's base (one SGPR) plus a
@@ -94,7 +97,6 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
     w.done = false; w.seed = 0; w.origin = w.dir = w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
     cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0;
     cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0; cur.lsub = 0;
-    constexpr bool CACHE = !COUNT;   // device_lib.h: label caching (the counting build evaluates in the reference's order)
 
     // software pipeline: the vertex built in iteration i is connected in iteration i + 1, in the same traversal pass that
     // extends the path by its next segment (the next direction is drawn before the connections, hit_program.cu:324-337)
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                             const int vc = f_counts[0];
                             if (vc > 0) lslot = uniform_sample(f_jump, vc, w.seed, pmf2);
                         } else {
-                            const int l = sample_first_stage(p, cur.sub, w.seed, pmf1, cn);
+                            const int l = sample_first_stage<COUNT, CACHE>(p, cur.sub, w.seed, pmf1, cn);
                             const DSubspace ss = f_subspace[l];
                             if (ss.size != 0) {
                                 const int k = binary_sample(f_cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
 // path with 1-2 live lanes; regenerating waves do the same work with a quarter of the resident blocks, which matters because
 // the pass shares the GPU with persistent eye kernels that never yield a block slot.  What a core computes and where it
 // stores it does not depend on the lane that runs it: seeds come from the global core index, slots from the core's range.
-template <bool COUNT>
+template <bool COUNT, bool CACHE>
 __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     const DeviceScene& S = p.scene;
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     int new_label, eye_label;
                     const f3 last_pos = ld3(last.position);
                     uint32_t own_eye_label = 0u;   // device_lib.h: label caching -- the new vertex's own eye-tree label + 1
-                    if (!COUNT) {
+                    if (CACHE) {
                         int own;
                         tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, g.P, N, inv_dir, true, new_label, own, cn);
                         own_eye_label = (uint32_t)own + 1u;
@@ -1274,14 +1276,17 @@ static inline int render_blocks(const KParams& p) {
 }
 int render_thread_count(const KParams& p) { return render_blocks(p) * BLOCK; }
 
-void launch_spcbpt(const KParams& p, bool count, int max_blocks, hipStream_t s) {
+// variant: 0 = timed (label caching, no counters), 1 = reference order with counters (also the generic form), 2 = the timed
+// kernel's own events, counted
+void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s) {
     // persistent grid: at most `max_blocks` (resident) blocks, never more than the tile queue can feed
     const int tiles = (int)p.n_tiles;
     if (tiles <= 0) return;
     int blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    if (count) hipLaunchKernelGGL((k_spcbpt<true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL((k_spcbpt<false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (variant == 1) hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else if (variant == 2) hipLaunchKernelGGL((k_spcbpt<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_spcbpt<false, false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 // p.frames / p.n_frames describe the batch; p.n_tiles is the tile count of ONE frame
 int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
@@ -1294,12 +1299,13 @@ int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
 void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
     const int blocks = spcbpt_batch_blocks(p, max_blocks);
     if (blocks <= 0) return;
-    hipLaunchKernelGGL((k_spcbpt<false, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
+    hipLaunchKernelGGL((k_spcbpt<false, true, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
 }
-int spcbpt_blocks_per_cu(bool count) {
+int spcbpt_blocks_per_cu(int variant) {
     int n = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false>, BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false>, BLOCK, 0);
+    hipError_t e = variant == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, false>, BLOCK, 0)
+                 : variant == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, true>, BLOCK, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true>, BLOCK, 0);
     return e == hipSuccess && n > 0 ? n : 1;
 }
 int render_tile_count(const KParams& p) {
@@ -1337,11 +1343,12 @@ int light_trace_blocks(const KParams& p, int max_blocks) {
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     return (int)blocks;
 }
-void launch_light_trace(const KParams& p, bool count, int max_blocks, hipStream_t s) {
+void launch_light_trace(const KParams& p, int variant, int max_blocks, hipStream_t s) {   // variants as launch_spcbpt
     const int blocks = light_trace_blocks(p, max_blocks);   // p.work_counter (the core queue head) must have been zeroed on `s`
     if (blocks <= 0) return;
-    if (count) hipLaunchKernelGGL(k_light_trace<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL(k_light_trace<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (variant == 1) hipLaunchKernelGGL((k_light_trace<true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else if (variant == 2) hipLaunchKernelGGL((k_light_trace<true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_light_trace<false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
                         LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, int capacity, uint32_t* overflow,

@@ -253,7 +253,7 @@ def test_c3_full_size_bench_scene_properties_and_counters(bench_scene, pkg, ob):
     ratio = cx["tree_nodes"] / cg["tree_nodes"]
     print("tree nodes per eye path: reference order %.1f, executed %.1f; cmf probes %.1f / %.1f" % (
         cg["tree_nodes"] / cg["eye_paths"], cx["tree_nodes"] / cx["eye_paths"], cg["cmf_probes"] / cg["eye_paths"], cx["cmf_probes"] / cx["eye_paths"]))
-    assert 0.15 < ratio < 0.45, ratio          # ~22 of ~87 nodes: the relabels are gone, the per-vertex descents stay
+    assert 0.3 < ratio < 0.8, ratio            # eye pass 87 -> 33 nodes per path (the relabels are gone, the per-vertex descents stay); the light pass classifies under both trees
     s2 = image_parity(r.read_accum()[band_rows_mask(H, stride)][..., :3], acc_ref_order[..., :3])
     assert s2["frac_close"] >= 0.999, s2       # cached labels ARE the re-derived labels (the rare miss: a label within rounding of a split)
     r.clear_accum()

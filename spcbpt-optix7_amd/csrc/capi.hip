@@ -95,7 +95,8 @@ int Context::check_diag() {
     uint32_t h[4] = {0, 0, 0, 0};
     HIP_TRY(this, hipMemcpy(h, d_diag, sizeof(h), hipMemcpyDeviceToHost));
     if (h[0] == 0 && h[1] == 0 && h[2] == 0) return 0;
-    HIP_TRY(this, hipMemset(d_diag, 0, sizeof(h)));
+    HIP_TRY(this, hipMemsetAsync(d_diag, 0, sizeof(h), stream));   // (a null-stream memset is not ordered against the context's non-blocking streams)
+    HIP_TRY(this, hipStreamSynchronize(stream));
     if (h[0] == 0 && h[1] == 0) {
         error = "light-vertex cache overflow: a light pass produced more vertices than a buffer set holds (" + std::to_string(lvc_capacity) +
                 ", sized from a probe pass); frames since the last sync are invalid -- fix the capacity with spcbpt_lvc_set_capacity";
@@ -1626,7 +1627,7 @@ int spcbpt_debug_unit(spcbpt_ctx* c, int op, const uint32_t* in, int in_words, u
     if (e == hipSuccess) e = dev_alloc(&d_out, (size_t)n * out_words);
     if (e == hipSuccess && aux && aux_floats > 0) e = dev_alloc(&d_aux, (size_t)aux_floats);
     if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * in_words * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(d_out, 0, (size_t)n * out_words * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)n * out_words * 4, c->stream);   // on the kernel's (non-blocking) stream: a memset on the null stream is not ordered before it
     if (e == hipSuccess && d_aux) e = hipMemcpy(d_aux, aux, (size_t)aux_floats * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         KParams kp = c->kp;

@@ -700,7 +700,6 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     kp.subframe = frame; kp.row_begin = r0; kp.row_end = std::min(r1, (int)kp.height); kp.row_step = rs;
     kp.counters = counting ? d_counters : nullptr;
     rk = (rk + 1) % n_render;   // consecutive render launches rotate through the render streams (see context.h)
-    if (spcbpt_alg && !eye_megakernel && !full_mis) rk = 0;   // the per-phase kernels share one set of queues: no overlap between their frames
     rstream = rstreams[rk];
     kp.result = d_result[rk];
     if (spcbpt_alg) {
@@ -708,17 +707,6 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         kp.lvc = set_lvc[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset];
         kp.jump = reinterpret_cast<const int32_t*>(set_vals2[eset]); kp.sampler_counts = set_counts[eset];
         if (rstream != stream && ev_sampler_set[eset]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[eset], 0));
-    }
-    if (spcbpt_alg && !eye_megakernel && !full_mis) {
-        kp.n_tiles = (uint32_t)render_tile_count(kp);
-        time_begin(name, rstream);
-        int rcw = launch_wavefront();
-        time_end();
-        if (rcw) return rcw;
-        HIP_TRY(this, hipGetLastError());
-        HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
-        ev_render_set[eset] = true;
-        return finish_frame();
     }
     int rc = ensure_spill((size_t)render_thread_count(kp), true);
     if (rc) return rc;
@@ -780,7 +768,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     if (n > (int)built_sets.size()) { error = "launch_eye_batch: fewer samplers have been built (and are still intact) than frames were asked for"; return SPCBPT_ERR_STATE; }
     // (SPCBPT_EYE_BATCH at spcbpt_create only sizes the ring of buffer sets so that batches, light passes ahead and builds do not
     // wait for each other; correctness rests on the per-set events and on `built_sets` naming intact samplers)
-    if (!eye_megakernel || counting) { error = "launch_eye_batch: megakernel eye pass without counters only"; return SPCBPT_ERR_STATE; }
+    if (counting) { error = "launch_eye_batch: not with event counters enabled (count with spcbpt_launch per frame)"; return SPCBPT_ERR_STATE; }
     if (tree_has_direction) { error = "launch_eye_batch: the batched kernel caches vertex labels, which needs classifier trees without direction nodes (use spcbpt_launch per frame)"; return SPCBPT_ERR_STATE; }
     if (kp.width >= 65536u || kp.height >= 65536u) { error = "launch_eye_batch: image too large"; return SPCBPT_ERR_INVALID_ARG; }
     if (rs < 1) rs = 1;
@@ -858,59 +846,6 @@ int Context::finish_frame() {
     return 0;
 }
 
-// Wavefront eye pass: state arrays for `slots` path slots (a multiple of 64) in one allocation.
-int Context::ensure_wf(size_t slots) {
-    if (slots > wf_slots_capacity) {
-        HIP_TRY(this, hipStreamSynchronize(rstream));
-        dev_free(d_wf_block);
-        d_wf_block = nullptr;
-        // float4 per slot: WF_ARRAYS state arrays + 3 x (conn_ray, conn_rec, contrib); dwords per slot: 2 queues + 3 vis
-        const size_t words = slots * (4 * (size_t)(WF_ARRAYS + 9) + 5) + (size_t)WF_MAX_BOUNCES * WFC_ROW;
-        HIP_TRY(this, dev_alloc(&d_wf_block, words));
-        wf_slots_capacity = slots;
-        float* q = d_wf_block;
-        for (int a = 0; a < WF_ARRAYS; a++) { wf.a[a] = q; q += 4 * slots; }
-        wf.conn_ray = q; q += 12 * slots;
-        wf.conn_rec = reinterpret_cast<uint32_t*>(q); q += 12 * slots;
-        wf.contrib = q; q += 12 * slots;
-        wf.queue[0] = reinterpret_cast<uint32_t*>(q); q += slots;
-        wf.queue[1] = reinterpret_cast<uint32_t*>(q); q += slots;
-        wf.vis = reinterpret_cast<uint32_t*>(q); q += 3 * slots;
-        wf.counts = reinterpret_cast<uint32_t*>(q);
-    }
-    if (!h_wf_counts) HIP_TRY(this, hipHostMalloc(reinterpret_cast<void**>(&h_wf_counts), (size_t)WF_MAX_BOUNCES * WFC_ROW * sizeof(uint32_t)));
-    wf.n_slots = (uint32_t)slots;
-    return 0;
-}
-
-// One frame of "SPCBPT_eye" as a stream of per-phase kernels.  Launch sizes never depend on a host read-back: every kernel
-// is a fixed persistent grid that pulls from device-side cursors.  The host only probes the queue length every 8 bounces
-// to stop issuing (empty) launches once every path has ended.
-int Context::launch_wavefront() {
-    const size_t slots = (size_t)kp.n_tiles * 64;
-    if (slots == 0) return 0;
-    int rc = ensure_wf(slots);
-    if (rc) return rc;
-    rc = ensure_spill(slots * SPCBPT_CONNECTION_N, true);  // one traversal stack per shadow-ray record
-    if (rc) return rc;
-    HIP_TRY(this, hipMemsetAsync(wf.counts, 0, (size_t)WF_MAX_BOUNCES * WFC_ROW * sizeof(uint32_t), rstream));
-    launch_wf_gen(kp, wf, counting, rstream);
-    size_t bound = slots;
-    int b = 0;
-    for (; b < WF_MAX_BOUNCES - 1; b++) {
-        launch_wf_bounce(kp, wf, b, counting, bound, rstream);
-        if ((b & 7) == 7) {
-            HIP_TRY(this, hipMemcpyAsync(h_wf_counts, wf.counts + (size_t)(b + 1) * WFC_ROW, sizeof(uint32_t), hipMemcpyDeviceToHost, rstream));
-            HIP_TRY(this, hipStreamSynchronize(rstream));
-            bound = h_wf_counts[0];
-            if (bound == 0) { b++; break; }
-        }
-    }
-    wf_bounces_last = b;
-    launch_wf_film(kp, wf, rstream);
-    return 0;
-}
-
 // The minimal VALID subspace tuple: single-leaf trees, Q from a few light passes, Gamma rows ~ Q.
 int Context::install_minimal_tuple() {
     spcbpt_tree_node leaf;
@@ -960,7 +895,7 @@ Context::~Context() {
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); }
     dev_free(d_set_counts_all); dev_free(lb_scratch); dev_free(lb_core_counts); dev_free(lb_core_offsets); dev_free(lb_path_counts); dev_free(lb_spill);
-    dev_free(d_counters); dev_free(d_diag); dev_free(d_work_counter); dev_free(d_wf_block); if (h_wf_counts) (void)hipHostFree(h_wf_counts); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
+    dev_free(d_counters); dev_free(d_diag); dev_free(d_work_counter); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
     for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
     if (h_frames) (void)hipHostFree(h_frames);
     for (int g2 = 0; g2 < 2; g2++) if (ev_import[g2]) (void)hipEventDestroy(ev_import[g2]);
@@ -1155,10 +1090,6 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
         c->num_cus = prop.multiProcessorCount;
-    }
-    {
-        const char* mode = getenv("SPCBPT_EYE_PASS");
-        c->eye_megakernel = !(mode && std::string(mode) == "wavefront");
     }
     CREATE_TRY(dev_alloc(&c->d_work_counter, (size_t)Context::kMaxRender + 2));   // tile queues of the render streams + core queues of the two light lanes
     CREATE_TRY(dev_alloc(&c->d_diag, (size_t)4));
@@ -1605,7 +1536,6 @@ int spcbpt_trace_any(spcbpt_ctx* c, const float* rays, int n, int32_t* out_visib
 int spcbpt_set_connection_sampler(spcbpt_ctx* c, int mode) {
     CTX_CHECK(c);
     if (mode != SPCBPT_SAMPLER_SUBSPACE && mode != SPCBPT_SAMPLER_UNIFORM) { c->error = "set_connection_sampler: unknown mode"; return SPCBPT_ERR_INVALID_ARG; }
-    if (mode == SPCBPT_SAMPLER_UNIFORM && !c->eye_megakernel) { c->error = "set_connection_sampler: uniformSample is built into the megakernel eye pass only"; return SPCBPT_ERR_STATE; }
     if (c->sync_all()) return SPCBPT_ERR_HIP;
     c->kp.uniform_lvc = mode;
     return SPCBPT_OK;

@@ -171,13 +171,6 @@ struct Context {
     int check_diag();                  // after a sync: SPCBPT_ERR_STATE if a kernel dropped stack entries since the last check
     // instrumentation
     uint32_t* d_work_counter = nullptr;
-    // wavefront eye pass (wavefront.hip): path state, queues and per-bounce counters
-    WfState wf = {};
-    float* d_wf_block = nullptr;       // one allocation carved into the WfState arrays
-    size_t wf_slots_capacity = 0;
-    uint32_t* h_wf_counts = nullptr;   // pinned mirror of wf.counts for the early-exit probe
-    bool eye_megakernel = true;        // SPCBPT_EYE_PASS=wavefront selects the per-phase kernels of wavefront.hip instead
-    int wf_bounces_last = 0;           // bounces launched by the last wavefront frame (diagnostics)
     int num_cus = 0, blocks_per_cu[3] = {0, 0, 0};   // per kernel variant
     int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 94 with several render streams, else 100 (launch_render)
     int light_blocks = -1;             // persistent grid of the light pass (SPCBPT_LIGHT_BLOCKS; default: one block per CU)
@@ -196,8 +189,6 @@ struct Context {
     void resolve_spans();
     int ensure_spill(size_t threads, bool render = false);
     int ensure_temp(size_t bytes);
-    int ensure_wf(size_t slots);
-    int launch_wavefront();
     int ensure_lvc_capacity(size_t n);
     int upload_tree(const spcbpt_tree_node* t, int n, float*& d_tree, std::vector<spcbpt_tree_node>& host_copy);
     int install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_tree_node* lt, int nl, const float* q, const float* g);

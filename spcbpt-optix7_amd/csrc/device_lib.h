@@ -656,8 +656,7 @@ SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA
 // lock-step pair of descents the vertex step already pays) and carry the labels along: EyeVertex::lsub, and the light vertex's
 // eye-tree label + 1 in spcbpt_light_vertex::pad (0 = not computed: an imported cache; the connection then descends as before).
 // 13 of the 17 descents per eye path disappear, and with them the longest dependent fetch chain of the connect phase; every label
-// is the label the reference computes.  CACHE = false (the counting instantiations, the per-function harness, the wavefront
-// form) evaluates in the reference's order and charges its events; a caller-supplied tree WITH direction nodes (type 2) runs on
+// is the label the reference computes.  CACHE = false (the counting instantiations, the per-function harness) evaluates in the reference's order and charges its events; a caller-supplied tree WITH direction nodes (type 2) runs on
 // those instantiations (Context::tree_has_direction).
 
 // Gamma(e,l)/Q[l] (optixPathTracer.h:173-189); the product always runs with a full tuple installed

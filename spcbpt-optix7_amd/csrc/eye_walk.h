@@ -1,4 +1,4 @@
-// Eye-walk steps shared by the megakernel, the wavefront kernels and the pretrace kernel.
+// Eye-walk steps shared by the megakernel, the per-function harness and the pretrace kernel.
 #pragma once
 #include "device_lib.h"
 

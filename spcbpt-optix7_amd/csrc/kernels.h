@@ -47,11 +47,6 @@ void launch_spcbpt_no_rmis(const KParams& p, hipStream_t s);
 // per-function harness (unit.hip)
 void launch_unit(const KParams& p, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n, const float* aux, hipStream_t s);
 
-// wavefront eye pass (wavefront.hip)
-void launch_wf_gen(const KParams& p, const WfState& wf, bool count, hipStream_t s);
-void launch_wf_bounce(const KParams& p, const WfState& wf, int bounce, bool count, size_t bound, hipStream_t s);
-void launch_wf_film(const KParams& p, const WfState& wf, hipStream_t s);
-
 #ifndef SPC_STACK_LDS
 #define SPC_STACK_LDS 16
 #endif

@@ -156,37 +156,4 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     uint32_t* diag;                // [0] traversal-stack entries dropped (deeper than LDS + spill): reported by the host as an error
 };
 
-// Wavefront ("streaming") eye pass: path state lives in HBM as SoA float4 arrays indexed by path slot
-// (slot = tile * 64 + pixel-in-tile), stages exchange queues of slots.  288 GB of HBM at 8 TB/s make the
-// state traffic (~0.4 KB per path per bounce) negligible next to the gathers of the stages themselves.
-enum WfArray {
-    WF_DIR = 0,   // next ray direction.xyz, RNG seed
-    WF_NEXT,      // NextVertex.flux.xyz, NextVertex.singlePdf
-    WF_POS,       // vertex position.xyz (= next ray origin), lastNormalProjection
-    WF_NRM,       // vertex normal.xyz, material id
-    WF_COL,       // vertex colour.xyz, pdf
-    WF_LASTPOS,   // previous vertex position.xyz, singlePdf
-    WF_FLUX,      // flux.xyz, subspace | lastZone << 16
-    WF_R3,        // RMIS_pointer_3.xyz, depth
-    WF_RESULT,    // radiance accumulated by the path.xyz, pixel x | y << 16 (0xffffffff = slot outside the image)
-    WF_HIT,       // closest hit: t, triangle (-1 = miss), u, v
-    WF_ARRAYS
-};
-enum WfCounter {  // one row of counters per bounce, zeroed at frame start
-    WFC_EXT_COUNT = 0,  // paths to extend at this bounce
-    WFC_VIS_COUNT,      // unoccluded connections of this bounce
-    WFC_ROW = 4
-};
-static constexpr int WF_MAX_BOUNCES = 52;  // depth > 50 ends a path (raygen.cu:361): at most 51 extensions
-struct WfState {
-    float* a[WF_ARRAYS];    // n_slots float4 each
-    float* conn_ray;        // [3 n_slots] float4: shadow-ray direction.xyz, length
-    uint32_t* conn_rec;     // [3 n_slots] uint4: LVC slot, pmf (bits), path slot, connection index
-    float* contrib;         // [3 n_slots] float4: contribution of connection (path slot * 3 + index), folded by the next stage
-    uint32_t* queue[2];     // extension queues (path slots), ping-pong per bounce
-    uint32_t* vis;          // [3 n_slots] indices of unoccluded connection records (compacted)
-    uint32_t* counts;       // [WF_MAX_BOUNCES][WFC_ROW]
-    uint32_t n_slots;
-};
-
 }  // namespace spc

@@ -187,34 +187,6 @@ def test_spcbpt_image_matches_oracle(gpu, pkg, ob, scene_name):
     assert abs(a.mean() - b.mean()) / b.mean() < 5e-3
 
 
-def test_wavefront_eye_pass_matches_oracle_and_megakernel(gpu, pkg, ob, monkeypatch):
-    """SPCBPT_EYE_PASS=wavefront (csrc/wavefront.hip: per-phase kernels over HBM queues) is held to the same bar as the
-    megakernel: >= 99 % of pixels within 2e-3 of the oracle at equal seeds, and the same event counters as the megakernel
-    (rays, vertices, connections exact; traversal work within 0.1 %: the two forms contract FMAs differently)."""
-    scene = pkg.scenes.cornell_box()
-    out = {}
-    for mode in ("wavefront", "megakernel"):
-        monkeypatch.setenv("SPCBPT_EYE_PASS", mode)
-        r, o = _pair(pkg, ob, scene, 96, 64)
-        tup = minimal_tuple(o, 2)
-        r.set_subspace(*tup); o.set_subspace(*tup)
-        o.set_cmf_double(True)
-        r.enable_counters(True); r.reset_counters()
-        for f in range(4):
-            r.render_frame("SPCBPT_eye", f)
-            if mode == "wavefront": o.render_frame("SPCBPT_eye", f)
-        out[mode] = (r.read_accum()[..., :3].copy(), r.counters())
-        if mode == "wavefront":
-            s = image_parity(out[mode][0], o.read_accum()[..., :3])
-            assert s["frac_close"] >= 0.99 and s["mean_rel"] < 5e-3, s
-    cw, cm = out["wavefront"][1], out["megakernel"][1]
-    for k in ("closest_rays", "shadow_rays", "surface_vertices", "connections", "pixel_samples", "cmf_probes"):
-        assert abs(cw[k] - cm[k]) <= 2e-4 * cm[k], (k, cw[k], cm[k])
-    for k in ("node_visits", "tri_tests", "tree_nodes"):
-        assert abs(cw[k] - cm[k]) <= 2e-3 * max(1, cm[k]), (k, cw[k], cm[k])
-    s = image_parity(out["wavefront"][0], out["megakernel"][0])
-    assert s["frac_close"] >= 0.99, s
-
 
 def test_spcbpt_with_multi_leaf_trees_and_textures(gpu, pkg, ob):
     """Classification, stage-1 sampling over many light subspaces and textured materials, on a bedroom-class scene."""

@@ -44,15 +44,37 @@ def tuple_from_q(pkg, q64):
 
 
 def image_parity(a: np.ndarray, b: np.ndarray, rel: float = 2e-3, abs_: float = 1e-4):
-    """Per-pixel comparison of two linear accum images rendered with the same seeds."""
+    """Per-pixel comparison of two linear accum images rendered with the same seeds.
+
+    Besides the share of pixels within tolerance (`frac_close`) it describes the pixels OUTSIDE it, so that a test cannot pass
+    with "3 % of the pixels differ by anything".  Two images of the same estimator at the same seeds differ beyond rounding only
+    where a path took another turn -- a hit within rounding of a triangle edge, a Russian-roulette or resampling decision within
+    rounding of its threshold -- and such a pixel then holds another SAMPLE of the same distribution: finite, of ordinary
+    magnitude, and unbiased.  So for the outliers: `finite` (no NaN / Inf on either side), `out_abs_share` = sum |a - b| over them
+    / sum |b| over the image (ordinary magnitude: about the share of outliers itself, not orders above it) and `out_signed_share`
+    = sum (a - b) over them / sum b (no systematic shift hiding in the tail)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
+    finite = bool(np.isfinite(a).all() and np.isfinite(b).all())
     d = np.abs(a - b)
     close = (d <= abs_ + rel * np.abs(b)).all(axis=-1)
     l2 = np.sqrt((d ** 2).sum(axis=-1))
+    out = ~close
+    tot = max(float(np.abs(b).sum()), 1e-30)
     return dict(frac_close=float(close.mean()), mean_a=float(a.mean()), mean_b=float(b.mean()),
                 mean_rel=float(abs(a.mean() - b.mean()) / max(b.mean(), 1e-12)),
-                rmse=float(np.sqrt((d ** 2).mean())), max_l2=float(l2.max()), p99_l2=float(np.percentile(l2, 99)))
+                rmse=float(np.sqrt((d ** 2).mean())), max_l2=float(l2.max()), p99_l2=float(np.percentile(l2, 99)),
+                finite=finite, n_out=int(out.sum()), out_abs_share=float(d[out].sum() / tot),
+                out_signed_share=float((a - b)[out].sum() / tot))
+
+
+def tails_explained(s: dict, magnitude: float = 4.0, shift: float = 2e-3) -> bool:
+    """The outliers of image_parity are other samples of the same distribution, not garbage: everything finite; their summed
+    absolute difference at most `magnitude` x their share of the pixels (two independent samples of a pixel differ by about the
+    pixel's own size; heavy-tailed scenes get a larger factor from their test); their summed SIGNED difference below `shift` of the
+    image's energy."""
+    share = 1.0 - s["frac_close"]
+    return bool(s["finite"] and s["out_abs_share"] <= magnitude * share + 1e-6 and abs(s["out_signed_share"]) <= shift)
 
 
 def rmse(a, b):

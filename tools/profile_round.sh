@@ -10,11 +10,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 32 --no-cpu-baseline $BENCH_ARGS > $OUT/bench_stats.json 2> $OUT/stats.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline $BENCH_ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline $BENCH_ARGS > $OUT/bench_write.json 2> $OUT/write.log
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline $BENCH_ARGS > $OUT/bench_l2.json 2> $OUT/l2.log
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline $BENCH_ARGS > $OUT/bench_sq.json 2> $OUT/sq.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 32 --no-cpu-baseline --long-steps 0 --sync-each-frames 0 $BENCH_ARGS > $OUT/bench_stats.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline --long-steps 0 --sync-each-frames 0 $BENCH_ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline --long-steps 0 --sync-each-frames 0 $BENCH_ARGS > $OUT/bench_write.json 2> $OUT/write.log
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline --long-steps 0 --sync-each-frames 0 $BENCH_ARGS > $OUT/bench_l2.json 2> $OUT/l2.log
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --steps 32 --warmup 32 --no-cpu-baseline --long-steps 0 --sync-each-frames 0 $BENCH_ARGS > $OUT/bench_sq.json 2> $OUT/sq.log
 find $OUT -name "*.csv" | head -30
 # keep only the small per-kernel summaries + counter rows of our kernels (the raw traces are large)
 for d in pmc_fetch pmc_write pmc_l2 pmc_sq; do

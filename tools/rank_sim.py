@@ -2,6 +2,9 @@
 step time of a rank scales with N and with the number of frames in flight (SPCBPT_RENDER_STREAMS).
   python tools/rank_sim.py N streams [steps] [--exchange] [--ahead | --ahead=D] [--batch=F] [--lbatch] [--trained]
 --lbatch: the light passes of a batch of F frames as one launch too (spcbpt_launch_light_batch), one batch ahead.
+--native: the C++ host (libspcbpt_mgpu) at world size 1 -- every call of the real frame loop is there (pack, RCCL all-gather, compaction,
+device-count sampler build), but the gather carries only this rank's own shard: what N - 1 peers add is the driver's to measure.
+--xbatch (with --native --lbatch): ONE exchange per light batch (spcbpt_comm_exchange_lvc_batch) instead of one per frame.
 --exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
 all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
 rate when its share of the image is small."""
@@ -41,6 +44,7 @@ if native:
     comm = p.dist.Comm(r, 0, 1, p.dist.unique_id())
     print("shard capacity after calibration:", comm.calibrate(passes=2, slack=1.5))
 lbatch = "--lbatch" in sys.argv and batch > 1
+xbatch = "--xbatch" in sys.argv and lbatch and comm is not None
 rows = (0, H, N)
 if lbatch:
     r.set_light_ahead(True)
@@ -57,11 +61,13 @@ def eye(f):
         r.launch_eye_batch(queued, rows); queued.clear()
 def step(f):
     if lbatch:
-        if f % batch == 0: r.launch_light_batch(f + 1 + batch, batch)
+        if f % batch == 0:
+            r.launch_light_batch(f + 1 + batch, batch)
+            if xbatch: comm.exchange_lvc_batch(batch)
     else: r.launch("light trace", f + 1 + depth)
     if ex is not None: ex.allgather_lvc()
     if throttle: r.sync_light()
-    if comm is not None: comm.exchange_lvc()
+    if comm is not None and not xbatch: comm.exchange_lvc()
     r.build_sampler(); eye(f)
 for f in range(batch * max(1, 8 // batch)): step(f)   # a multiple of the batch: nothing is left queued when the clock starts
 r.sync()
@@ -75,7 +81,9 @@ def timed_step(f):
     b = time.perf_counter()
     if ex is not None: ex.allgather_lvc()
     if throttle: r.sync_light()
-    if comm is not None: comm.exchange_lvc()
+    if xbatch:
+        if f % batch == 0: comm.exchange_lvc_batch(batch)
+    elif comm is not None: comm.exchange_lvc()
     c2 = time.perf_counter(); r.build_sampler()
     d = time.perf_counter(); eye(f)
     e = time.perf_counter()
@@ -87,7 +95,7 @@ t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
 print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' lbatch' if lbatch else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' + (' (one per light batch)' if xbatch else '') if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' lbatch' if lbatch else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -16,6 +16,10 @@ rows.sort()
 t0 = rows[0][0]
 for s, e, n, st in rows[-220:]:
     print(f"{(s - t0) / 1e6:10.3f} -> {(e - t0) / 1e6:10.3f}  ({(e - s) / 1e6:7.3f} ms)  {n}  s{st}")
+coll = [r for r in rows if "nccl" in r[2].lower() or "rccl" in r[2].lower() or "k_gather_compact" in r[2] or "k_pack_shards" in r[2]]
+eyes = [r for r in rows if "k_spcbpt" in r[2]]
+import collections
+print("---- exchange kernels in the trace:", dict(collections.Counter(r[2] for r in coll)), "| eye launches:", len(eyes))
 print("---- eye / light kernels only")
 for s, e, n, st in [r for r in rows if "k_spcbpt" in r[2] or "k_light_trace" in r[2]][-40:]:
     print(f"{(s - t0) / 1e6:10.3f} -> {(e - t0) / 1e6:10.3f}  ({(e - s) / 1e6:7.3f} ms)  {n}  s{st}")

@@ -155,11 +155,16 @@ typedef struct spcbpt_light_vertex {
     uint32_t path_id;  /* global light path index = core * m_per_core + k */
     /* Cached classification: the vertex's label under the EYE tree + 1, written by the light pass for surface
      * vertices; 0 = not computed (an emitter vertex, or a cache the caller assembled: write 0).  The connection code uses
-     * pad - 1 when 1 <= pad <= SPCBPT_NUM_SUBSPACE and re-derives the label by a tree descent for any other value, so a
+     * (pad & 0xffff) - 1 when that is a label (1 .. SPCBPT_NUM_SUBSPACE) and re-derives the label by a tree descent for any other value, so a
      * cache imported with a stale or uninitialised word costs time, never a wrong row of Gamma.  The label belongs to the
      * trees the cache was traced under (like subspace_id): trace a new cache after spcbpt_set_subspace. */
     uint32_t pad;
 } spcbpt_light_vertex;
+/* spcbpt_light_vertex::pad: bits 0-15 the cached eye-tree label + 1 (above); bit 31: the vertex is a direction of the environment
+ * map (BDPTVertex::type == ENV: position = its point on the sky disk, normal = minus the sky direction); bit 30: the vertex was hit
+ * straight from the environment map (BDPTVertex::isLastVertex_direction, hit_program.cu:412). */
+#define SPCBPT_LV_DIRECTION 0x80000000u
+#define SPCBPT_LV_LAST_DIRECTION 0x40000000u
 
 /* Per-subspace record of the sampler = struct Subspace (optixPathTracer.h:43-51). */
 typedef struct spcbpt_subspace {
@@ -294,6 +299,20 @@ int spcbpt_lvc_import_gathered_batch(spcbpt_ctx* ctx, const void* shards, const 
 int spcbpt_film_pack_bands(spcbpt_ctx* ctx, int rank, int world, void* packed, void* hip_stream);
 int spcbpt_film_unpack_bands(spcbpt_ctx* ctx, int world, const void* packed_all, void* out_image, void* hip_stream);
 int spcbpt_image_size(spcbpt_ctx* ctx, int* width, int* height);
+/* The environment map as one more light (row f4; upstream "unfinished", readme.md:29 -- what its live code does is built):
+ * env_params_setup (optixPathTracer.cpp:431-461) + the ENV entry of LightSource_shift (scene_shift.cpp:108-153).  `rgba` = width x
+ * height RGBA floats as the .hdr file stores them (row 0 = top; spcbpt_hdr_load); the context keeps the row-flipped texture
+ * HDRLoader::loadTexture makes and the sampling CMF envMapCMFBuild makes.  Light sub-paths then start on the sky with probability
+ * 1 / n_lights (cuProg.h:611-666), "SPCBPT_eye" connects to sky vertices (raygen.cu:234-258, rmis.h:249-280) and "pt" samples the
+ * sky by next-event estimation and shows it to primary rays (hit_program.cu:502-518, raygen.cu:687-697); an eye SUB-PATH that
+ * leaves the scene never sees it.  center / radius = sky.center / sky.r (upstream: centre and diagonal of the scene
+ * box it computes); radius <= 0 or center == NULL: centre and diagonal of the true bounding box.  The quad lights'
+ * patch subspaces move up by 100 (their div_level^2 may sum to 100 at most).  Call once, before the first light pass. */
+int spcbpt_set_environment(spcbpt_ctx* ctx, const float* rgba, int width, int height, const float* center, float radius);
+int spcbpt_get_environment(spcbpt_ctx* ctx, int* width, int* height, float center[3], float* radius, int* n_lights);
+/* Radiance .hdr reader = HDRLoader (scene_shift.cpp:334-500): RGBE, flat or new-style RLE scanlines, "-Y h +X w" only.  rgba == NULL:
+ * size query.  The fourth float of a texel is 0 (upstream leaves it unset). */
+int spcbpt_hdr_load(const char* path, int* width, int* height, float* rgba, size_t capacity_floats);
 /* The light-pass geometry in force (spcbpt_set_light_trace with core_count resolved; the defaults before any call). */
 int spcbpt_get_light_trace(spcbpt_ctx* ctx, spcbpt_light_trace_params* out);
 /* Host copy of the LVC in deterministic order (path_id, depth). */
@@ -563,6 +582,11 @@ int spcbpt_gltf_load(const char* path, spcbpt_scene_file** out, char* error, int
 int spcbpt_scene_file_desc(spcbpt_scene_file* s, spcbpt_scene_desc* desc);
 int spcbpt_scene_file_camera(spcbpt_scene_file* s, float eye[3], float lookat[3], float up[3], float* fov_y_deg,
                              int* width, int* height);
+/* The scene's environment map: `env_file` of the cameraSetting block (sceneLoader.cpp:242), read like HDRLoader does (width = 0: the
+ * scene names none, or it could not be read: see the warnings), and the sky.center / sky.r env_params_setup would derive from
+ * the reference's scene box (optixPathTracer.cpp:458-459; SURVEY q7: only the first third of every OBJ shape's vertices enters it)
+ * -- to be handed to spcbpt_set_environment.  The pointers stay valid until spcbpt_scene_file_free. */
+int spcbpt_scene_file_environment(spcbpt_scene_file* scene, const float** rgba, int* width, int* height, float center[3], float* radius);
 const char* spcbpt_scene_file_warnings(spcbpt_scene_file* s);
 int spcbpt_scene_file_free(spcbpt_scene_file* s);
 

@@ -168,6 +168,21 @@ class Oracle:
         image is the same either way; only the event counts change."""
         self.l.orc_set_skip_null_connections(self.h, int(on))
 
+    def set_environment(self, rgba, center, radius):
+        """The environment map as one more light (env_params_setup + LightSource_shift): rgba = (h, w, 4) float32 as the .hdr stores it."""
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        c3 = np.ascontiguousarray(center, dtype=np.float32)
+        rc = self.l.orc_set_environment(self.h, C.c_void_p(a.ctypes.data), a.shape[1], a.shape[0], C.c_void_p(c3.ctypes.data), C.c_float(radius))
+        assert rc == 0, rc
+
+    def set_pt_env_nee_fixed(self, on):
+        """Test knob: "pt" aims the shadow ray of its sky sample along the sampled direction (upstream aims it at P + d + 2r(1,1,1))."""
+        self.l.orc_set_pt_env_nee_fixed(self.h, int(on))
+
+    def set_env_miss_strategy(self, on):
+        """Test knob: eye sub-paths that leave the scene see the sky, weighted by rmis::light_hit_env (uncalled upstream): completes the estimator."""
+        self.l.orc_set_env_miss_strategy(self.h, int(on))
+
     def set_count_as_executed(self, on):
         """Test knob, counters only: charge the classification and first-stage-sampling events the product's timed kernels execute
         (labels cached per vertex, two counting passes per first stage) instead of the reference's."""

@@ -102,8 +102,16 @@ int orc_set_light_trace(orc_ctx* c, int num_core, int core_padding, int m_per_co
     c->P.lt.validState = c->lvc_valid.data();
     return 0;
 }
+// env_params_setup + the ENV entry of LightSource_shift: `rgba` = width x height RGBA floats as the .hdr file stores them (row 0 = top)
+int orc_set_environment(orc_ctx* c, const float* rgba, int w, int h, const float* center, float radius) {
+    if (!rgba || w < 1 || h < 1 || !center || !(radius > 0)) return SPCBPT_ERR_INVALID_ARG;
+    c->scene.set_environment(rgba, w, h, load3(center), radius);
+    return 0;
+}
 int orc_set_cmf_double(orc_ctx* c, int on) { c->P.cmf_double = on != 0; return 0; }
 int orc_set_skip_null_connections(orc_ctx* c, int on) { c->P.skip_null_connections = on != 0; return 0; }
+int orc_set_pt_env_nee_fixed(orc_ctx* c, int on) { c->P.pt_env_nee_fixed = on != 0; return 0; }
+int orc_set_env_miss_strategy(orc_ctx* c, int on) { c->P.env_miss_strategy = on != 0; return 0; }
 int orc_set_count_as_executed(orc_ctx* c, int on) { c->P.count_as_executed = on != 0; return 0; }
 int orc_set_uniform_lvc(orc_ctx* c, int on) { c->P.uniform_lvc = on != 0; return 0; }
 int orc_enable_counters(orc_ctx* c, int on) { c->count_events = on != 0; return 0; }
@@ -167,6 +175,7 @@ static void export_vertex(const BDPTVertex& v, spcbpt_light_vertex& o) {
     o.last_normal_projection = v.lastNormalProjection;
     o.material_id = v.materialId; o.subspace_id = v.subspaceId; o.depth = v.depth; o.last_zone_id = v.lastZoneId;
     o.path_id = v.path_id;
+    o.pad = (v.type == ENV ? SPCBPT_LV_DIRECTION : 0u) | (v.isLastVertex_direction ? SPCBPT_LV_LAST_DIRECTION : 0u);   // (no cached label: bits 0-15 stay 0)
 }
 static void import_vertex(const spcbpt_light_vertex& o, BDPTVertex& v) {
     v = BDPTVertex();
@@ -178,7 +187,8 @@ static void import_vertex(const spcbpt_light_vertex& o, BDPTVertex& v) {
     v.materialId = o.material_id; v.subspaceId = o.subspace_id; v.depth = o.depth; v.lastZoneId = o.last_zone_id;
     v.path_id = o.path_id;
     v.isOrigin = o.depth == 0;
-    v.type = o.depth == 0 ? QUAD : NORMALHIT;
+    v.type = o.depth == 0 ? ((o.pad & SPCBPT_LV_DIRECTION) ? ENV : QUAD) : NORMALHIT;
+    v.isLastVertex_direction = (o.pad & SPCBPT_LV_LAST_DIRECTION) != 0;
 }
 // valid LVC slots in slot order (= (path_id, depth) order)
 int orc_lvc_read(orc_ctx* c, spcbpt_light_vertex* out, int capacity, int* count) {
@@ -336,7 +346,8 @@ int orc_connect(orc_ctx* c, const orc_eye_vertex* a, const spcbpt_light_vertex* 
         import_vertex(b[i], lv);
         float3 r = connectVertex_SPCBPT(c->P, ev, lv);
         out_rgb[3 * i] = r.x; out_rgb[3 * i + 1] = r.y; out_rgb[3 * i + 2] = r.z;
-        out_w[i] = lv.depth == 0 ? rmis::connection_lightSource(c->P, ev, lv) : rmis::general_connection(c->P, ev, lv);
+        out_w[i] = lv.is_DIRECTION() ? rmis::connection_direction_lightSource(c->P, ev, lv)
+                 : lv.depth == 0 ? rmis::connection_lightSource(c->P, ev, lv) : rmis::general_connection(c->P, ev, lv);
     }
     return 0;
 }

@@ -172,7 +172,7 @@ inline void raygen_TrainData(const Params& P, int launch_index, int iteration, i
         buffer[buffer_size++] = payload.path.currentVertex();
         BDPTVertex& eye_subpath = payload.path.currentVertex();
         lightSample light_sample;
-        light_sample.sample(P, payload.seed);
+        light_sample.sample_quad(P, payload.seed);
         float3 vis_vec = light_sample.position - eye_subpath.position;
         BDPTVertex light_vertex;
         init_vertex_from_lightSample(light_sample, light_vertex);

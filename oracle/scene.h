@@ -26,6 +26,133 @@ struct Light {  // cuda/Light.h:65-84 (QUAD) ; u, v are ABSOLUTE corner points (
     float3 corner, u, v, emission, normal;
     float area;
     int id, divLevel, ssBase;
+    bool env = false;   // Light::Type::ENV: default-constructed otherwise (scene_shift.cpp:146-151: id / divLevel / ssBase stay as Light() leaves them)
+};
+
+// uv2dir / dir2uv (optixPathTracer.h:139-165); `2 * v - 1.0` and `0.5 * M_1_PIf` promote to double as written
+inline float3 uv2dir(float2 uv) {
+    float3 dir;
+    float u = uv.x, v = uv.y;
+    float phi = asinf((float)(2 * v - 1.0));
+    float theta = (float)(u / (0.5 * M_1_PIf_) - M_PIf_);
+    dir.y = cosf(M_PIf_ * 0.5f - phi);
+    dir.x = cosf(phi) * sinf(theta);
+    dir.z = cosf(phi) * cosf(theta);
+    return dir;
+}
+inline float2 dir2uv(float3 dir) {
+    float theta = atan2f(dir.x, dir.z);
+    float phi = M_PIf_ * 0.5f - acosf(dir.y);
+    float u = (theta + M_PIf_) * (0.5f * M_1_PIf_);
+    float v = 0.5f * (1.0f + sinf(phi));
+    return float2{u, v};
+}
+
+// envInfo + envInfo_device (optixPathTracer.h:98-137, cuProg.h:125-243) and its set-up env_params_setup / envMapCMFBuild /
+// surroundsIndex (optixPathTracer.cpp:381-461).  The texture is the raster with its rows flipped (HDRLoader::loadTexture,
+// scene_shift.cpp:528-540) while the CMF is built over the raster as read -- the sampling density is the image upside down.  As
+// written upstream (unbiased: pdf() uses the same CMF); kept.
+struct EnvInfo {
+    std::vector<float4> tex;   // width x height, row j = raster row height - 1 - j
+    std::vector<float> cmf;
+    float r = 0;
+    float3 center{};
+    int size = 0, width = 0, height = 0, divLevel = 0, ssBase = 0;
+    bool valid = false;
+
+    int coord2index(int cx, int cy) const { return cx + cy * width; }
+    float3 sample(uint32_t& seed) const {   // cuProg.h:164-184: the bespoke bisection of binary_sample, then a jittered point of the texel
+        float index = rnd(seed);
+        int mid = size / 2 - 1, l = 0, rr = size;
+        while (rr - l > 1) {
+            if (index < cmf[mid]) rr = mid + 1;
+            else l = mid + 1;
+            mid = (l + rr) / 2 - 1;
+        }
+        int cx = l % width, cy = l / width;
+        float r1 = rnd(seed), r2 = rnd(seed);
+        float u = (float)(cx + r1) / (float)width, v = (float)(cy + r2) / (float)height;
+        return uv2dir(float2{u, v});
+    }
+    float3 sample_projectPos(float3 dir, uint32_t& seed) const {   // 185-195
+        const float r1 = rnd(seed);
+        const float r2 = rnd(seed);
+        float3 pos;
+        Onb onb(dir);
+        cosine_sample_hemisphere(r1, r2, pos);
+        return 10 * r * (dir) + pos.x * r * onb.m_tangent + pos.y * r * onb.m_binormal + center;
+    }
+    float projectPdf() const { return (float)(1 / (3.14159265358979323846 * r * r)); }   // 196-199 (M_PI: double)
+    void uv2coord(float2 uv, int& x, int& y) const {
+        x = (int)(uv.x * width); y = (int)(uv.y * height);
+        x = x < width - 1 ? x : width - 1; y = y < height - 1 ? y : height - 1;
+    }
+    int getLabel(float3 dir) const {   // 201-216
+        float2 uv = dir2uv(dir);
+        int ux = clampi((int)floorf(uv.x * divLevel), 0, divLevel - 1);
+        int uy = clampi((int)floorf(uv.y * divLevel), 0, divLevel - 1);
+        return SPCBPT_NUM_SUBSPACE - 1 - (ux * divLevel + uy);
+    }
+    float3 color(float3 dir) const {   // 217-226: tex2D<float4>, normalised coordinates, wrap, linear filter (exact-fraction bilinear here)
+        float2 uv = dir2uv(dir);
+        const float x = uv.x * (float)width - 0.5f, y = uv.y * (float)height - 0.5f;
+        const float fx = floorf(x), fy = floorf(y);
+        const float ax = x - fx, ay = y - fy;
+        int x0 = (int)fx % width, y0 = (int)fy % height;
+        if (x0 < 0) x0 += width;
+        if (y0 < 0) y0 += height;
+        const int x1 = x0 + 1 == width ? 0 : x0 + 1, y1 = y0 + 1 == height ? 0 : y0 + 1;
+        const float4 t00 = tex[(size_t)y0 * width + x0], t10 = tex[(size_t)y0 * width + x1], t01 = tex[(size_t)y1 * width + x0], t11 = tex[(size_t)y1 * width + x1];
+        const float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
+        return make_float3(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x, w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                           w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z);
+    }
+    float pdf(float3 dir) const {   // 227-241 (M_PI: double)
+        float2 uv = dir2uv(dir);
+        int cx, cy;
+        uv2coord(uv, cx, cy);
+        int index = coord2index(cx, cy);
+        float pdf1 = index == 0 ? cmf[index] : cmf[index] - cmf[index - 1];
+        return (float)(pdf1 * size / (4 * 3.14159265358979323846));
+    }
+    // env_params_setup (optixPathTracer.cpp:431-461): `raster` = width x height RGBA floats as HDRLoader leaves them (row 0 = top)
+    void setup(const float* raster, int w, int h, float3 c, float radius) {
+        width = w; height = h; size = w * h;
+        divLevel = (int)sqrt(0.5 * SPCBPT_NUM_SUBSPACE_LIGHTSOURCE);
+        ssBase = 0;
+        tex.resize((size_t)size);
+        for (int i = 0; i < w; i++)
+            for (int j = 0; j < h; j++) {
+                const float* q = raster + ((size_t)(h - j - 1) * w + i) * 4;
+                tex[(size_t)j * w + i] = float4{q[0], q[1], q[2], 1.0f};
+            }
+        // envMapCMFBuild (404-430): luminance + the mean of the up-to-12 neighbours within |dx| + |dy| <= 2, accumulated in float
+        std::vector<float> p2((size_t)size);
+        const float uniform_rate = 0.25f;
+        const float uniform_pdf = (float)(1.0 / size);
+        auto lum = [&](int i) { return raster[(size_t)i * 4] + raster[(size_t)i * 4 + 1] + raster[(size_t)i * 4 + 2]; };
+        for (int i = 0; i < size; i++) {
+            const int cx = i % w, cy = i / w;
+            int n = 0, idxs[13];
+            for (int dx = -2; dx <= 2; dx++)
+                for (int dy = -2; dy <= 2; dy++)
+                    if (abs(dx) + abs(dy) <= 2) {
+                        const int sx = cx + dx, sy = cy + dy;
+                        if (sx >= 0 && sy >= 0 && sx < w && sy < h) idxs[n++] = sx + sy * w;
+                    }
+            p2[i] = lum(i);
+            for (int k = 0; k < n; k++) p2[i] += lum(idxs[k]) / n;
+            if (i >= 1) p2[i] += p2[i - 1];
+        }
+        const float sum = p2[size - 1];
+        for (int i = 0; i < size; i++) {
+            p2[i] /= sum;
+            p2[i] = p2[i] * (1 - uniform_rate) + (uniform_pdf * (i + 1) * uniform_rate);
+        }
+        cmf = p2;
+        center = c; r = radius;
+        valid = true;
+    }
 };
 
 struct Texture {
@@ -66,6 +193,7 @@ struct Scene {
     std::vector<Pbr> materials;      // params.materials: scene materials, then one pseudo-material per light
     std::vector<int> mat_light_id;   // MaterialData::light_id for emissive pseudo-materials, else -1
     std::vector<Light> lights;       // params.lights
+    EnvInfo sky;                     // params.sky
     std::vector<Texture> textures;
     std::vector<BVHNode> nodes;
     std::vector<int> tri_order;
@@ -131,6 +259,17 @@ struct Scene {
             tri_mat.push_back((int)materials.size() - 1);
         }
         build_bvh();
+    }
+
+    // The environment map as one more light (scene_shift.cpp:108-153, optixPathTracer.cpp:431-461): the quad lights' patch
+    // subspaces start at 0.5 * NUM_SUBSPACE_LIGHTSOURCE, the sky takes 0 .. divLevel^2 - 1, and an ENV light is appended.
+    void set_environment(const float* raster, int w, int h, float3 center, float radius) {
+        if (sky.valid) return;
+        for (Light& l : lights) l.ssBase += (int)(0.5 * SPCBPT_NUM_SUBSPACE_LIGHTSOURCE);
+        Light e{};
+        e.env = true; e.id = (int)lights.size(); e.divLevel = 0; e.ssBase = 0;   // (Light() leaves them indeterminate upstream: scene_shift.cpp:146-151)
+        lights.push_back(e);
+        sky.setup(raster, w, h, center, radius);
     }
 
     // ---- BVH (median split on the widest centroid axis, leaves <= 4) ----

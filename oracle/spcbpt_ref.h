@@ -1,10 +1,12 @@
 // ORACLE — test infrastructure only (see vec.h).
 // CPU restatement of the SPCBPT hot path of ssufujia/SPCBPT-OptiX7.  Every
 // function cites the reference file:line it follows (paths relative to
-// src/OptiXPathTracer unless prefixed).  Scope: QUAD lights only — the
-// DIRECTION/ENV branches are "unfinished" in the reference (readme.md:29,
-// SURVEY q1) and belong to row f4; `isBrdf/inBrdf/lastBrdf` are never true
-//  so their early-outs are omitted.
+// src/OptiXPathTracer unless prefixed).  Scope: QUAD lights and the light side
+// of the environment map (ENV: sub-paths that start on the sky, connections to
+// them, NEE of "pt" -- row f4; the sky is never SEEN by an eye sub-path, SURVEY
+// q1: light_hit_env has no caller); DIRECTION lights never reach params.lights
+// (scene_shift.cpp:117-123); `isBrdf/inBrdf/lastBrdf` are never true (SURVEY
+// q3) so their early-outs are omitted.
 //
 // PARITY STATUS: the reference cannot be built here (needs the OptiX 7.5 SDK
 // headers + nvcc; no stand-ins are written).  Pinned pieces: rng.h against the
@@ -62,7 +64,10 @@ struct BDPTVertex {
     float RMIS_pointer = 0, last_lum = 0, lastNormalProjection = 0, pdf = 0, singlePdf = 0, lastSinglePdf = 0;
     short materialId = 0, subspaceId = 0, depth = 0, lastZoneId = 0, type = QUAD;
     bool isOrigin = false;
+    bool isLastVertex_direction = false;   // this vertex comes straight from the environment map (BDPTVertex.h:62)
     uint32_t path_id = 0;  // oracle-only bookkeeping (global light path index)
+    bool is_LL_DIRECTION() const { return isLastVertex_direction; }            // BDPTVertex.h:67
+    bool is_DIRECTION() const { return type == DIRECTION || type == ENV; }     // BDPTVertex.h:68
 };
 
 struct BDPTPath {  // BDPTVertex.h:72-117, 3-slot ring
@@ -130,6 +135,17 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
     // relabels of rmis.h:58-79 / 131-151 read those labels (DIR_JUDGE 0 makes a label a property of the vertex), and
     // the first sampling stage reads 2 x 32 CMF values + the bin's two instead of bisecting (device_lib.h: sample_first_stage)
     bool count_as_executed = false;
+    // test knob, NOT reference behaviour: "pt" shoots the shadow ray of its environment-map next-event sample ALONG the sampled
+    // direction.  Upstream (hit_program.cu:513) aims it at P + direction + 2 r with the scalar added to every component, i.e.
+    // towards (1, 1, 1): its "pt" shadows the sky wrongly.  The product restates that as written; the fixed form is the
+    // independent estimator the unbiasedness test of the sky's LIGHT side compares "SPCBPT_eye" with.
+    bool pt_env_nee_fixed = false;
+    // test knob, NOT reference behaviour: an eye sub-path that leaves the scene SEES the sky, weighted by rmis::light_hit_env
+    // (rmis.h:325-358 -- defined upstream, called nowhere: __miss__BDPTVertex only sets `done`).  The connection weights of
+    // the sky's light side (connection_direction_lightSource etc.) reserve a share for this strategy; without it the reference's
+    // image is too dark by that share.  With the knob the estimator is complete, which is what the consistency test of the
+    // restated light side needs: SPCBPT + this == PT.
+    bool env_miss_strategy = false;
 
     float Gamma(int eye_id, int light_id) const {
         if (CMFGamma && Q) {
@@ -189,9 +205,19 @@ struct lightSample {
         subspaceId = SPCBPT_NUM_SUBSPACE - lightSpaceId - 1;
     }
     void sample(const Params& P, const Light& light, uint32_t& seed) {  // 602-621
-        float r1 = rnd(seed);
-        float r2 = rnd(seed);
-        ReverseSample(P, light, make_float2(r1, r2));
+        if (!light.env) {
+            float r1 = rnd(seed);
+            float r2 = rnd(seed);
+            ReverseSample(P, light, make_float2(r1, r2));
+        } else {   // Light::Type::ENV (611-619)
+            const EnvInfo& SKY = P.scene->sky;
+            direction = SKY.sample(seed);
+            emission = SKY.color(direction);
+            subspaceId = SKY.getLabel(direction);
+            uv = dir2uv(direction);
+            pdf = SKY.pdf(direction);
+            pdf /= (float)P.scene->lights.size();
+        }
         bindLight = &light;
     }
     void sample(const Params& P, uint32_t& seed) {  // 622-627
@@ -199,15 +225,27 @@ struct lightSample {
         int light_id = clampi((int)floorf(rnd(seed) * n), 0, n - 1);
         sample(P, P.scene->lights[light_id], seed);
     }
-    float3 normal() const { return bindLight ? bindLight->normal : make_float3(0); }  // 628-643
-    float3 trace_direction() const { return direction; }                               // 644-647
-    void traceMode(uint32_t& seed) {                                                   // 648-665
-        float r1 = rnd(seed);
-        float r2 = rnd(seed);
-        Onb onb(bindLight->normal);
-        cosine_sample_hemisphere(r1, r2, direction);
-        onb.inverse_transform(direction);
-        dir_pdf = fabsf(dot(direction, bindLight->normal)) / M_PIf_;
+    // the light pick of the training pass: QUAD lights only.  Upstream picks among all lights there too (raygen.cu:820-823) and then
+    // reads the sample's `position`, which the ENV branch never sets: undefined, so the sky is left out of the NEE candidates.
+    void sample_quad(const Params& P, uint32_t& seed) {
+        int n = (int)P.scene->lights.size() - (P.scene->sky.valid ? 1 : 0);
+        int light_id = clampi((int)floorf(rnd(seed) * n), 0, n - 1);
+        sample(P, P.scene->lights[light_id], seed);
+    }
+    float3 normal() const { return bindLight ? (bindLight->env ? -direction : bindLight->normal) : make_float3(0); }  // 628-643
+    float3 trace_direction() const { return bindLight->env ? -direction : direction; }   // 644-647
+    void traceMode(const Params& P, uint32_t& seed) {                                    // 648-665 (dir_pdf and dir_pos_pdf share a union)
+        if (!bindLight->env) {
+            float r1 = rnd(seed);
+            float r2 = rnd(seed);
+            Onb onb(bindLight->normal);
+            cosine_sample_hemisphere(r1, r2, direction);
+            onb.inverse_transform(direction);
+            dir_pdf = fabsf(dot(direction, bindLight->normal)) / M_PIf_;
+        } else {
+            position = P.scene->sky.sample_projectPos(direction, seed);
+            dir_pdf = P.scene->sky.projectPdf();
+        }
     }
 };
 
@@ -256,7 +294,8 @@ inline float getLast_pdf(const Params& P, const BDPTVertex& Mid, float3 in_dir) 
     Pbr mat = getMat(P, Mid);
     float3 out_vec = Mid.lastPosition - Mid.position;
     float3 out_dir = normalize(out_vec);
-    float pdf = Pdf(mat, Mid.normal, in_dir, out_dir) / dot(out_vec, out_vec) * Mid.lastNormalProjection;
+    float pdf = Mid.is_LL_DIRECTION() ? Pdf(mat, Mid.normal, in_dir, out_dir)   // 45-47: the step back leads to the sky: a direction, no area measure
+                                      : Pdf(mat, Mid.normal, in_dir, out_dir) / dot(out_vec, out_vec) * Mid.lastNormalProjection;
     pdf *= getRR(Mid);
     return pdf;
 }
@@ -292,7 +331,7 @@ inline float3 getFluxMultiplier(const Params& P, const BDPTVertex& v, float3 in_
 }
 inline float3 tracing_weight_eye(const Params& P, const BDPTVertex& Mid, const BDPTVertex& Last) {  // 131-151
     if (Last.depth == 1) return make_float3(0.0f);
-    float3 inver_dir = normalize(Mid.position - Last.position);
+    float3 inver_dir = Mid.is_DIRECTION() ? -Mid.normal : normalize(Mid.position - Last.position);   // 141
     int eye_label = Last.lastZoneId;
     int light_label = getLabel(P, Last.position, Last.normal, inver_dir, true, !P.count_as_executed);
     float3 lum = make_float3(1.0f);
@@ -300,13 +339,23 @@ inline float3 tracing_weight_eye(const Params& P, const BDPTVertex& Mid, const B
 }
 inline float getPdf(const Params& P, const BDPTVertex& begin, const BDPTVertex& end, float3 in_dir) {  // 153-172
     Pbr mat = getMat(P, begin);
-    float3 out_vec = end.position - begin.position;
-    float3 out_dir = normalize(out_vec);
-    float pdf = Pdf(mat, begin.normal, in_dir, out_dir) / dot(out_vec, out_vec) * fabsf(dot(out_dir, end.normal));
+    float pdf;
+    if (end.is_DIRECTION()) {   // 158-162
+        float3 out_dir = -end.normal;
+        pdf = Pdf(mat, begin.normal, in_dir, out_dir);
+    } else {
+        float3 out_vec = end.position - begin.position;
+        float3 out_dir = normalize(out_vec);
+        pdf = Pdf(mat, begin.normal, in_dir, out_dir) / dot(out_vec, out_vec) * fabsf(dot(out_dir, end.normal));
+    }
     pdf *= getRR(begin);
     return pdf;
 }
-inline float getPdf_from_light_source(const BDPTVertex& light, const BDPTVertex& end) {  // 173-188 ; M_PI is double
+inline float getPdf_from_light_source(const Params& P, const BDPTVertex& light, const BDPTVertex& end) {  // 173-188 ; M_PI is double
+    if (light.is_DIRECTION()) {   // 183-187
+        float3 dir = light.normal;
+        return P.scene->sky.projectPdf() * fabsf(dot(dir, end.normal));
+    }
     float3 conn_vec = end.position - light.position;
     float3 conn_dir = normalize(conn_vec);
     float pdf_angle = (float)((double)fabsf(dot(light.normal, conn_dir)) / 3.14159265358979323846);
@@ -348,6 +397,27 @@ inline float general_connection(const Params& P, const BDPTVertex& eye, const BD
     float D_B = D_B_0 * pdf_B / light.singlePdf;
     return weight / (weight + D_A + D_B);
 }
+inline float connection_direction_lightSource(const Params& P, const BDPTVertex& eye, const BDPTVertex& light) {  // 249-280
+    float3 connect_dir = light.normal;
+    float3 flux = light.flux / light.pdf;
+
+    float LL_pdf_A = getLL_pdf(P, light, eye);   // (in_dir runs from the eye vertex to the light vertex's POSITION on the sky disk: as written)
+    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, -connect_dir);
+    float3 weight_A = tracing_weight_eye(P, light, eye);
+    float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
+
+    float pdf_A = getPdf_from_light_source(P, light, eye);
+    float flux_multiplier_1 = light.is_DIRECTION() ? (float)(1.0 / P.scene->sky.projectPdf()) : M_PIf_;
+    float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
+
+    float weight = float3weight(connectRate_SOL(P, eye.subspaceId, light.subspaceId, flux));
+
+    float D_B_0 = light.RMIS_pointer;
+    float3 LB = normalize(eye.lastPosition - eye.position);
+    float pdf_B = getPdf(P, eye, light, LB);
+    float D_B = D_B_0 * pdf_B / light.singlePdf;
+    return weight / (weight + D_A + D_B);
+}
 inline float connection_lightSource(const Params& P, const BDPTVertex& eye, const BDPTVertex& light) {  // 281-313
     float3 connect_vec = eye.position - light.position;
     float3 connect_dir = normalize(connect_vec);
@@ -358,7 +428,7 @@ inline float connection_lightSource(const Params& P, const BDPTVertex& eye, cons
     float3 weight_A = tracing_weight_eye(P, light, eye);
     float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
 
-    float pdf_A = getPdf_from_light_source(light, eye);
+    float pdf_A = getPdf_from_light_source(P, light, eye);
     float flux_multiplier_1 = M_PIf_;
     float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
 
@@ -380,11 +450,27 @@ inline float light_hit(const Params& P, BDPTVertex& eye, BDPTVertex& light) {  /
     float3 weight_A = tracing_weight_eye(P, light, eye);
     float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
 
-    float pdf_A = getPdf_from_light_source(light, eye);
+    float pdf_A = getPdf_from_light_source(P, light, eye);
     float flux_multiplier_1 = M_PIf_;
     float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
     float weight = float3weight(connectRate_SOL(P, eye.subspaceId, light.subspaceId, flux));
 
+    float D_B = light.RMIS_pointer;
+    float3 LB = normalize(eye.lastPosition - eye.position);
+    float pdf_B = getPdf(P, eye, light, LB);
+    return D_B / ((weight + D_A) / pdf_B * light.singlePdf + D_B);
+}
+inline float light_hit_env(const Params& P, BDPTVertex& eye, BDPTVertex& light) {  // 325-358 (uncalled upstream; see Params::env_miss_strategy)
+    float3 connect_dir = -light.normal;
+    float3 flux = light.flux / light.pdf;
+    float LL_pdf_A = getLast_pdf(P, eye, connect_dir);
+    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, -connect_dir);
+    float3 weight_A = tracing_weight_eye(P, light, eye);
+    float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
+    float pdf_A = getPdf_from_light_source(P, light, eye);
+    float flux_multiplier_1 = (float)(1.0 / P.scene->sky.projectPdf());
+    float D_A = float3weight(D_A_0 * pdf_A * flux_multiplier_1 * flux / eye.singlePdf);
+    float weight = float3weight(connectRate_SOL(P, eye.subspaceId, light.subspaceId, flux));
     float D_B = light.RMIS_pointer;
     float3 LB = normalize(eye.lastPosition - eye.position);
     float pdf_B = getPdf(P, eye, light, LB);
@@ -430,6 +516,7 @@ inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const Hi
     Mid.normal = N;
     Mid.type = NORMALHIT;
     float pdf_G = fabsf(dot(Mid.normal, ray_direction) * dot(Last.normal, ray_direction)) / (t_hit * t_hit);
+    if (light_side && Last.is_DIRECTION()) pdf_G = fabsf(dot(Mid.normal, ray_direction) * dot(Last.normal, ray_direction));   // hit_program.cu:372-375 (parallel rays: no 1 / t^2)
     if (Last.isOrigin) Mid.flux = Last.flux * pdf_G;
     else Mid.flux = Mid.flux * Last.flux * pdf_G;
     Next.flux = Eval(currentPbr, N, -ray_direction, prd->ray_direction);
@@ -437,6 +524,7 @@ inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const Hi
     Next.singlePdf = prd->pdf;
 
     Mid.lastPosition = Last.position;
+    if (Last.is_DIRECTION()) Mid.lastPosition = Mid.position - ray_direction;   // hit_program.cu:290-293 / 386-389
     Mid.color = currentPbr.base_color;
     Mid.lastNormalProjection = fabsf(dot(Last.normal, ray_direction));
     Mid.materialId = (short)S.tri_mat[h.tri];
@@ -453,6 +541,7 @@ inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const Hi
     if (light_side) Mid.last_lum = float3weight(Last.flux / Last.pdf);  // 408
 
     Mid.lastSinglePdf = Last.singlePdf;
+    if (light_side) Mid.isLastVertex_direction = Last.depth == 0 && Last.is_DIRECTION();   // hit_program.cu:412
     if (light_side) {
         if (Last.isOrigin) rmis::tracing_init_light(Mid, Last);
         else rmis::tracing_update_light(P, Mid, Last);
@@ -538,7 +627,20 @@ inline void closesthit_radiance(const Params& P, PayloadRadiance* prd, const Hit
     int n_lights = (int)S.lights.size();
     int light_id = clampi((int)floorf(rnd(prd->seed) * n_lights), 0, n_lights - 1);
     const Light& light = S.lights[light_id];
-    {
+    if (light.env) {   // hit_program.cu:502-518
+        lightSample light_sample;
+        light_sample.sample(P, light, prd->seed);
+        const float3 V = -normalize(h.ray_direction);
+        const float3 L = light_sample.direction;
+        float L_dot_N = dot(light_sample.direction, N);
+        if (L_dot_N > 0.0f) {
+            prd->vis_pos_A = geom.P;
+            prd->vis_pos_B = geom.P + light_sample.direction + make_float3(S.sky.r * 2);   // float3 + float adds the scalar to every component: as written
+            if (P.pt_env_nee_fixed) prd->vis_pos_B = geom.P + light_sample.direction * (S.sky.r * 2);
+            float3 eval = Eval(currentPbr, N, V, L);
+            result += prd->throughput * light_sample.emission / light_sample.pdf * eval * L_dot_N;
+        }
+    } else {
         lightSample light_sample;
         light_sample.sample(P, light, prd->seed);
         const float L_dist = length(light_sample.position - geom.P);
@@ -668,9 +770,10 @@ inline void raygen_pinhole(const Params& P, unsigned x, unsigned y) {
         ray_direction = payload.ray_direction;
         ray_origin = payload.origin;
         Hit h = S.closest_hit(ray_origin, ray_direction, SPCBPT_SCENE_EPSILON, 1e16f, P.counters);
-        if (h.tri < 0) {  // __miss__constant_radiance (raygen.cu:687-697), no env map
+        if (h.tri < 0) {  // __miss__constant_radiance (raygen.cu:687-697)
             payload.done = true;
             payload.currentResult = make_float3(0);
+            if (payload.depth == 0 && S.sky.valid) payload.result = payload.throughput * S.sky.color(payload.ray_direction);
         } else {
             HitInfo hi{h.tri, h.t, ray_direction, h.bu, h.bv};
             if (S.tri_is_emitter(h.tri)) closesthit_lightsource(P, &payload, hi);
@@ -699,7 +802,7 @@ inline void init_vertex_from_lightSample(lightSample& ls, BDPTVertex& v) {
     v.materialId = (short)ls.bindLight->id;
     v.RMIS_pointer = 1;
     v.uv = ls.uv;
-    v.type = QUAD;
+    v.type = ls.bindLight->env ? ENV : QUAD;
 }
 inline void init_lightSubPath_from_lightSample(lightSample& ls, BDPTPath& p) {
     p.clear();
@@ -725,7 +828,33 @@ inline void init_EyeSubpath(BDPTPath& p, float3 origin, float3 direction) {
 inline void trace_subpath(const Params& P, float3 o, float3 d, PayloadBDPTVertex* prd, bool light_side) {
     const Scene& S = *P.scene;
     Hit h = S.closest_hit(o, d, SPCBPT_SCENE_EPSILON, 1e16f, P.counters);
-    if (h.tri < 0) { prd->done = true; return; }  // __miss__BDPTVertex raygen.cu:699-704
+    if (h.tri < 0) {  // __miss__BDPTVertex raygen.cu:699-704
+        prd->done = true;
+        if (!light_side && P.env_miss_strategy && S.sky.valid) {   // test knob: the eye sub-path sees the sky (an ENV_MISS vertex, like the emitter hit)
+            prd->path.push();
+            BDPTVertex& Mid = prd->path.currentVertex();
+            BDPTVertex& Last = prd->path.lastVertex();
+            const float3 Le = S.sky.color(d);
+            const float lightPdf = S.sky.pdf(d) / (float)S.lights.size();
+            Mid.type = ENV_MISS;
+            Mid.normal = -d;
+            const float pdf_G = fabsf(dot(Last.normal, d));   // a direction: no 1 / t^2, no cosine at the sky
+            if (Last.isOrigin) Mid.flux = Last.flux * pdf_G * Le;
+            else Mid.flux = Mid.flux * Last.flux * pdf_G * Le;
+            Mid.singlePdf = Mid.singlePdf * pdf_G / fabsf(dot(Last.normal, d));
+            Mid.pdf = Last.pdf * Mid.singlePdf;
+            Mid.depth = Last.depth + 1;
+            Mid.subspaceId = (short)S.sky.getLabel(d);
+            if (Mid.depth == 1) Mid.RMIS_pointer = 1.0f;
+            else {
+                BDPTVertex virtual_light;   // construct_virtual_env_light (rmis.h:314-324)
+                virtual_light.type = DIRECTION; virtual_light.flux = Le; virtual_light.pdf = lightPdf; virtual_light.singlePdf = lightPdf;
+                virtual_light.normal = -d; virtual_light.RMIS_pointer = 1; virtual_light.subspaceId = Mid.subspaceId;
+                Mid.RMIS_pointer = (float)(1.0 / (double)rmis::light_hit_env(P, Last, virtual_light));
+            }
+        }
+        return;
+    }
     HitInfo hi{h.tri, h.t, d, h.bu, h.bv};
     if (S.tri_is_emitter(h.tri)) {
         if (light_side) prd->done = true;  // __closesthit__lightSource_subpath hit_program.cu:239-244
@@ -768,8 +897,32 @@ inline int sampleFirstStage(const Params& P, int eye_subspace, uint32_t& seed, f
 }
 
 // connectVertex_SPCBPT (raygen.cu:253-303)
+// direction_connect_ZGCBPT (raygen.cu:234-252): the light vertex is a direction of the environment map
+inline float3 direction_connect_ZGCBPT(const Params& P, const BDPTVertex& a, const BDPTVertex& b) {
+    const Scene& S = *P.scene;
+    float3 L = make_float3(0.0f);
+    float3 connectDir = -b.normal;
+    if (dot(a.normal, connectDir) > 0.0f) {
+        Pbr mat_a = S.materials[a.materialId];
+        mat_a.base_color = a.color;
+        float3 f = Eval(mat_a, a.normal, normalize(a.lastPosition - a.position), connectDir) * dot(a.normal, connectDir);
+        L = a.flux / a.pdf * f * b.flux / b.pdf * rmis::connection_direction_lightSource(P, a, b);
+    }
+    if (is_invalid(L)) return make_float3(0.0f);
+    return L;
+}
+// visibilityTest(handle, eyeVertex, lightVertex) (cuProg.h:489-500)
+inline bool visibilityTest_vertices(const Params& P, const BDPTVertex& eye, const BDPTVertex& light) {
+    const Scene& S = *P.scene;
+    if (light.is_DIRECTION()) {
+        float3 n_pos = -10 * S.sky.r * light.normal + eye.position;
+        return S.visibilityTest(eye.position, n_pos, P.counters);
+    }
+    return S.visibilityTest(eye.position, light.position, P.counters);
+}
 inline float3 connectVertex_SPCBPT(const Params& P, const BDPTVertex& a, const BDPTVertex& b) {
     const Scene& S = *P.scene;
+    if (b.is_DIRECTION()) return direction_connect_ZGCBPT(P, a, b);   // raygen.cu:255-258
     float3 connectVec = a.position - b.position;
     float3 connectDir = normalize(connectVec);
     float G = fabsf(dot(a.normal, connectDir)) * fabsf(dot(b.normal, connectDir)) / dot(connectVec, connectVec);
@@ -839,10 +992,14 @@ inline float3 spcbpt_sample(const Params& P, unsigned x, unsigned y) {
                                                             : sampleSecondStage(P, light_id, payload.seed, pmf_secondStage);
             if (P.counters) P.counters->connections++;
             if (P.skip_null_connections) {
-                const float3 cd = normalize(eye_subpath.position - light_subpath.position);
-                if (dot(eye_subpath.normal, -cd) <= 0.0f || dot(light_subpath.normal, cd) < 0.0f) continue;
+                if (light_subpath.is_DIRECTION()) {   // direction_connect_ZGCBPT contributes only with the sky above the eye vertex's surface
+                    if (!(dot(eye_subpath.normal, -light_subpath.normal) > 0.0f)) continue;
+                } else {
+                    const float3 cd = normalize(eye_subpath.position - light_subpath.position);
+                    if (dot(eye_subpath.normal, -cd) <= 0.0f || dot(light_subpath.normal, cd) < 0.0f) continue;
+                }
             }
-            if (S.visibilityTest(eye_subpath.position, light_subpath.position, P.counters)) {
+            if (visibilityTest_vertices(P, eye_subpath, light_subpath)) {
                 float pmf = P.sampler.path_count * pmf_secondStage * pmf_firstStage;
                 float3 res = connectVertex_SPCBPT(P, eye_subpath, light_subpath) / pmf;
                 if (!is_invalid(res)) result += res / (float)SPCBPT_CONNECTION_N;
@@ -1072,7 +1229,7 @@ inline void raygen_lightTrace(const Params& P, int launch_index) {
         const Light& light = S.lights[light_id];
         lightSample light_sample;
         light_sample.sample(P, light, seed);
-        light_sample.traceMode(seed);
+        light_sample.traceMode(P, seed);
         float3 ray_direction = light_sample.trace_direction();
         float3 ray_origin = light_sample.position;
         init_lightSubPath_from_lightSample(light_sample, payload.path);

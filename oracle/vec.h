@@ -55,5 +55,6 @@ inline float fmaxf3(float3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 inline float float3weight(float3 a) { return a.x + a.y + a.z; }  // BDPTVertex.h:124
 
 static const float M_PIf_ = 3.14159265358979323846f;
+static const float M_1_PIf_ = 0.318309886183790671538f;
 
 }  // namespace orc

@@ -130,6 +130,7 @@ class Scene:
     textures: List[np.ndarray] = field(default_factory=list)  # (h, w, 4) u8
     camera: dict = field(default_factory=dict)  # eye, lookat, up, fov
     name: str = "scene"
+    environment: Optional[dict] = None   # rgba (h, w, 4) f32 as a .hdr stores it (row 0 = top), center (3,), radius: Renderer.set_environment(**scene.environment)
 
     def desc(self):
         """Returns (SceneDesc, keepalive)."""
@@ -239,9 +240,17 @@ def _scene_from_handle(lib, h, name):
         fov, w, hh = C.c_float(), C.c_int(), C.c_int()
         lib.spcbpt_scene_file_camera(h, _fp(eye), _fp(look), _fp(up), C.byref(fov), C.byref(w), C.byref(hh))
         cam = dict(eye=tuple(eye), lookat=tuple(look), up=tuple(up), fov=fov.value, width=w.value, height=hh.value)
+        env = None
+        ep, ew, eh, er = C.c_void_p(), C.c_int(), C.c_int(), C.c_float()
+        ec = np.zeros(3, np.float32)
+        if hasattr(lib, "spcbpt_scene_file_environment"):    # (absent only from an older SPCBPT_LIB build)
+            lib.spcbpt_scene_file_environment(h, C.byref(ep), C.byref(ew), C.byref(eh), _fp(ec), C.byref(er))
+        if ew.value > 0:
+            px = np.ctypeslib.as_array(C.cast(ep, C.POINTER(C.c_float)), shape=(eh.value, ew.value, 4)).copy()
+            env = dict(rgba=px, center=ec.copy(), radius=float(er.value))
         warn = lib.spcbpt_scene_file_warnings(h).decode()
         return Scene(vertices=V, indices=I, tri_material=M, materials=mats, lights=lights, texcoords=UV, textures=texs,
-                     camera=cam, name=name), warn
+                     camera=cam, name=name, environment=env), warn
     finally:
         lib.spcbpt_scene_file_free(h)
 
@@ -368,6 +377,20 @@ class Viewer:
         return out
 
 
+def hdr_load(path: str):
+    """(h, w, 4) float32 raster of a Radiance .hdr file, decoded as the reference's HDRLoader (scene_shift.cpp:334-500); row 0 = top."""
+    lib = load_library()
+    w, h = C.c_int(), C.c_int()
+    rc = lib.spcbpt_hdr_load(os.fsencode(path), C.byref(w), C.byref(h), None, 0)
+    if rc:
+        raise SpcbptError(f"hdr_load({path}) failed ({rc})")
+    px = np.zeros((h.value, w.value, 4), np.float32)
+    rc = lib.spcbpt_hdr_load(os.fsencode(path), C.byref(w), C.byref(h), px.ctypes.data, px.size)
+    if rc:
+        raise SpcbptError(f"hdr_load({path}) failed ({rc})")
+    return px
+
+
 def image_load(path: str):
     """RGBA8 image (h, w, 4) of a JPEG / PNG / binary PPM file, decoded as the reference's stbi_load(..., STBI_rgb_alpha)."""
     lib = load_library()
@@ -460,6 +483,9 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_launch_light_batch": [vp, u32, i32],
         "spcbpt_lvc_export": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)],
         "spcbpt_lvc_import": [vp, vp, i32, i32],
+        "spcbpt_set_environment": [vp, vp, i32, i32, vp, C.c_float],
+        "spcbpt_get_environment": [vp, C.POINTER(i32), C.POINTER(i32), f32p, C.POINTER(C.c_float), C.POINTER(i32)],
+        "spcbpt_hdr_load": [C.c_char_p, C.POINTER(i32), C.POINTER(i32), vp, C.c_size_t],
         "spcbpt_lvc_set_capacity": [vp, i32],
         "spcbpt_lvc_get_capacity": [vp, C.POINTER(i32), C.POINTER(i32)],
         "spcbpt_lvc_read": [vp, vp, i32, C.POINTER(i32)],
@@ -514,11 +540,14 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_scene_file_load": [C.c_char_p, C.c_char_p, C.POINTER(vp)],
         "spcbpt_scene_file_desc": [vp, C.POINTER(SceneDesc)],
         "spcbpt_scene_file_camera": [vp, f32p, f32p, f32p, f32p, C.POINTER(i32), C.POINTER(i32)],
+        "spcbpt_scene_file_environment": [vp, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), f32p, C.POINTER(C.c_float)],
         "spcbpt_scene_file_free": [vp],
         "spcbpt_get_subspace": [vp, vp, C.POINTER(i32), i32, vp, C.POINTER(i32), i32, vp, vp],
         "spcbpt_scene_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
     }
     for name, args in sig.items():
+        if os.environ.get("SPCBPT_LIB") and not hasattr(lib, name):
+            continue                   # an older build of the ABI in a developer A/B run
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
@@ -537,7 +566,7 @@ def load_library(path: str = LIB_PATH):
 EXPORTED_SYMBOLS = [
     "spcbpt_create", "spcbpt_destroy", "spcbpt_last_error", "spcbpt_set_camera", "spcbpt_set_camera_lookat",
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_launch_light_batch", "spcbpt_build_sampler",
-    "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
+    "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit",
     "spcbpt_build_source_hash", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
@@ -545,7 +574,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
     "spcbpt_get_gamma", "spcbpt_gltf_load", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
-    "spcbpt_scene_file_warnings", "spcbpt_scene_file_free",
+    "spcbpt_scene_file_warnings", "spcbpt_scene_file_environment", "spcbpt_scene_file_free",
     "spcbpt_viewer_create", "spcbpt_viewer_destroy", "spcbpt_viewer_mouse_button", "spcbpt_viewer_cursor_pos", "spcbpt_viewer_scroll",
     "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_frame",
     "spcbpt_viewer_get_state", "spcbpt_viewer_alg_name",
@@ -720,6 +749,20 @@ class Renderer:
 
     def lvc_import_device(self, d_ptr: int, count: int):
         self._chk(self.lib.spcbpt_lvc_import(self.h, C.c_void_p(d_ptr), count, 1), "lvc_import")
+
+    def set_environment(self, rgba, center=None, radius=0.0):
+        """The environment map as one more light (spcbpt_set_environment): rgba = (h, w, 4) float32 as the .hdr stores it (row 0 = top)."""
+        a = np.ascontiguousarray(rgba, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[2] == 4
+        c3 = None if center is None else np.ascontiguousarray(center, dtype=np.float32)
+        self._chk(self.lib.spcbpt_set_environment(self.h, a.ctypes.data, a.shape[1], a.shape[0], None if c3 is None else c3.ctypes.data, float(radius)), "set_environment")
+
+    def environment(self):
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        c3 = np.zeros(3, np.float32)
+        r = C.c_float()
+        self._chk(self.lib.spcbpt_get_environment(self.h, C.byref(w), C.byref(h), _fp(c3), C.byref(r), C.byref(n)), "get_environment")
+        return dict(width=w.value, height=h.value, center=c3, radius=r.value, n_lights=n.value)
 
     def lvc_set_capacity(self, vertices: int):
         """Vertices per buffer set, fixed by hand (0 = sized from a probe pass: spcbpt_lvc_set_capacity)."""

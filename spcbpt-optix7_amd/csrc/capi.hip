@@ -16,6 +16,7 @@
 #include "context.h"
 #include "kernels.h"
 #include "lbvh.h"
+#include "env_host.h"
 
 using namespace spc;
 
@@ -202,6 +203,53 @@ int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_t
     HIP_TRY(this, hipStreamSynchronize(stream));
     kp.eye_tree = d_eye_tree; kp.light_tree = d_light_tree; kp.Q = d_Q; kp.cmf_gamma = d_gamma; kp.cmf_gamma2 = gamma_monotone ? d_gamma2 : nullptr;
     have_subspace = true;
+    return 0;
+}
+
+// The environment map as one more light: env_params_setup (optixPathTracer.cpp:431-461) + the ENV entry and the patch-subspace
+// shift of LightSource_shift (scene_shift.cpp:108-153).
+int Context::set_environment(const float* rgba, int w, int h, const float* center, float radius) {
+    if (!rgba || w < 1 || h < 1 || (long long)w * h > (1ll << 26)) { error = "set_environment: bad image"; return SPCBPT_ERR_INVALID_ARG; }
+    if (kp.scene.env.valid) { error = "set_environment: the context already has an environment map"; return SPCBPT_ERR_STATE; }
+    int patches = 0;
+    for (const DLight& L : h_lights) patches += L.div_level * L.div_level;
+    if (patches > SPCBPT_NUM_SUBSPACE_LIGHTSOURCE / 2) { error = "set_environment: with an environment map the quad lights may use at most 100 patch subspaces (sum of div_level^2)"; return SPCBPT_ERR_INVALID_ARG; }
+    for (size_t i = 0; i < (size_t)w * h * 4; i++) if (!std::isfinite(rgba[i])) { error = "set_environment: non-finite texel"; return SPCBPT_ERR_INVALID_ARG; }
+    if (sync_all()) return SPCBPT_ERR_HIP;
+    std::vector<float> tex, cmf;
+    env_build(rgba, w, h, tex, cmf);
+    if (!(cmf.back() > 0.0f) || !std::isfinite(cmf.back())) { error = "set_environment: the image holds no energy"; return SPCBPT_ERR_INVALID_ARG; }
+    dev_free(d_env_tex); dev_free(d_env_cmf);
+    HIP_TRY(this, dev_alloc(&d_env_tex, tex.size()));
+    HIP_TRY(this, dev_alloc(&d_env_cmf, cmf.size()));
+    HIP_TRY(this, hipMemcpy(d_env_tex, tex.data(), tex.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(this, hipMemcpy(d_env_cmf, cmf.data(), cmf.size() * 4, hipMemcpyHostToDevice));
+    // scene_shift.cpp:110: the quad lights' patches start at 0.5 * NUM_SUBSPACE_LIGHTSOURCE, the sky's divLevel^2 directions at 0
+    for (DLight& L : h_lights) L.ss_base += SPCBPT_NUM_SUBSPACE_LIGHTSOURCE / 2;
+    DLight E;
+    memset(&E, 0, sizeof(E));
+    E.type = 1; E.id = (int)h_lights.size();   // (Light() leaves id / divLevel / ssBase indeterminate upstream)
+    h_lights.push_back(E);
+    dev_free(d_lights);
+    HIP_TRY(this, dev_alloc(&d_lights, h_lights.size()));
+    HIP_TRY(this, hipMemcpy(d_lights, h_lights.data(), h_lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    n_lights = (int)h_lights.size();
+    DEnv& V = kp.scene.env;
+    V.tex = d_env_tex; V.cmf = d_env_cmf;
+    V.width = w; V.height = h; V.size = w * h;
+    V.div_level = (int)sqrt(0.5 * SPCBPT_NUM_SUBSPACE_LIGHTSOURCE);
+    if (center && radius > 0.0f) { memcpy(V.center, center, 12); V.r = radius; }
+    else {   // the scene's bounding box: centre and diagonal (sky.center / sky.r of env_params_setup, over the TRUE box: SURVEY q7)
+        double d2 = 0.0;
+        for (int k = 0; k < 3; k++) { V.center[k] = 0.5f * (bbox_lo[k] + bbox_hi[k]); const double e = (double)bbox_lo[k] - (double)bbox_hi[k]; d2 += e * e; }
+        V.r = (float)sqrt(d2);
+    }
+    V.project_pdf = (float)(1 / (3.14159265358979323846 * V.r * V.r));
+    V.valid = 1;
+    kp.scene.lights = d_lights; kp.scene.n_lights = n_lights;
+    // every cache traced so far is without sky vertices
+    have_sampler = false; pending.clear(); built_sets.clear(); lvc_count = 0;
+    lvc_probe_needed = lvc_fixed == 0;
     return 0;
 }
 
@@ -710,6 +758,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     }
     int rc = ensure_spill((size_t)render_thread_count(kp), true);
     if (rc) return rc;
+    if (full_mis && kp.scene.env.valid) { error = "SPCBPT_no_rmis: not with an environment map (the full-path weights of cuProg.h:901-1105 know area lights only)"; return SPCBPT_ERR_STATE; }
     if (full_mis) {   // "SPCBPT_no_rmis": a plain one-lane-per-pixel launch over the same sampler tables
         time_begin(name, rstream);
         launch_spcbpt_no_rmis(kp, rstream);
@@ -890,7 +939,7 @@ Context::~Context() {
     free_preprocess();
     dev_free(d_nodes); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
-    dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
+    dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); }
@@ -1067,6 +1116,10 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     CREATE_TRY(hipMemcpy(c->d_tri_orig, bvh.tri_orig.data(), bvh.tri_orig.size() * 4, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(c->d_mats, mats.data(), mats.size() * sizeof(DMaterial), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(c->d_lights, lights.data(), lights.size() * sizeof(DLight), hipMemcpyHostToDevice));
+    c->h_lights = lights;
+    for (int k = 0; k < 3; k++) { c->bbox_lo[k] = 1e30f; c->bbox_hi[k] = -1e30f; }
+    for (size_t i = 0; i < V.size(); i += 3)
+        for (int k = 0; k < 3; k++) { c->bbox_lo[k] = std::min(c->bbox_lo[k], V[i + k]); c->bbox_hi[k] = std::max(c->bbox_hi[k], V[i + k]); }
     std::vector<DTexture> texs;
     for (int i = 0; i < sc->n_textures; i++) {
         const spcbpt_texture& t = sc->textures[i];
@@ -1172,6 +1225,21 @@ int spcbpt_set_subspace(spcbpt_ctx* c, const spcbpt_tree_node* et, int ne, const
     CTX_CHECK(c);
     if (!et && !lt && !q && !g) return c->install_minimal_tuple();
     return c->install_subspace(et, ne, lt, nl, q, g);
+}
+
+int spcbpt_set_environment(spcbpt_ctx* c, const float* rgba, int width, int height, const float* center, float radius) {
+    CTX_CHECK(c);
+    return c->set_environment(rgba, width, height, center, radius);
+}
+int spcbpt_get_environment(spcbpt_ctx* c, int* width, int* height, float center[3], float* radius, int* n_lights) {
+    CTX_CHECK(c);
+    const DEnv& V = c->kp.scene.env;
+    if (width) *width = V.valid ? V.width : 0;
+    if (height) *height = V.valid ? V.height : 0;
+    if (center) memcpy(center, V.center, 12);
+    if (radius) *radius = V.valid ? V.r : 0.0f;
+    if (n_lights) *n_lights = c->n_lights;
+    return SPCBPT_OK;
 }
 
 int spcbpt_set_light_trace(spcbpt_ctx* c, const spcbpt_light_trace_params* p) {

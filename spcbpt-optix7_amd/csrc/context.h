@@ -114,6 +114,12 @@ struct Context {
     DTexture* d_tex = nullptr;
     std::vector<uint32_t*> d_tex_data;
     int n_triangles = 0, n_nodes = 0, bvh_depth = 0, n_lights = 0, n_mats = 0;
+    // environment map (params.sky; spcbpt_set_environment): device copies of the flipped texture and the sampling CMF
+    float* d_env_tex = nullptr;
+    float* d_env_cmf = nullptr;
+    std::vector<DLight> h_lights;          // the light list as uploaded (the ENV light is appended to it)
+    float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};   // of every vertex handed to spcbpt_create (+ the light quads)
+    int set_environment(const float* rgba, int w, int h, const float* center, float radius);
     // film
     float* d_accum = nullptr;
     uint32_t* d_frame = nullptr;

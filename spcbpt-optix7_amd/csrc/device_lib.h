@@ -736,6 +736,7 @@ struct VCore {
     f3 pos, n, color, lastPos;
     float lnp;  // lastNormalProjection
     int mat;
+    bool lld;   // is_LL_DIRECTION (BDPTVertex.h:67): the vertex was hit straight from the environment map (light vertices only)
 };
 SPC_DEV float rr_of(f3 color) { return fmaxf(max3(color), SPCBPT_MIN_RR_RATE); }  // getRR rmis.h:28-40 (q10)
 
@@ -743,7 +744,8 @@ SPC_DEV float rr_of(f3 color) { return fmaxf(max3(color), SPCBPT_MIN_RR_RATE); }
 SPC_DEV float rmis_last_pdf(const Pbr& mat, const VCore& v, f3 in_dir) {
     const f3 out_vec = v.lastPos - v.pos;
     const f3 out_dir = normalize(out_vec);
-    float pdf = bsdf_pdf(mat, v.n, in_dir, out_dir) / dot(out_vec, out_vec) * v.lnp;
+    // rmis.h:45-47: the step back from a vertex lit straight by the sky leads to a direction, not to a point: no area measure
+    float pdf = v.lld ? bsdf_pdf(mat, v.n, in_dir, out_dir) : bsdf_pdf(mat, v.n, in_dir, out_dir) / dot(out_vec, out_vec) * v.lnp;
     return pdf * rr_of(v.color);
 }
 // getFluxMultiplier (rmis.h:102-118)
@@ -805,25 +807,63 @@ SPC_DEV float rmis_weight_light(const KParams& p, const VCore& last, int last_la
     return gamma_ss(p, eye_label, last_lastZone, cn) * last_lum * (float)SPCBPT_CONNECTION_N;
 }
 
+template <bool ENV = true>
 SPC_DEV VCore core_of(const LightVertex& b) {
     VCore c;
     c.pos = ld3(b.position); c.n = ld3(b.normal); c.color = ld3(b.color); c.lastPos = ld3(b.last_position);
     c.lnp = b.last_normal_projection; c.mat = b.material_id;
+    c.lld = ENV && (b.pad & SPCBPT_LV_LAST_DIRECTION) != 0u;
     return c;
 }
 
 // A connection whose value is exactly zero whatever the visibility: the eye vertex sees the light vertex from
 // behind its own surface (bsdf_eval returns 0 for N.V <= 0), or the light vertex faces away (N.L <= 0 on a surface vertex,
 // the one-sided term on an emitter vertex).  Same vectors and the same normalize() as connect_vertices.
+// ... and for a direction of the environment map: direction_connect_ZGCBPT contributes only with the sky above the eye vertex's surface
+SPC_DEV bool null_connection_direction(f3 an, f3 bn) { return !(dot(an, -bn) > 0.0f); }
 SPC_DEV bool null_connection(f3 apos, f3 an, f3 bpos, f3 bn) {
     const f3 connectDir = normalize(apos - bpos);
     return dot(an, -connectDir) <= 0.0f || dot(bn, connectDir) < 0.0f;
 }
 
+// direction_connect_ZGCBPT (raygen.cu:234-252) with rmis::connection_direction_lightSource (rmis.h:249-280): the light vertex is a
+// direction of the environment map (type ENV: normal = minus the sky direction, position = its point on the sky disk).
+template <bool COUNT, bool CACHE>
+SPC_DEV f3 connect_direction(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn, float* w_out) {
+    const DeviceScene& S = p.scene;
+    const f3 bn = ld3(b.normal), bflux = ld3(b.flux);
+    const f3 connectDir = -bn;
+    if (w_out) *w_out = 0.0f;
+    if (!(dot(a.c.n, connectDir) > 0.0f)) return mk3(0.0f);
+    const f3 LA_DIR = normalize(a.c.lastPos - a.c.pos);
+    const Pbr mat_a = load_pbr_colored(S, a.c.mat, a.c.color);
+    const f3 f = bsdf_eval(mat_a, a.c.n, LA_DIR, connectDir) * dot(a.c.n, connectDir);
+    const f3 lflux = bflux / b.pdf;
+    // getLL_pdf(light, eye): the incoming direction runs from the eye vertex to the light vertex's POSITION on the sky disk (as written)
+    const float LL_pdf_A = rmis_last_pdf(mat_a, a.c, normalize(ld3(b.position) - a.c.pos));
+    const f3 fm0 = rmis_flux_multiplier(mat_a, a.c, -bn, LA_DIR);                       // getFluxMultiplier(eye, -connect_dir), connect_dir = light.normal
+    int light_label = a.lsub;
+    if (!CACHE && a.depth != 1) light_label = tree_label(p.light_tree, a.c.pos, a.c.n, -bn, cn);   // tracing_weight_eye: inver_dir = -Mid.normal for a direction (rmis.h:141)
+    const float wA = rmis_weight_eye_l(p, a.depth, a.lastZone, light_label, cn);
+    const f3 D_A_0 = a.R3 * LL_pdf_A * fm0 + mk3(wA);
+    const float pdf_A = S.env.project_pdf * fabsf(dot(bn, a.c.n));                     // getPdf_from_light_source, direction branch (183-187)
+    const float fm1 = (float)(1.0 / S.env.project_pdf);
+    const float D_A = sum3(D_A_0 * pdf_A * fm1 * lflux / a.singlePdf);
+    const float weight = sum3(gamma_ss(p, a.sub, b.subspace_id, cn) * lflux * (float)SPCBPT_CONNECTION_N);
+    const float pdf_B = bsdf_pdf(mat_a, a.c.n, LA_DIR, -bn) * rr_of(a.c.color);        // getPdf(eye, light, LB), end is a direction (158-162)
+    const float D_B = b.rmis_pointer * pdf_B / b.single_pdf;
+    const float w_rmis = weight / (weight + D_A + D_B);
+    if (w_out) *w_out = w_rmis;
+    return a.flux / a.pdf * f * bflux / b.pdf * w_rmis;
+}
+
 // connectVertex_SPCBPT (raygen.cu:253-303) with rmis::general_connection / connection_lightSource
 // (rmis.h:212-247 / 281-313) fused: every BSDF lobe is fetched once.
-template <bool COUNT, bool CACHE = false>
+// ENV = false: the scene has no environment map -- no vertex carries a direction flag, and the two tests fold away (the timed
+// kernels of a scene without a sky are instantiated so: 3 % of the frame)
+template <bool COUNT, bool CACHE = false, bool ENV = true>
 SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn, float* w_out = nullptr) {
+    if (ENV && (b.pad & SPCBPT_LV_DIRECTION)) return connect_direction<COUNT, CACHE>(p, a, b, cn, w_out);   // raygen.cu:255-258
     const DeviceScene& S = p.scene;
     const f3 bpos = ld3(b.position), bn = ld3(b.normal), bflux = ld3(b.flux);
     const f3 connectVec = a.c.pos - bpos;
@@ -843,9 +883,9 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
     int light_label, eye_label;
     if (CACHE) {
         light_label = a.lsub;                    // unused at depth 1, like the descent it replaces
-        eye_label = (int)b.pad - 1;              // unused for an emitter vertex
+        eye_label = (int)(b.pad & 0xffffu) - 1;  // unused for an emitter vertex
         // imported cache without labels (0), or a word that is not a label at all (spcbpt.h: never used as a row index unchecked)
-        if (b.pad - 1u >= (uint32_t)SPCBPT_NUM_SUBSPACE && b.depth != 0) eye_label = tree_label(p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), cn);
+        if ((b.pad & 0xffffu) - 1u >= (uint32_t)SPCBPT_NUM_SUBSPACE && b.depth != 0) eye_label = tree_label(p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), cn);
     } else {
         tree_label2(p.light_tree, a.c.pos, a.c.n, normalize(bpos - a.c.pos), a.depth != 1,
                     p.eye_tree, bpos, bn, normalize(a.c.pos - bpos), b.depth != 0, light_label, eye_label, cn);
@@ -863,7 +903,7 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
         D_A = sum3(D_A_0 * pdf_A * kPi * lflux / a.singlePdf);
         D_B = b.rmis_pointer * pdf_B / b.single_pdf;
     } else {  // general_connection
-        const VCore bc = core_of(b);
+        const VCore bc = core_of<ENV>(b);
         const Pbr mat_b = load_pbr_colored(S, bc.mat, bc.color);
         const f3 LB_DIR = normalize(bc.lastPos - bc.pos);
         fb = bsdf_eval(mat_b, bn, connectDir, LB_DIR);
@@ -885,8 +925,83 @@ SPC_DEV bool is_invalid(f3 a) {  // ISINVALIDVALUE raygen.cu:43
     return a.x > 100000.0f || isnan(a.x) || a.y > 100000.0f || isnan(a.y) || a.z > 100000.0f || isnan(a.z);
 }
 
-// ---- light sampling (cuProg.h:554-666, QUAD) ------------------------------------
+// ---- the environment map as a light (envInfo_device, cuProg.h:125-243; uv2dir / dir2uv, optixPathTracer.h:139-165) ------------
+// `2 * v - 1.0` and `0.5 * M_1_PIf` promote to double upstream; kept (these run once per light path).
+SPC_DEV f3 uv2dir(float u, float v) {
+    const float phi = asinf((float)(2 * v - 1.0));
+    const float theta = (float)(u / (0.5 * 0.318309886183790671538f) - kPi);
+    return mk3(cosf(phi) * sinf(theta), cosf(kPi * 0.5f - phi), cosf(phi) * cosf(theta));
+}
+SPC_DEV void dir2uv(f3 dir, float& u, float& v) {
+    const float theta = atan2f(dir.x, dir.z);
+    const float phi = kPi * 0.5f - acosf(dir.y);
+    u = (theta + kPi) * (0.5f * 0.318309886183790671538f);
+    v = 0.5f * (1.0f + sinf(phi));
+}
+SPC_DEV f3 env_sample(const DEnv& E, uint32_t& seed) {   // 164-184: the bisection of binary_sample over the texels, then a jittered point of the texel
+    const float index = rnd(seed);
+    int mid = E.size / 2 - 1, l = 0, r = E.size;
+    while (r - l > 1) {
+        if (index < E.cmf[mid]) r = mid + 1;
+        else l = mid + 1;
+        mid = (l + r) / 2 - 1;
+    }
+    const int cx = l % E.width, cy = l / E.width;
+    const float r1 = rnd(seed), r2 = rnd(seed);
+    return uv2dir((float)(cx + r1) / (float)E.width, (float)(cy + r2) / (float)E.height);
+}
+SPC_DEV int env_label(const DEnv& E, f3 dir) {   // 201-216
+    float u, v;
+    dir2uv(dir, u, v);
+    const int ux = min(max((int)floorf(u * E.div_level), 0), E.div_level - 1);
+    const int uy = min(max((int)floorf(v * E.div_level), 0), E.div_level - 1);
+    return SPCBPT_NUM_SUBSPACE - 1 - (ux * E.div_level + uy);
+}
+SPC_DEV f3 env_color(const DEnv& E, f3 dir) {   // 217-226: tex2D<float4>, normalised coordinates, wrap, linear (exact-fraction bilinear, like tex_fetch_rgb)
+    float u, v;
+    dir2uv(dir, u, v);
+    const float x = u * (float)E.width - 0.5f, y = v * (float)E.height - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const float ax = x - fx, ay = y - fy;
+    int x0 = (int)fx % E.width, y0 = (int)fy % E.height;
+    if (x0 < 0) x0 += E.width;
+    if (y0 < 0) y0 += E.height;
+    const int x1 = x0 + 1 == E.width ? 0 : x0 + 1, y1 = y0 + 1 == E.height ? 0 : y0 + 1;
+    const float4 t00 = ldq(E.tex, (size_t)y0 * E.width + x0), t10 = ldq(E.tex, (size_t)y0 * E.width + x1),
+                 t01 = ldq(E.tex, (size_t)y1 * E.width + x0), t11 = ldq(E.tex, (size_t)y1 * E.width + x1);
+    const float w00 = (1 - ax) * (1 - ay), w10 = ax * (1 - ay), w01 = (1 - ax) * ay, w11 = ax * ay;
+    return mk3(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x, w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+               w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z);
+}
+SPC_DEV float env_pdf(const DEnv& E, f3 dir) {   // 227-241 (M_PI: double)
+    float u, v;
+    dir2uv(dir, u, v);
+    const int cx = min((int)(u * E.width), E.width - 1), cy = min((int)(v * E.height), E.height - 1);
+    const int index = cx + cy * E.width;
+    const float pdf1 = index == 0 ? E.cmf[index] : E.cmf[index] - E.cmf[index - 1];
+    return (float)(pdf1 * E.size / (4 * 3.14159265358979323846));
+}
+
+// ---- light sampling (cuProg.h:554-666: QUAD, ENV) ------------------------------
 struct LightSampleD { f3 position, emission, normal; float pdf; int subspace; };
+// lightSample::operator() for the ENV light (611-619) + traceMode (660-664): the sky direction, its radiance, and the start of the
+// sub-path: a point on the disk of radius r that faces the scene from 10 r away (sample_projectPos, 185-195), pdf projectPdf per area.
+// Returns the sample with `normal` = minus the sky direction = the direction the sub-path is shot in (lightSample::normal, 639).
+SPC_DEV LightSampleD env_light_sample(const DeviceScene& S, uint32_t& seed, float& dir_pos_pdf) {
+    const DEnv& E = S.env;
+    LightSampleD s;
+    const f3 direction = env_sample(E, seed);
+    s.emission = env_color(E, direction);
+    s.subspace = env_label(E, direction);
+    s.pdf = env_pdf(E, direction) / (float)S.n_lights;
+    s.normal = -direction;
+    const float r1 = rnd(seed), r2 = rnd(seed);
+    const Onb onb(direction);
+    const f3 pos = cosine_sample_hemisphere(r1, r2);
+    s.position = 10 * E.r * direction + pos.x * E.r * onb.t + pos.y * E.r * onb.b + ld3(E.center);
+    dir_pos_pdf = E.project_pdf;
+    return s;
+}
 SPC_DEV LightSampleD light_reverse_sample(const DeviceScene& S, const DLight& L, float r1, float r2) {
     LightSampleD s;
     const float r3 = 1 - r1 - r2;

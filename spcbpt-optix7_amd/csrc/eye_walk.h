@@ -35,6 +35,7 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
     mid.c.lastPos = last.c.pos;
     mid.c.color = pbr.base;
     mid.c.lnp = fabsf(dot(last.c.n, ray_dir));
+    mid.c.lld = false;
     mid.c.mat = g.mat;
     // eye-tree label of the new vertex and light-tree relabel of the previous one (tracing_weight_eye, depth >= 3) together
     int light_label;

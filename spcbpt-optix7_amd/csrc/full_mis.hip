@@ -143,7 +143,7 @@ __global__ __launch_bounds__(FBLOCK) void k_spcbpt_no_rmis(const KParams p) {
     w.origin = ld3(p.eye);
     w.done = false; w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
     EyeVertex cur;   // init_EyeSubpath
-    cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
+    cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0; cur.c.lld = false;
     cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0; cur.lsub = 0;
     PVertex path[MAX_PATH];
     int size = 0;

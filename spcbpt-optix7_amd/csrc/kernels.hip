@@ -49,7 +49,8 @@ static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye
 // CACHE: label caching (device_lib.h).  <false, *, true> are the timed kernels; <true, false, false> evaluates in the reference's
 // order and charges its events (the contract's byte table, and the generic form for classifier trees with direction nodes);
 // <true, false, true> counts the events the TIMED kernels execute (roofline.frac: what runs, not what the reference would run).
-template <bool COUNT, bool BATCH, bool CACHE>
+// ENV = false (timed forms only, chosen by the launcher for a scene without an environment map): the direction tests are compiled out.
+template <bool COUNT, bool BATCH, bool CACHE, bool ENV = true>
 __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     // everything else a wave keeps in LDS sits in ONE record per wave: every field is then the wave's base (one SGPR) plus a
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
     f3 result = mk3(0.0f);
     int depth = 0;
     w.done = false; w.seed = 0; w.origin = w.dir = w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
-    cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0;
+    cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0; cur.c.lld = false;
     cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0; cur.lsub = 0;
 
     // software pipeline: the vertex built in iteration i is connected in iteration i + 1, in the same traversal pass that
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     const uint32_t* col = w_stack + owner;
                     const float4 po = w_org[owner];
                     EyeVertex a;
-                    a.c.pos = mk3(po.x, po.y, po.z); a.c.lnp = po.w;
+                    a.c.pos = mk3(po.x, po.y, po.z); a.c.lnp = po.w; a.c.lld = false;
                     a.c.n = mk3(__uint_as_float(col[0 * BLOCK]), __uint_as_float(col[1 * BLOCK]), __uint_as_float(col[2 * BLOCK]));
                     a.c.color = mk3(__uint_as_float(col[3 * BLOCK]), __uint_as_float(col[4 * BLOCK]), __uint_as_float(col[5 * BLOCK]));
                     a.c.lastPos = mk3(__uint_as_float(col[6 * BLOCK]), __uint_as_float(col[7 * BLOCK]), __uint_as_float(col[8 * BLOCK]));
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     float4* dst = reinterpret_cast<float4*>(&b);
 #pragma unroll
                     for (int q = 0; q < 6; q++) dst[q] = src[q];
-                    f3 res = connect_vertices<COUNT, CACHE>(p, a, b, cn);
+                    f3 res = connect_vertices<COUNT, CACHE, ENV>(p, a, b, cn);
                     if (is_invalid(res)) res = mk3(0.0f);
                     res = res / w_pmf[slot];
                     const bool ok = !is_invalid(res);
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         }
         if (fresh) {  // init_EyeSubpath (raygen.cu:216-231)
             fresh = false;
-            cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0;
+            cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0; cur.c.lld = false;
             cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0; cur.lsub = 0;
         }
         has_vertex = false;
@@ -318,13 +319,18 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                             cn.add(C_CONN);
                             const float4 bq0 = reinterpret_cast<const float4*>(f_lvc + lslot)[0];
                             const float4 bq1 = reinterpret_cast<const float4*>(f_lvc + lslot)[1];
-                            const f3 bias = mk3(bq0.x, bq0.y, bq0.z) - cur.c.pos;
+                            w_pmf[it * 64 + lane] = (float)f_path_count * pmf2 * pmf1;
+                            // a light vertex that is a DIRECTION of the environment map (only scenes with one pay the flag fetch):
+                            // visibilityTest shoots from the eye vertex to eye - 10 r n_b (cuProg.h:489-495)
+                            const bool b_dir = ENV && (f_lvc[lslot].pad & SPCBPT_LV_DIRECTION) != 0u;
+                            const f3 target = b_dir ? -10 * S.env.r * mk3(bq1.x, bq1.y, bq1.z) + cur.c.pos : mk3(bq0.x, bq0.y, bq0.z);
+                            const f3 bias = target - cur.c.pos;
                             const float len = sqrtf(dot(bias, bias));
                             const f3 sdir = bias / len;
-                            w_pmf[it * 64 + lane] = (float)f_path_count * pmf2 * pmf1;
                             // a pair that faces away on either side has a BSDF factor of exactly zero (bsdf_eval / the one-sided
                             // emitter term of connect_vertices): its shadow ray cannot change the pixel and is not traced
-                            if (!null_connection(cur.c.pos, cur.c.n, mk3(bq0.x, bq0.y, bq0.z), mk3(bq1.x, bq1.y, bq1.z)))
+                            if (b_dir ? !null_connection_direction(cur.c.n, mk3(bq1.x, bq1.y, bq1.z))
+                                      : !null_connection(cur.c.pos, cur.c.n, mk3(bq0.x, bq0.y, bq0.z), mk3(bq1.x, bq1.y, bq1.z)))
                                 rq = make_float4(sdir.x, sdir.y, sdir.z, len);
                         }
                         w_ray[it * 64 + lane] = rq;
@@ -383,7 +389,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
             cn.add(C_CLOSEST);
             f3 current = mk3(0.0f), visA = mk3(0.0f), visB = mk3(0.0f);
             if (!traverse<false, COUNT>(S, st, origin, dir, kEps, 1e16f, h, cn)) {
-                done = true;  // __miss__constant_radiance, no env map
+                done = true;  // __miss__constant_radiance (raygen.cu:687-697): the sky is seen by primary rays only
+                if (depth == 0 && S.env.valid) result = throughput * env_color(S.env, dir);
             } else {
                 const Geom g = local_geometry(S, h);
                 Pbr pbr = load_pbr(S, g.mat);
@@ -407,7 +414,18 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
                     const float rr = clampf(max3(pbr.base), SPCBPT_MIN_RR_RATE, 1.0f);
                     const int lid = pick_light(S, seed);
                     const DLight& L = S.lights[lid];
-                    {
+                    if (L.type == 1) {   // next-event estimation of the environment map (hit_program.cu:502-518)
+                        const f3 direction = env_sample(S.env, seed);
+                        const f3 emission = env_color(S.env, direction);
+                        const float lpdf = env_pdf(S.env, direction) / (float)S.n_lights;
+                        const f3 V = -normalize(dir);
+                        const float L_dot_N = dot(direction, N);
+                        if (L_dot_N > 0.0f) {
+                            visA = g.P; visB = g.P + direction + mk3(S.env.r * 2);   // float3 + float adds the scalar to every component: as written upstream
+                            const f3 eval = bsdf_eval(pbr, N, V, direction);
+                            current = throughput * emission / lpdf * eval * L_dot_N;
+                        }
+                    } else {
                         const float r1 = rnd(seed), r2 = rnd(seed);
                         const LightSampleD ls = light_reverse_sample(S, L, r1, r2);
                         const f3 dvec = ls.position - g.P;
@@ -548,12 +566,21 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
         if (has_core && !in_path) {
             const int lid = pick_light(S, seed);
             const DLight& L = S.lights[lid];
-            const float r1 = rnd(seed), r2 = rnd(seed);
-            const LightSampleD ls = light_reverse_sample(S, L, r1, r2);
-            const float d1 = rnd(seed), d2 = rnd(seed);  // traceMode
-            const Onb onb(ls.normal);
-            dir = onb.to_world(cosine_sample_hemisphere(d1, d2));
-            const float dir_pdf = fabsf(dot(dir, ls.normal)) * kInvPi;
+            LightSampleD ls;
+            float dir_pdf;
+            uint32_t origin_flags = 0u;
+            if (L.type == 1) {   // the environment map: a sky direction, the sub-path starts on the sky disk and runs against it
+                ls = env_light_sample(S, seed, dir_pdf);
+                dir = ls.normal;
+                origin_flags = SPCBPT_LV_DIRECTION;
+            } else {
+                const float r1 = rnd(seed), r2 = rnd(seed);
+                ls = light_reverse_sample(S, L, r1, r2);
+                const float d1 = rnd(seed), d2 = rnd(seed);  // traceMode
+                const Onb onb(ls.normal);
+                dir = onb.to_world(cosine_sample_hemisphere(d1, d2));
+                dir_pdf = fabsf(dot(dir, ls.normal)) * kInvPi;
+            }
             origin = ls.position;
             path_id = (uint32_t)(p.core_begin + local_core) * (uint32_t)p.m_per_core + (uint32_t)npaths;
             cn.add(C_LIGHT);
@@ -565,7 +592,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
             v.color[0] = v.color[1] = v.color[2] = 0.0f; v.last_lum = 0.0f;
             v.last_position[0] = v.last_position[1] = v.last_position[2] = 0.0f; v.last_normal_projection = 0.0f;
             v.material_id = (int16_t)L.id; v.subspace_id = (int16_t)ls.subspace; v.depth = 0; v.last_zone_id = 0;
-            v.path_id = path_id; v.pad = 0;
+            v.path_id = path_id; v.pad = origin_flags;
             store(v);
             origins++;
             last = v;
@@ -599,7 +626,8 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
                     if (!(pdf > 0.0f)) done = true;
                     const f3 last_n = ld3(last.normal), last_flux = ld3(last.flux);
-                    const float pdf_G = fabsf(dot(N, dir) * dot(last_n, dir)) / (h.t * h.t);
+                    const bool last_dir = (last.pad & SPCBPT_LV_DIRECTION) != 0u;   // LastVertex.is_DIRECTION(): parallel rays from the sky, no 1 / t^2 (hit_program.cu:372-375)
+                    const float pdf_G = last_dir ? fabsf(dot(N, dir) * dot(last_n, dir)) : fabsf(dot(N, dir) * dot(last_n, dir)) / (h.t * h.t);
                     const f3 flux = last.depth == 0 ? last_flux * pdf_G : next_flux * last_flux * pdf_G;
                     LightVertex m;
                     m.position[0] = g.P.x; m.position[1] = g.P.y; m.position[2] = g.P.z;
@@ -607,6 +635,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     m.flux[0] = flux.x; m.flux[1] = flux.y; m.flux[2] = flux.z;
                     m.color[0] = pbr.base.x; m.color[1] = pbr.base.y; m.color[2] = pbr.base.z;
                     m.last_position[0] = last.position[0]; m.last_position[1] = last.position[1]; m.last_position[2] = last.position[2];
+                    if (last_dir) { const f3 lp = g.P - dir; m.last_position[0] = lp.x; m.last_position[1] = lp.y; m.last_position[2] = lp.z; }   // hit_program.cu:386-389
                     m.last_normal_projection = fabsf(dot(last_n, dir));
                     m.material_id = (int16_t)g.mat;
                     // light-tree label of the new vertex and eye-tree relabel of the previous one (tracing_weight_light) in lock-step
@@ -617,7 +646,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                         int own;
                         tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, g.P, N, inv_dir, true, new_label, own, cn);
                         own_eye_label = (uint32_t)own + 1u;
-                        eye_label = (int)last.pad - 1;   // the previous vertex's, cached when it was created (unused when it is the origin)
+                        eye_label = (int)(last.pad & 0xffffu) - 1;   // the previous vertex's, cached when it was created (unused when it is the origin)
                     } else {
                         tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
                                     new_label, eye_label, cn);
@@ -628,7 +657,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
                     m.pdf = last.pdf * m.single_pdf;
                     m.last_lum = sum3(last_flux / last.pdf);
-                    m.path_id = path_id; m.pad = own_eye_label;
+                    m.path_id = path_id; m.pad = own_eye_label | (last_dir ? SPCBPT_LV_LAST_DIRECTION : 0u);   // isLastVertex_direction (hit_program.cu:412: the predecessor is the origin)
                     if (last.depth == 0) {
                         m.rmis_pointer = last.rmis_pointer / last.single_pdf;  // tracing_init_light
                     } else {  // tracing_update_light (rmis.h:80-94)
@@ -1194,7 +1223,7 @@ __global__ __launch_bounds__(BLOCK) void k_pretrace(const KParams p, uint32_t it
     w.done = false; w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
     EyeVertex buffer[PRETRACE_MAX];
     EyeVertex& cam = buffer[0];
-    cam.c.pos = w.origin; cam.c.n = w.dir; cam.c.color = mk3(0.0f); cam.c.lastPos = w.origin; cam.c.lnp = 0.0f; cam.c.mat = 0;
+    cam.c.pos = w.origin; cam.c.n = w.dir; cam.c.color = mk3(0.0f); cam.c.lastPos = w.origin; cam.c.lnp = 0.0f; cam.c.mat = 0; cam.c.lld = false;
     cam.flux = mk3(1.0f); cam.R3 = mk3(0.0f); cam.pdf = 1.0f; cam.singlePdf = 1.0f; cam.sub = 0; cam.lastZone = 0; cam.depth = 0;
     int buffer_size = 1, resample_number = 0, depth = 0;
     spcbpt_pretrace_path path;
@@ -1227,7 +1256,10 @@ __global__ __launch_bounds__(BLOCK) void k_pretrace(const KParams p, uint32_t it
         buffer[buffer_size] = mid;
         buffer_size++;
         // next-event candidate
-        const int lid = pick_light(S, w.seed);
+        // QUAD lights only: upstream picks among all lights here too (raygen.cu:820-823) and then reads the sample's position, which
+        // the ENV branch never sets -- undefined, so the sky is left out of the training pass's next-event candidates
+        const int n_quads = S.n_lights - (S.env.valid ? 1 : 0);
+        const int lid = min(max((int)floorf(rnd(w.seed) * n_quads), 0), n_quads - 1);
         const float r1 = rnd(w.seed), r2 = rnd(w.seed);
         const LightSampleD ls = light_reverse_sample(S, S.lights[lid], r1, r2);
         const f3 vis_vec = ls.position - mid.c.pos;
@@ -1286,7 +1318,8 @@ void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s)
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     if (variant == 1) hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
     else if (variant == 2) hipLaunchKernelGGL((k_spcbpt<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL((k_spcbpt<false, false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else if (p.scene.env.valid) hipLaunchKernelGGL((k_spcbpt<false, false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_spcbpt<false, false, true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 // p.frames / p.n_frames describe the batch; p.n_tiles is the tile count of ONE frame
 int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
@@ -1299,7 +1332,8 @@ int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
 void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
     const int blocks = spcbpt_batch_blocks(p, max_blocks);
     if (blocks <= 0) return;
-    hipLaunchKernelGGL((k_spcbpt<false, true, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
+    if (p.scene.env.valid) hipLaunchKernelGGL((k_spcbpt<false, true, true, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_spcbpt<false, true, true, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
 }
 int spcbpt_blocks_per_cu(int variant) {
     int n = 0;

@@ -46,9 +46,20 @@ struct DLight {  // 80 B; Light::QUAD (cuda/Light.h:65-84); u, v are absolute co
     float u[3]; int32_t div_level;
     float v[3]; int32_t ss_base;
     float emission[3]; int32_t id;
-    float normal[3]; int32_t pad;
+    float normal[3]; int32_t type;   // 0 = QUAD, 1 = ENV (the environment map: every other field unused)
 };
 static_assert(sizeof(DLight) == 80, "DLight");
+
+// params.sky (envInfo, optixPathTracer.h:98-137): the environment map as a light.  `tex` is the .hdr raster with its rows flipped
+// (HDRLoader::loadTexture), `cmf` the sampling CMF over the raster as read (env_params_setup): device copies owned by the context.
+struct DEnv {
+    const float* tex;     // width x height float4
+    const float* cmf;     // size
+    float center[3]; float r;
+    int32_t width, height, size, div_level;
+    int32_t valid; float project_pdf;   // 1 / (pi r^2)
+    int32_t pad[2];
+};
 
 struct DTexture {
     const uint32_t* rgba;  // device pointer, RGBA8 packed little-endian
@@ -95,8 +106,9 @@ struct DeviceScene {
     const DMaterial* mats;
     const DLight* lights;
     const DTexture* tex;
-    int32_t n_lights;
+    int32_t n_lights;        // QUAD lights, then the ENV light if the scene has an environment map
     int32_t n_mats;
+    DEnv env;
 };
 
 // One frame of a batched eye launch (k_spcbpt<*, BATCH = true>): what differs between the frames that share a tile queue.

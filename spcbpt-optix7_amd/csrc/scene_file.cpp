@@ -9,6 +9,7 @@
 // Textures: JPEG, PNG and binary PPM (image_file.cpp, held bit-exactly to the reference's stb_image); a file that cannot be
 // decoded is reported in the warnings string and the material renders with its flat colour.
 // The `.scene` grammar itself is PARITY UNPINNED: sceneLoader.cpp needs the CMake-generated sampleConfig.h (via sutil.h).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -149,6 +150,11 @@ bool load_obj(const std::string& path, spcbpt_scene_file& s, int material) {
             }
         }
         const size_t nv = s.V.size() / 3 - v0;
+        for (size_t i = 0; i < nv; i += 3)   // get_aabb(std::vector<float>): floats i, i + 1, i + 2 for i = 0, 3, 6, ... < size / 3
+            for (int k = 0; k < 3; k++) {
+                const float x = s.V[3 * v0 + i + (size_t)k];
+                s.ref_lo[k] = std::min(s.ref_lo[k], x); s.ref_hi[k] = std::max(s.ref_hi[k], x);
+            }
         uv.resize(2 * nv, 0.0f);  // scene_shift.cpp:204-207 (pads, never truncates: uv.size() <= 2 nv by construction)
         s.UV.insert(s.UV.end(), uv.begin(), uv.end());
         group.clear();
@@ -279,6 +285,8 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
                 sscanf(line, " lookat %f %f %f", &s->lookat[0], &s->lookat[1], &s->lookat[2]);
                 sscanf(line, " up %f %f %f", &s->up[0], &s->up[1], &s->up[2]);
                 sscanf(line, " fov %f", &s->fov);
+                char ef[256] = "";
+                if (sscanf(line, " env_file %255s", ef) == 1) s->env_file = fix_slashes(ef);   // (env_lum is parsed upstream and used nowhere)
             }
         }
         if (strstr(line, "mesh")) {  // sceneLoader.cpp:258-300
@@ -331,7 +339,38 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
         if (k >= s->materials.size()) { s->warnings += "mesh " + mesh_files[k] + " has no material; skipped; "; continue; }
         if (!load_obj(root + "/" + mesh_files[k], *s, (int)k)) s->warnings += "mesh " + mesh_files[k] + " could not be read; ";
     }
+    for (const spcbpt_quad_light& L : s->lights)   // the light quads' meshes enter the scene box with all four corners (scene_shift.cpp:276-317)
+        for (int c = 0; c < 4; c++)
+            for (int k = 0; k < 3; k++) {
+                const float x = L.position[k] + ((c & 1) ? L.u[k] : 0.0f) + ((c & 2) ? L.v[k] : 0.0f);
+                s->ref_lo[k] = std::min(s->ref_lo[k], x); s->ref_hi[k] = std::max(s->ref_hi[k], x);
+            }
+    if (!s->env_file.empty()) {   // env_params_setup: <data>/<env_file> through HDRLoader
+        const std::string ep = root + "/" + s->env_file;
+        int w = 0, h = 0;
+        if (spcbpt_hdr_load(ep.c_str(), &w, &h, nullptr, 0) == SPCBPT_OK) {
+            s->env_rgba.resize((size_t)w * h * 4);
+            if (spcbpt_hdr_load(ep.c_str(), &w, &h, s->env_rgba.data(), s->env_rgba.size()) == SPCBPT_OK) { s->env_w = w; s->env_h = h; }
+        }
+        if (!s->env_w) { s->env_rgba.clear(); s->warnings += "environment map " + s->env_file + " not loaded (missing, or not a Radiance RGBE file); "; }
+    }
     *out = s;
+    return SPCBPT_OK;
+}
+
+// The scene's environment map (width = 0: none) and the sky.center / sky.r the reference derives from its scene box
+int spcbpt_scene_file_environment(spcbpt_scene_file* s, const float** rgba, int* width, int* height, float center[3], float* radius) {
+    if (!s) return SPCBPT_ERR_INVALID_ARG;
+    if (rgba) *rgba = s->env_w ? s->env_rgba.data() : nullptr;
+    if (width) *width = s->env_w;
+    if (height) *height = s->env_h;
+    double d2 = 0.0;
+    for (int k = 0; k < 3; k++) {
+        if (center) center[k] = 0.5f * (s->ref_lo[k] + s->ref_hi[k]);    // Aabb::center
+        const double e = (double)s->ref_lo[k] - (double)s->ref_hi[k];
+        d2 += e * e;
+    }
+    if (radius) *radius = (float)sqrt(d2);                                 // length(aabb.m_min - aabb.m_max)
     return SPCBPT_OK;
 }
 

@@ -19,6 +19,13 @@ struct spcbpt_scene_file {
     int width = 1920, height = 1001;  // sceneLoader.cpp:201-203 defaults (parsed, ignored by the app)
     int n_mesh_blocks = 0;
     std::string warnings;
+    // environment map: `env_file` of the cameraSetting block (sceneLoader.cpp:242), read with the HDRLoader restatement
+    std::string env_file;
+    std::vector<float> env_rgba;   // width x height RGBA floats, row 0 = top
+    int env_w = 0, env_h = 0;
+    // the box the reference's sky.center / sky.r come from (optixPathTracer.cpp:458-459): per OBJ shape get_aabb(std::vector<float>)
+    // covers only the first third of its vertices (scene_shift.cpp:21-32); the light quads enter with all four corners
+    float ref_lo[3] = {1e30f, 1e30f, 1e30f}, ref_hi[3] = {-1e30f, -1e30f, -1e30f};
 };
 
 

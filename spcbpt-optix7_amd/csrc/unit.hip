@@ -31,7 +31,7 @@ SPC_DEV void stf(uint32_t* w, float v) { *w = __float_as_uint(v); }
 SPC_DEV EyeVertex load_eye_vertex(const uint32_t* w) {
     EyeVertex a;
     a.c.pos = ldw3(w); a.c.n = ldw3(w + 3); a.flux = ldw3(w + 6); a.c.color = ldw3(w + 9); a.c.lastPos = ldw3(w + 12); a.R3 = ldw3(w + 15);
-    a.pdf = ldf(w + 18); a.singlePdf = ldf(w + 19); a.c.lnp = ldf(w + 20);
+    a.pdf = ldf(w + 18); a.singlePdf = ldf(w + 19); a.c.lnp = ldf(w + 20); a.c.lld = false;
     a.c.mat = (int)w[21]; a.sub = (int)w[22]; a.depth = (int)w[23]; a.lastZone = (int)w[24];
     return a;
 }

@@ -244,6 +244,83 @@ def simple_room(n: int = 4) -> Scene:
     return b.finish(mats, lights, camera=cam, name="simple_room")
 
 
+def sky_texture(width: int = 64, height: int = 32, sun=(0.62, 0.30), sun_lum: float = 60.0) -> np.ndarray:
+    """A small procedural environment map as a .hdr raster ((h, w, 4) float32, row 0 = top): blue-to-white gradient plus a sun blob
+    at raster position (u, v) = sun.  (The reference samples the raster as read but looks colours up in the row-flipped texture,
+    so the sun is IMPORTANCE-sampled upside down: the scene keeps it away from the horizon to make that visible in the tests.)"""
+    y, x = np.mgrid[0:height, 0:width].astype(np.float32)
+    u, v = (x + 0.5) / width, (y + 0.5) / height
+    sky = np.stack([0.25 + 0.35 * v, 0.35 + 0.35 * v, 0.7 + 0.2 * v], -1)
+    d2 = ((u - sun[0]) * 2.0) ** 2 + (v - sun[1]) ** 2
+    blob = sun_lum * np.exp(-d2 / (2 * 0.03 ** 2))
+    rgb = sky + blob[..., None] * np.array([1.0, 0.9, 0.7], np.float32)
+    return np.concatenate([rgb, np.zeros((height, width, 1))], -1).astype(np.float32)
+
+
+def courtyard(n: int = 6, with_quad_light: bool = True) -> Scene:
+    """An open-top yard for the environment-map rows (f4): floor, three walls (one glossy), a box that throws a sky shadow, NO
+    ceiling; a dim quad light on a wall (the reference needs at least one QUAD light for its training pass) and a sky with a sun."""
+    b = _Builder()
+    b.grid((-1.5, 0, 1.5), (3, 0, 0), (0, 0, -3), n, n, 0)          # floor (normal +y)
+    b.grid((-1.5, 0, -1.5), (3, 0, 0), (0, 1.6, 0), n, n, 1)        # back wall, glossy
+    b.grid((-1.5, 0, 1.5), (0, 0, -3), (0, 1.6, 0), n, n, 2)        # left wall
+    b.grid((1.5, 0, -1.5), (0, 0, 3), (0, 1.6, 0), n, n, 0)         # right wall
+    b.box((-0.45, 0.0, -0.35), (0.35, 0.8, 0.45), 2, sub=max(1, n // 2), rot_y=0.5)
+    mats = [dict(color=(0.7, 0.68, 0.62), roughness=0.6, metallic=0.0),
+            dict(color=(0.8, 0.6, 0.4), roughness=0.2, metallic=0.5),
+            dict(color=(0.25, 0.35, 0.75), roughness=0.45, metallic=0.0)]
+    lights = [dict(position=(1.497, 0.9, -0.3), u=(0, 0, 0.6), v=(0, 0.4, 0), emission=(2.0, 1.6, 1.2), div_level=3)] if with_quad_light else []
+    cam = dict(eye=(0.0, 1.9, 3.6), lookat=(0.0, 0.5, 0.0), up=(0, 1, 0), fov=45.0)
+    sc = b.finish(mats, lights, camera=cam, name="courtyard")
+    lo, hi = sc.vertices.min(0), sc.vertices.max(0)
+    sc.environment = dict(rgba=sky_texture(), center=(0.5 * (lo + hi)).astype(np.float32), radius=float(np.linalg.norm(hi - lo)))
+    return sc
+
+
+def write_hdr(path: str, rgba: np.ndarray, rle: bool = True, exposure: float = None) -> None:
+    """Writes an (h, w, >= 3) float raster as a Radiance RGBE .hdr (new-style RLE scanlines when `rle` and 8 <= w < 32768, else flat):
+    the file format HDRLoader reads (scene_shift.cpp:334-500).  A test / authoring helper; mantissas are floor(value / 2^(e - 8))."""
+    a = np.asarray(rgba, np.float64)[..., :3]
+    h, w = a.shape[:2]
+    m = a.max(-1)
+    e = np.zeros_like(m, dtype=np.int64)
+    nz = m > 1e-38
+    e[nz] = np.floor(np.log2(m[nz])).astype(np.int64) + 1          # m < 2^e
+    scale = np.where(nz, np.ldexp(1.0, (8 - e).astype(np.int64)), 0.0)
+    mant = np.clip(np.floor(a * scale[..., None]), 0, 255).astype(np.uint8)
+    rgbe = np.concatenate([mant, np.where(nz, e + 128, 0).astype(np.uint8)[..., None]], -1)
+    rgbe[~nz] = 0
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\n# written by spcbpt-optix7_amd/scenes.py\nFORMAT=32-bit_rle_rgbe\n")
+        if exposure is not None:
+            f.write(b"EXPOSURE=%g\n" % exposure)
+        f.write(b"\n-Y %d +X %d\n" % (h, w))
+        for y in range(h):
+            row = rgbe[y]
+            if not rle or w < 8 or w > 0x7fff:
+                f.write(row.tobytes()); continue
+            f.write(bytes([2, 2, (w >> 8) & 0xff, w & 0xff]))
+            for ch in range(4):
+                col = row[:, ch]
+                x = 0
+                while x < w:
+                    run = 1
+                    while x + run < w and run < 127 and col[x + run] == col[x]:
+                        run += 1
+                    if run >= 4:
+                        f.write(bytes([128 + run, int(col[x])])); x += run
+                    else:   # literal span up to the next run of >= 4 (or 128 bytes)
+                        start = x
+                        while x < w and x - start < 128:
+                            r2 = 1
+                            while x + r2 < w and r2 < 4 and col[x + r2] == col[x]:
+                                r2 += 1
+                            if r2 >= 4:
+                                break
+                            x += 1
+                        f.write(bytes([x - start]) + col[start:x].tobytes())
+
+
 def needle_room(n_needles: int = 20000, seed: int = 11) -> Scene:
     """Test scene for deep traversal stacks: the Cornell room with a cloud of long sliver triangles that span the whole room.
     Every sliver's bounding box covers a large part of the scene, so sibling boxes overlap at every level of the BVH, a ray
@@ -299,7 +376,11 @@ def write_scene(scene: Scene, data_root: str, rel_dir: str) -> str:
         lines += ["}", ""]
     c = scene.camera
     lines += ["cameraSetting", "{", "    eye %.9g %.9g %.9g" % tuple(c["eye"]), "    lookat %.9g %.9g %.9g" % tuple(c["lookat"]),
-              "    up %.9g %.9g %.9g" % tuple(c.get("up", (0, 1, 0))), "    fov %.9g" % c.get("fov", 35.0), "}", ""]
+              "    up %.9g %.9g %.9g" % tuple(c.get("up", (0, 1, 0))), "    fov %.9g" % c.get("fov", 35.0)]
+    if getattr(scene, "environment", None):
+        write_hdr(os.path.join(data_root, f"{rel_dir}/sky.hdr"), scene.environment["rgba"])
+        lines.append(f"    env_file {rel_dir}/sky.hdr")
+    lines += ["}", ""]
     uv = scene.texcoords if scene.texcoords is not None else np.zeros((scene.vertices.shape[0], 2), np.float32)
     for k in range(len(scene.materials)):
         tris = scene.indices[scene.tri_material == k]

@@ -183,6 +183,24 @@ class Oracle:
         """Test knob: eye sub-paths that leave the scene see the sky, weighted by rmis::light_hit_env (uncalled upstream): completes the estimator."""
         self.l.orc_set_env_miss_strategy(self.h, int(on))
 
+    def env_partition(self, depth, n, frame=1):
+        """Test utility (orc_debug_env_partition): RMIS weights of every strategy of n camera paths that leave the scene after `depth`
+        surface vertices: (weights [n, 6]: sum, miss, k = 0 .. 3; first-principles weights [n, 5]: miss, k = 0 .. 3)."""
+        out = np.zeros((n, 7), np.float32); truth = np.zeros((n, 5), np.float32)
+        self.l.orc_debug_env_partition.restype = C.c_int
+        m = self.l.orc_debug_env_partition(self.h, int(depth), int(n), C.c_uint(frame), out.ctypes.data_as(C.c_void_p), truth.ctypes.data_as(C.c_void_p))
+        if m < 0: raise RuntimeError("env_partition: needs an environment map and 1 <= depth <= 4")
+        return out[:m, :6], truth[:m]
+
+    def quad_partition(self, depth, n, frame=1):
+        """Test utility (orc_debug_quad_partition): the same for camera paths that END ON A QUAD EMITTER after `depth` surface vertices:
+        (weights [n, 6]: sum, emitter hit, k = 0 .. 3; first-principles weights [n, 5])."""
+        out = np.zeros((n, 7), np.float32); truth = np.zeros((n, 5), np.float32)
+        self.l.orc_debug_quad_partition.restype = C.c_int
+        m = self.l.orc_debug_quad_partition(self.h, int(depth), int(n), C.c_uint(frame), out.ctypes.data_as(C.c_void_p), truth.ctypes.data_as(C.c_void_p))
+        if m < 0: raise RuntimeError("quad_partition: 1 <= depth <= 4")
+        return out[:m, :6], truth[:m]
+
     def set_count_as_executed(self, on):
         """Test knob, counters only: charge the classification and first-stage-sampling events the product's timed kernels execute
         (labels cached per vertex, two counting passes per first stage) instead of the reference's."""

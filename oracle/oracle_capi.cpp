@@ -420,3 +420,185 @@ int orc_eye_step(orc_ctx* c, const orc_eye_step_in* in, int n, orc_eye_step_out*
 }
 
 }  // extern "C"
+
+// ---- test utility: do the recursive-MIS weights of the sky's strategies form a partition of unity?  For `n` camera paths that
+// leave the scene after exactly `depth` surface vertices (c, x1 .. xD, sky direction w), every strategy that can produce the path
+// is built by the generation code itself -- the eye sub-path as traced, the light sub-path y0 (the sky direction w), y1 = xD,
+// y2 = xD-1 ... re-traced from the sky with the scattering directions forced -- and its weight is evaluated by the very functions
+// the renderers call: connection_direction_lightSource(eD, y0), general_connection(e_d, y_k) for d + k = D, light_hit_env for the
+// miss.  out[7 * i]: the weights' sum; [1]: miss; [2 .. 5]: k = 0 .. 3; [6]: sum of the weights RECOMPUTED from first principles
+// (rate of a strategy = eye pdf x connectRate_SOL x light pdf; miss = eye pdf x solid-angle pdf) -- 1 by construction, a check of
+// the check.  Returns the number of paths found.
+extern "C" int orc_debug_env_partition(orc_ctx* c, int depth, int n, unsigned frame, float* out, float* truth) {
+    Params P = c->P;
+    P.counters = nullptr;
+    const Scene& S = *P.scene;
+    if (!S.sky.valid || depth < 1 || depth > 4) return -1;
+    int found = 0;
+    for (unsigned pix = 0; found < n && pix < 4000000u; pix++) {
+        const unsigned x = pix % P.width, y = (pix / P.width) % P.height;
+        uint32_t seed = tea<4>(y * P.width + x, frame + pix / (P.width * P.height));
+        float jx = rnd(seed), jy = rnd(seed);
+        const float dx = 2.0f * (((float)x + jx) / (float)P.width) - 1.0f, dy = 2.0f * (((float)y + jy) / (float)P.height) - 1.0f;
+        float3 dir = normalize(dx * P.U + dy * P.V + P.W), org = P.eye;
+        PayloadBDPTVertex prd;
+        prd.clear(); prd.seed = seed; prd.ray_direction = dir; prd.origin = org;
+        init_EyeSubpath(prd.path, org, dir);
+        std::vector<BDPTVertex> ev;   // e1 .. eD
+        bool ok = true;
+        for (int d = 0; d < depth; d++) {
+            const int before = prd.path.size;
+            trace_subpath(P, prd.origin, prd.ray_direction, &prd, false);
+            if (prd.path.size == before || prd.path.hit_lightSource() || prd.done) { ok = false; break; }
+            ev.push_back(prd.path.currentVertex());
+        }
+        if (!ok) continue;
+        // the next segment must leave the scene
+        const float3 w = prd.ray_direction;
+        if (S.closest_hit(prd.origin, w, SPCBPT_SCENE_EPSILON, 1e16f, nullptr).tri >= 0) continue;
+        const float next_single_pdf = prd.path.nextVertex().singlePdf;   // solid-angle pdf x RR of the direction w at xD
+        // ---- miss strategy
+        Params Pm = P; Pm.env_miss_strategy = true;
+        PayloadBDPTVertex pm = prd;
+        trace_subpath(Pm, prd.origin, w, &pm, false);
+        if (!(float3weight(pm.path.currentVertex().flux) > 0.0f)) continue;   // (as in orc_debug_quad_partition: a zero-flux path)
+        const float w_miss = 1.0f / pm.path.currentVertex().RMIS_pointer;
+        // ---- the light sub-path of the same path: y0 = direction w with the disk point above xD, y1 = xD, y2 = xD-1, ...
+        const Light& sky_light = S.lights.back();
+        lightSample ls;
+        ls.bindLight = &sky_light; ls.direction = w; ls.emission = S.sky.color(w); ls.subspaceId = S.sky.getLabel(w); ls.uv = dir2uv(w);
+        ls.pdf = S.sky.pdf(w) / (float)S.lights.size();
+        const float3 xD = ev[depth - 1].position;
+        ls.position = xD + dot(S.sky.center + 10 * S.sky.r * w - xD, w) * w;
+        ls.dir_pdf = S.sky.projectPdf();
+        PayloadBDPTVertex pl;
+        pl.clear();
+        init_lightSubPath_from_lightSample(ls, pl.path);
+        std::vector<BDPTVertex> lv;   // y0 .. yD
+        lv.push_back(pl.path.currentVertex());
+        float3 lo = ls.position, ld = -w;
+        for (int k = 1; k <= depth && ok; k++) {
+            const int before = pl.path.size;
+            pl.done = false;
+            trace_subpath(P, lo, ld, &pl, true);
+            if (pl.path.size == before) { ok = false; break; }
+            BDPTVertex& Mid = pl.path.currentVertex();
+            const BDPTVertex& want = ev[depth - k];
+            if (length(Mid.position - want.position) > 1e-3f) { ok = false; break; }
+            lv.push_back(Mid);
+            if (k == depth) break;
+            // force the scattered direction towards the next vertex of the path (x_{D-k}) and set what Sample / Pdf / Eval would have
+            const float3 nd = normalize(ev[depth - k - 1].position - Mid.position);
+            Pbr pbr = S.materials[Mid.materialId];
+            pbr.base_color = Mid.color;
+            BDPTVertex& Next = pl.path.nextVertex();
+            Next.flux = Eval(pbr, Mid.normal, -ld, nd);
+            Next.singlePdf = Pdf(pbr, Mid.normal, -ld, nd) * rr_rate_of(Mid.color);
+            lo = Mid.position; ld = nd;
+        }
+        if (!ok) continue;
+        float ws[4] = {0, 0, 0, 0}, rate[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < depth && k < 4; k++) {
+            const BDPTVertex& e = ev[depth - 1 - k];
+            const BDPTVertex& l = lv[k];
+            ws[k] = k == 0 ? rmis::connection_direction_lightSource(P, e, l) : rmis::general_connection(P, e, l);
+            rate[k] = e.pdf * float3weight(connectRate_SOL(P, e.subspaceId, l.subspaceId, l.flux / l.pdf)) * l.pdf;
+        }
+        rate[4] = ev[depth - 1].pdf * next_single_pdf;
+        double rs = rate[4];
+        for (int k = 0; k < depth && k < 4; k++) rs += rate[k];
+        float* o = out + 7 * (size_t)found;
+        o[0] = w_miss + ws[0] + ws[1] + ws[2] + ws[3]; o[1] = w_miss; o[2] = ws[0]; o[3] = ws[1]; o[4] = ws[2]; o[5] = ws[3]; o[6] = 1.0f;
+        float* t = truth + 5 * (size_t)found;
+        t[0] = (float)(rate[4] / rs);
+        for (int k = 0; k < 4; k++) t[1 + k] = (float)(rate[k] / rs);
+        found++;
+    }
+    return found;
+}
+
+// The same for QUAD emitters: camera paths c, x1 .. xD whose next segment HITS an emitter at z (front side).  Strategies: the
+// emitter hit (rmis::light_hit through __closesthit__eyeSubpath_LightSource), e_D <-> y0 = z (connection_lightSource),
+// e_{D-k} <-> y_k for k >= 1 (general_connection), the light sub-path re-traced from z with its directions forced.  out / truth as above
+// ([1] / [0] = the emitter hit).  Rates in area measure over (x1 .. xD, z).
+extern "C" int orc_debug_quad_partition(orc_ctx* c, int depth, int n, unsigned frame, float* out, float* truth) {
+    Params P = c->P;
+    P.counters = nullptr;
+    const Scene& S = *P.scene;
+    if (depth < 1 || depth > 4) return -1;
+    int found = 0;
+    for (unsigned pix = 0; found < n && pix < 40000000u; pix++) {
+        const unsigned x = pix % P.width, y = (pix / P.width) % P.height;
+        uint32_t seed = tea<4>(y * P.width + x, frame + pix / (P.width * P.height));
+        float jx = rnd(seed), jy = rnd(seed);
+        const float dx = 2.0f * (((float)x + jx) / (float)P.width) - 1.0f, dy = 2.0f * (((float)y + jy) / (float)P.height) - 1.0f;
+        float3 dir = normalize(dx * P.U + dy * P.V + P.W), org = P.eye;
+        PayloadBDPTVertex prd;
+        prd.clear(); prd.seed = seed; prd.ray_direction = dir; prd.origin = org;
+        init_EyeSubpath(prd.path, org, dir);
+        std::vector<BDPTVertex> ev;
+        bool ok = true;
+        for (int d = 0; d < depth; d++) {
+            const int before = prd.path.size;
+            trace_subpath(P, prd.origin, prd.ray_direction, &prd, false);
+            if (prd.path.size == before || prd.path.hit_lightSource() || prd.done) { ok = false; break; }
+            ev.push_back(prd.path.currentVertex());
+        }
+        if (!ok) continue;
+        {   // the next segment must hit an emitter on its front side
+            const int before = prd.path.size;
+            trace_subpath(P, prd.origin, prd.ray_direction, &prd, false);
+            if (prd.path.size == before || prd.path.currentVertex().type != HIT_LIGHT_SOURCE) continue;
+        }
+        const BDPTVertex hit = prd.path.currentVertex();
+        if (!(float3weight(hit.flux) > 0.0f)) continue;   // a path that scattered INTO a surface on its way (upstream lets it live with a flux of zero, DESIGN d11): it carries nothing, and no light sub-path can retrace it
+        const float w_hit = 1.0f / hit.RMIS_pointer;
+        const Light& light = S.lights[hit.materialId];
+        lightSample ls;
+        ls.ReverseSample(P, light, hit.uv);
+        const float3 xD = ev[depth - 1].position;
+        ls.direction = normalize(xD - ls.position);
+        ls.dir_pdf = fabsf(dot(ls.direction, light.normal)) / M_PIf_;   // traceMode's pdf of this direction
+        PayloadBDPTVertex pl;
+        pl.clear();
+        init_lightSubPath_from_lightSample(ls, pl.path);
+        std::vector<BDPTVertex> lv;
+        lv.push_back(pl.path.currentVertex());
+        float3 lo = ls.position, ld = ls.direction;
+        for (int k = 1; k <= depth && ok; k++) {
+            const int before = pl.path.size;
+            pl.done = false;
+            trace_subpath(P, lo, ld, &pl, true);
+            if (pl.path.size == before) { ok = false; break; }
+            BDPTVertex& Mid = pl.path.currentVertex();
+            if (length(Mid.position - ev[depth - k].position) > 1e-3f) { ok = false; break; }
+            lv.push_back(Mid);
+            if (k == depth) break;
+            const float3 nd = normalize(ev[depth - k - 1].position - Mid.position);
+            Pbr pbr = S.materials[Mid.materialId];
+            pbr.base_color = Mid.color;
+            BDPTVertex& Next = pl.path.nextVertex();
+            Next.flux = Eval(pbr, Mid.normal, -ld, nd);
+            Next.singlePdf = Pdf(pbr, Mid.normal, -ld, nd) * rr_rate_of(Mid.color);
+            lo = Mid.position; ld = nd;
+        }
+        if (!ok) continue;
+        float ws[4] = {0, 0, 0, 0}, rate[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < depth && k < 4; k++) {
+            const BDPTVertex& e = ev[depth - 1 - k];
+            const BDPTVertex& l = lv[k];
+            ws[k] = k == 0 ? rmis::connection_lightSource(P, e, l) : rmis::general_connection(P, e, l);
+            rate[k] = e.pdf * float3weight(connectRate_SOL(P, e.subspaceId, l.subspaceId, l.flux / l.pdf)) * l.pdf;
+        }
+        rate[4] = hit.pdf;
+        double rs = rate[4];
+        for (int k = 0; k < depth && k < 4; k++) rs += rate[k];
+        float* o = out + 7 * (size_t)found;
+        o[0] = w_hit + ws[0] + ws[1] + ws[2] + ws[3]; o[1] = w_hit; o[2] = ws[0]; o[3] = ws[1]; o[4] = ws[2]; o[5] = ws[3]; o[6] = 1.0f;
+        float* t = truth + 5 * (size_t)found;
+        t[0] = (float)(rate[4] / rs);
+        for (int k = 0; k < 4; k++) t[1 + k] = (float)(rate[k] / rs);
+        found++;
+    }
+    return found;
+}

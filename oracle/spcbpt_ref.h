@@ -460,11 +460,16 @@ inline float light_hit(const Params& P, BDPTVertex& eye, BDPTVertex& light) {  /
     float pdf_B = getPdf(P, eye, light, LB);
     return D_B / ((weight + D_A) / pdf_B * light.singlePdf + D_B);
 }
-inline float light_hit_env(const Params& P, BDPTVertex& eye, BDPTVertex& light) {  // 325-358 (uncalled upstream; see Params::env_miss_strategy)
+// (uncalled upstream; see Params::env_miss_strategy).  As written upstream the flux multiplier of the eye vertex is taken with
+// in_dir = -connect_dir although connect_dir here already points TO the sky (= -light.normal; light_hit, which it was copied from, has
+// connect_dir pointing from the light to the eye vertex): the multiplier of a direction below the surface, i.e. the strategies with
+// a shorter eye sub-path drop out of the weight from eye depth 2 on (orc_debug_env_partition: miss weight 0.03 where first principles
+// say 0.99).  Dead code upstream, so nothing there shows it.  `as_written` = false (what the knob uses) points it at the sky.
+inline float light_hit_env(const Params& P, BDPTVertex& eye, BDPTVertex& light, bool as_written = false) {  // 325-358
     float3 connect_dir = -light.normal;
     float3 flux = light.flux / light.pdf;
     float LL_pdf_A = getLast_pdf(P, eye, connect_dir);
-    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, -connect_dir);
+    float3 flux_multiplier_0 = getFluxMultiplier(P, eye, as_written ? -connect_dir : connect_dir);
     float3 weight_A = tracing_weight_eye(P, light, eye);
     float3 D_A_0 = ((eye.RMIS_pointer_3 * LL_pdf_A * flux_multiplier_0) + weight_A);
     float pdf_A = getPdf_from_light_source(P, light, eye);

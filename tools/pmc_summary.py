@@ -41,7 +41,7 @@ notes = ("FETCH_SIZE / WRITE_SIZE are in KB per launch, collected in separate --
          "range [FETCH_SIZE, 2*FETCH_SIZE] + WRITE_SIZE; Infinity-Cache hits are included in these memory-side counters.")
 out = {"tag": tag, "notes": notes, "kernels": summary}
 # the dominant kernel of the run: the batched instantiation when the run used it, else the single-frame one (non-counting)
-key = next((k for k in ("spc::k_spcbpt<false, true, true>", "spc::k_spcbpt<false, false, true>", "spc::k_spcbpt<false, true>", "spc::k_spcbpt<false, false>", "spc::k_spcbpt<false>")
+key = next((k for k in ("spc::k_spcbpt<false, true, true, false>", "spc::k_spcbpt<false, true, true, true>", "spc::k_spcbpt<false, false, true, false>", "spc::k_spcbpt<false, true, true>", "spc::k_spcbpt<false, false, true>", "spc::k_spcbpt<false, true>", "spc::k_spcbpt<false, false>", "spc::k_spcbpt<false>")
             if k in summary and "FETCH_SIZE" in summary[k]), "")
 frames_per_launch = int(os.environ.get("FRAMES_PER_LAUNCH", "32" if key.startswith("spc::k_spcbpt<false, true") else "1"))
 if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[key]:

@@ -28,6 +28,7 @@ def test_every_declared_symbol_is_exported(hip_lib, pkg):
 
 
 def _make(pkg, scene, batch, lt=(3000, 64, 1)):
+    """(a scene with an environment map gets it installed: the sky is then light n_lights - 1 of every context)"""
     if batch > 1:
         os.environ["SPCBPT_EYE_BATCH"] = str(batch)
     try:
@@ -37,6 +38,9 @@ def _make(pkg, scene, batch, lt=(3000, 64, 1)):
     cam = scene.camera
     r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
     r.resize(W, H)
+    if getattr(scene, "environment", None):
+        e = scene.environment
+        r.set_environment(e["rgba"], e["center"], e["radius"])
     r.set_light_trace(*lt)
     return r
 
@@ -51,13 +55,15 @@ def _single(pkg, scene, nf, lt=(3000, 64, 1)):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,batch,lt,lbatch,xbatch", [(2, 2, (3000, 64, 1), False, False), (3, 1, (3000, 64, 1), False, False), (2, 2, (40, 200, 60), False, False),
-                                                          (3, 3, (3000, 64, 1), True, False),   # lbatch: a batch's light passes as one launch too
-                                                          (3, 3, (3000, 64, 1), True, True),    # xbatch: ... and their shards as ONE exchange
-                                                          (3, 2, (1000, 64, 1), True, True),    # 1000 cores on 3 ranks: 333 / 333 / 334 (uneven scratch sizes)
-                                                          (7, 3, (1000, 64, 1), True, True)])
-def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, lbatch, xbatch):
-    scene = pkg.scenes.cornell_box()
+@pytest.mark.parametrize("world,batch,lt,lbatch,xbatch,scene_name", [(2, 2, (3000, 64, 1), False, False, "cornell"), (3, 1, (3000, 64, 1), False, False, "cornell"), (2, 2, (40, 200, 60), False, False, "cornell"),
+                                                          (3, 3, (3000, 64, 1), True, False, "cornell"),   # lbatch: a batch's light passes as one launch too
+                                                          (3, 3, (3000, 64, 1), True, True, "cornell"),    # xbatch: ... and their shards as ONE exchange
+                                                          (3, 2, (1000, 64, 1), True, True, "cornell"),    # 1000 cores on 3 ranks: 333 / 333 / 334 (uneven scratch sizes)
+                                                          (7, 3, (1000, 64, 1), True, True, "cornell"),
+                                                          (3, 3, (3000, 64, 1), True, True, "courtyard"),  # environment map: direction flags of the light vertices travel through the exchange
+                                                          (2, 1, (3000, 64, 1), False, False, "courtyard")])
+def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, lbatch, xbatch, scene_name):
+    scene = pkg.scenes.cornell_box() if scene_name == "cornell" else pkg.scenes.courtyard()
     NF = 6
     single, want = _single(pkg, scene, NF, lt)
     ranks = []
@@ -117,6 +123,9 @@ def test_local_ranks_reproduce_the_single_gpu_film(gpu, pkg, world, batch, lt, l
     single.launch("light trace", NF); single.build_sampler()  # the frame the last exchange carried: launch frame NF
     s2 = single.sampler_read()
     assert (vc, pc) == (s2[3], s2[4]) and np.array_equal(jump, s2[2]) and np.array_equal(cmfs, s2[1])
+    if scene_name == "courtyard":                             # the scene really has sky vertices (spcbpt.h: pad bits 31 / 30)
+        lv = single.lvc_read()                                # (the films above can only agree if the flags survived the exchange: a sky vertex connects differently)
+        assert ((lv["pad"] & 0x80000000) != 0).sum() > 500 and ((lv["pad"] & 0x40000000) != 0).sum() > 100
     for c in comms:
         c.close()
 

@@ -183,22 +183,28 @@ class Oracle:
         """Test knob: eye sub-paths that leave the scene see the sky, weighted by rmis::light_hit_env (uncalled upstream): completes the estimator."""
         self.l.orc_set_env_miss_strategy(self.h, int(on))
 
-    def env_partition(self, depth, n, frame=1):
+    def env_partition(self, depth, n, frame=1, vertices=False):
         """Test utility (orc_debug_env_partition): RMIS weights of every strategy of n camera paths that leave the scene after `depth`
         surface vertices: (weights [n, 6]: sum, miss, k = 0 .. 3; first-principles weights [n, 5]: miss, k = 0 .. 3)."""
         out = np.zeros((n, 7), np.float32); truth = np.zeros((n, 5), np.float32)
+        ev = np.zeros((n, 4), EYE_VERTEX_DTYPE); lv = np.zeros((n, 4), self.pkg.LIGHT_VERTEX_DTYPE)
         self.l.orc_debug_env_partition.restype = C.c_int
-        m = self.l.orc_debug_env_partition(self.h, int(depth), int(n), C.c_uint(frame), out.ctypes.data_as(C.c_void_p), truth.ctypes.data_as(C.c_void_p))
+        m = self.l.orc_debug_env_partition(self.h, int(depth), int(n), C.c_uint(frame), out.ctypes.data_as(C.c_void_p), truth.ctypes.data_as(C.c_void_p),
+                                          ev.ctypes.data_as(C.c_void_p) if vertices else None, lv.ctypes.data_as(C.c_void_p) if vertices else None)
         if m < 0: raise RuntimeError("env_partition: needs an environment map and 1 <= depth <= 4")
+        if vertices: return out[:m, :6], truth[:m], ev[:m], lv[:m]     # ev / lv [path, k]: the (eye vertex, light vertex) pair of strategy k
         return out[:m, :6], truth[:m]
 
-    def quad_partition(self, depth, n, frame=1):
+    def quad_partition(self, depth, n, frame=1, vertices=False):
         """Test utility (orc_debug_quad_partition): the same for camera paths that END ON A QUAD EMITTER after `depth` surface vertices:
         (weights [n, 6]: sum, emitter hit, k = 0 .. 3; first-principles weights [n, 5])."""
         out = np.zeros((n, 7), np.float32); truth = np.zeros((n, 5), np.float32)
+        ev = np.zeros((n, 4), EYE_VERTEX_DTYPE); lv = np.zeros((n, 4), self.pkg.LIGHT_VERTEX_DTYPE)
         self.l.orc_debug_quad_partition.restype = C.c_int
-        m = self.l.orc_debug_quad_partition(self.h, int(depth), int(n), C.c_uint(frame), out.ctypes.data_as(C.c_void_p), truth.ctypes.data_as(C.c_void_p))
+        m = self.l.orc_debug_quad_partition(self.h, int(depth), int(n), C.c_uint(frame), out.ctypes.data_as(C.c_void_p), truth.ctypes.data_as(C.c_void_p),
+                                          ev.ctypes.data_as(C.c_void_p) if vertices else None, lv.ctypes.data_as(C.c_void_p) if vertices else None)
         if m < 0: raise RuntimeError("quad_partition: 1 <= depth <= 4")
+        if vertices: return out[:m, :6], truth[:m], ev[:m], lv[:m]     # ev / lv [path, k]: the (eye vertex, light vertex) pair of strategy k
         return out[:m, :6], truth[:m]
 
     def set_count_as_executed(self, on):

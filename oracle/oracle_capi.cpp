@@ -429,7 +429,7 @@ int orc_eye_step(orc_ctx* c, const orc_eye_step_in* in, int n, orc_eye_step_out*
 // miss.  out[7 * i]: the weights' sum; [1]: miss; [2 .. 5]: k = 0 .. 3; [6]: sum of the weights RECOMPUTED from first principles
 // (rate of a strategy = eye pdf x connectRate_SOL x light pdf; miss = eye pdf x solid-angle pdf) -- 1 by construction, a check of
 // the check.  Returns the number of paths found.
-extern "C" int orc_debug_env_partition(orc_ctx* c, int depth, int n, unsigned frame, float* out, float* truth) {
+extern "C" int orc_debug_env_partition(orc_ctx* c, int depth, int n, unsigned frame, float* out, float* truth, orc_eye_vertex* ev_out, spcbpt_light_vertex* lv_out) {
     Params P = c->P;
     P.counters = nullptr;
     const Scene& S = *P.scene;
@@ -503,6 +503,7 @@ extern "C" int orc_debug_env_partition(orc_ctx* c, int depth, int n, unsigned fr
             const BDPTVertex& l = lv[k];
             ws[k] = k == 0 ? rmis::connection_direction_lightSource(P, e, l) : rmis::general_connection(P, e, l);
             rate[k] = e.pdf * float3weight(connectRate_SOL(P, e.subspaceId, l.subspaceId, l.flux / l.pdf)) * l.pdf;
+            if (ev_out && lv_out) { export_eye_vertex(e, ev_out[4 * (size_t)found + k]); export_vertex(l, lv_out[4 * (size_t)found + k]); }   // the pair of strategy k, for the device harness
         }
         rate[4] = ev[depth - 1].pdf * next_single_pdf;
         double rs = rate[4];
@@ -521,7 +522,7 @@ extern "C" int orc_debug_env_partition(orc_ctx* c, int depth, int n, unsigned fr
 // emitter hit (rmis::light_hit through __closesthit__eyeSubpath_LightSource), e_D <-> y0 = z (connection_lightSource),
 // e_{D-k} <-> y_k for k >= 1 (general_connection), the light sub-path re-traced from z with its directions forced.  out / truth as above
 // ([1] / [0] = the emitter hit).  Rates in area measure over (x1 .. xD, z).
-extern "C" int orc_debug_quad_partition(orc_ctx* c, int depth, int n, unsigned frame, float* out, float* truth) {
+extern "C" int orc_debug_quad_partition(orc_ctx* c, int depth, int n, unsigned frame, float* out, float* truth, orc_eye_vertex* ev_out, spcbpt_light_vertex* lv_out) {
     Params P = c->P;
     P.counters = nullptr;
     const Scene& S = *P.scene;
@@ -589,6 +590,7 @@ extern "C" int orc_debug_quad_partition(orc_ctx* c, int depth, int n, unsigned f
             const BDPTVertex& l = lv[k];
             ws[k] = k == 0 ? rmis::connection_lightSource(P, e, l) : rmis::general_connection(P, e, l);
             rate[k] = e.pdf * float3weight(connectRate_SOL(P, e.subspaceId, l.subspaceId, l.flux / l.pdf)) * l.pdf;
+            if (ev_out && lv_out) { export_eye_vertex(e, ev_out[4 * (size_t)found + k]); export_vertex(l, lv_out[4 * (size_t)found + k]); }
         }
         rate[4] = hit.pdf;
         double rs = rate[4];

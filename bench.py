@@ -464,6 +464,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms_long = float(t.item())
     ms_sync_each = None
+    ms_sync_each_ahead = None
     if args.sync_each_frames > 0 and ex is None:
         # optixPathTracer.cpp:791-822: launchLVCTrace (light pass + LVC_Process) then launchSubframe, a device sync after each
         # (513, 634) -- one frame in flight, nothing batched, nothing ahead
@@ -486,6 +487,20 @@ def main():
             t = torch.tensor([ms_sync_each], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ms_sync_each = float(t.item())
+        if comm is None:
+            # the same loop with the viewer's opt-in (spcbpt_viewer_set_light_ahead): the next frame's light pass is launched beside
+            # this frame's eye kernel, before the sync -- still one eye launch and one device sync per frame
+            r.set_light_ahead(True)
+            r.launch("light trace", 5200)
+            for f in range(args.sync_each_frames + 2):
+                if f == 2:
+                    t1 = time.perf_counter()
+                r.build_sampler()
+                r.launch("SPCBPT_eye", 5200 + f, rows)
+                r.launch("light trace", 5201 + f)
+                r.sync()
+            ms_sync_each_ahead = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
+            r.set_light_ahead(False)
 
     eye_paths = args.width * args.height
     total_paths = (eye_paths + M) * args.steps
@@ -522,6 +537,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "ms_per_step_long": None if ms_long is None else round(ms_long, 3),
             "ms_per_frame_sync_each": None if ms_sync_each is None else round(ms_sync_each, 3),
+            "ms_per_frame_sync_each_light_ahead": None if ms_sync_each_ahead is None else round(ms_sync_each_ahead, 3),
             "notes": {"ms_per_step_long": f"the same loop over {args.long_steps} more steps (steady state; value / ms_per_step are the contract's {args.steps} steps)",
                       "ms_per_frame_sync_each": "the reference's loop form (optixPathTracer.cpp:791-822): one light pass, one sampler build, one eye launch and a device sync per frame"},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

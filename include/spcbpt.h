@@ -556,6 +556,11 @@ int spcbpt_viewer_window_size(spcbpt_viewer* v, int width, int height);
 int spcbpt_viewer_iconify(spcbpt_viewer* v, int iconified);
 int spcbpt_viewer_key(spcbpt_viewer* v, int key, int action);
 int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps);
+/* Opt-in (the reference has no such mode): with "SPCBPT_eye" the loop launches the NEXT frame's light pass right after this
+ * frame's eye launch, before the sync, so that it runs beside the eye kernel instead of in front of the next one (light sub-paths
+ * do not depend on the camera).  Same launch frames, same caches, same images -- one frame takes the eye launch's time instead of
+ * light pass + build + eye launch.  Sets spcbpt_set_light_ahead on the context. */
+int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on);
 int spcbpt_viewer_frame(spcbpt_viewer* v);
 int spcbpt_viewer_get_state(spcbpt_viewer* v, spcbpt_viewer_state* state);
 const char* spcbpt_viewer_alg_name(int alg_id);

@@ -348,6 +348,9 @@ class Viewer:
     def set_fps(self, fps):
         self._chk(self.lib.spcbpt_viewer_set_fps(self.h, C.c_float(fps)), "set_fps")
 
+    def set_light_ahead(self, on):
+        self._chk(self.lib.spcbpt_viewer_set_light_ahead(self.h, int(on)), "viewer_set_light_ahead")
+
     def frame(self):
         self._chk(self.lib.spcbpt_viewer_frame(self.h), "viewer_frame")
 
@@ -531,6 +534,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_viewer_iconify": [vp, i32],
         "spcbpt_viewer_key": [vp, i32, i32],
         "spcbpt_viewer_set_fps": [vp, C.c_float],
+        "spcbpt_viewer_set_light_ahead": [vp, i32],
         "spcbpt_viewer_frame": [vp],
         "spcbpt_viewer_get_state": [vp, C.POINTER(ViewerState)],
         "spcbpt_image_load": [C.c_char_p, C.POINTER(i32), C.POINTER(i32), vp, C.c_size_t],
@@ -576,7 +580,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_get_gamma", "spcbpt_gltf_load", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
     "spcbpt_scene_file_warnings", "spcbpt_scene_file_environment", "spcbpt_scene_file_free",
     "spcbpt_viewer_create", "spcbpt_viewer_destroy", "spcbpt_viewer_mouse_button", "spcbpt_viewer_cursor_pos", "spcbpt_viewer_scroll",
-    "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_frame",
+    "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_set_light_ahead", "spcbpt_viewer_frame",
     "spcbpt_viewer_get_state", "spcbpt_viewer_alg_name",
     "spcbpt_image_load", "spcbpt_checkpoint_write", "spcbpt_checkpoint_read", "spcbpt_gamma_to_cmf", "spcbpt_checkpoint_save", "spcbpt_checkpoint_load",
 ]

@@ -122,6 +122,7 @@ struct spcbpt_viewer {
     uint32_t subframe_index = 0, lt_launch_frame = 0;
     double cursor_x = 0, cursor_y = 0;  // what glfwGetCursorPos returns inside mouseButtonCallback
     bool fixed_fps = false;
+    bool light_ahead = false, light_pending = false;   // spcbpt_viewer_set_light_ahead: the next frame's light pass is already in flight
     long long frames = 0;
 };
 
@@ -247,6 +248,14 @@ int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps) {
     return SPCBPT_OK;
 }
 
+int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on) {
+    if (!v) return SPCBPT_ERR_INVALID_ARG;
+    if (v->ctx) { const int rc = spcbpt_set_light_ahead(v->ctx, on != 0); if (rc) return rc; }   // (drops a pass launched ahead)
+    v->light_ahead = on != 0;
+    v->light_pending = false;
+    return SPCBPT_OK;
+}
+
 // One pass of the render loop (791-822): updateState -> [SPCBPT_eye: launchLVCTrace] -> launchSubframe -> ++subframe_index.
 int spcbpt_viewer_frame(spcbpt_viewer* v) {
     if (!v) return SPCBPT_ERR_INVALID_ARG;
@@ -269,13 +278,19 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
     }
     if (v->ctx) {
         if (v->render_alg_id == 1) {  // launchLVCTrace (515-522)
-            rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);
+            if (!v->light_pending) rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);   // (else: launched ahead by the previous frame)
             if (rc) return rc;
+            v->light_pending = false;
             rc = spcbpt_build_sampler(v->ctx);
             if (rc) return rc;
         }
         rc = spcbpt_launch(v->ctx, kAlgs[v->render_alg_id], v->subframe_index, 0, v->height, 1);  // launchSubframe (609-635)
         if (rc) return rc;
+        if (v->light_ahead && v->render_alg_id == 1) {   // the next frame's light pass, beside this frame's eye kernel
+            rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);
+            if (rc) return rc;
+            v->light_pending = true;
+        }
         rc = spcbpt_sync(v->ctx);  // CUDA_SYNC_CHECK: the interactive loop shows every subframe
         if (rc) return rc;
     }

@@ -124,3 +124,33 @@ def test_viewer_loop_renders_what_the_plain_loop_renders(gpu, pkg):
     v.key("SPACE"); v.frame()
     b.clear_accum(); b.render_frame("pt", 0); b.sync()
     assert v.state()["alg"] == "pt" and np.array_equal(a.read_accum(), b.read_accum())
+
+
+@pytest.mark.gpu
+def test_viewer_light_ahead_renders_the_same_frames(gpu, pkg):
+    """spcbpt_viewer_set_light_ahead: the next frame's light pass is launched beside this frame's eye kernel -- same launch frames, same
+    caches, the same images bit for bit, also across a camera drag and an algorithm switch back and forth."""
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    W = H = 96
+    imgs = []
+    for ahead in (False, True):
+        r = pkg.Renderer(scene, 0)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+        r.resize(W, H)
+        r.set_light_trace(3000, 64, 1)
+        r.set_subspace()
+        v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], W, H)
+        v.set_light_ahead(ahead)
+        shots = []
+        for _ in range(3): v.frame()
+        shots.append(r.read_accum().copy())
+        v.mouse_button("left", 1, 40, 40); v.cursor_pos(60, 50); v.mouse_button("left", 0, 60, 50)
+        for _ in range(2): v.frame()
+        shots.append(r.read_accum().copy())
+        v.key("SPACE"); v.frame()                          # "pt": no light pass; one may still be pending from the frame before
+        shots.append(r.read_accum().copy())
+        assert v.state()["alg"] == "pt"
+        imgs.append(shots)
+    for a, b in zip(*imgs):
+        assert np.array_equal(a, b)

@@ -96,7 +96,7 @@ def test_images_with_an_environment_map_match_the_oracle(yard):
 def test_connections_to_sky_vertices_value_and_weight(yard, pkg, ob):
     """connectVertex_SPCBPT on (eye vertex, light vertex) pairs whose light vertex is a sky direction (direction_connect_ZGCBPT +
     connection_direction_lightSource) or was lit straight by the sky (is_LL_DIRECTION in getLast_pdf), through the per-function
-    harness: value within 5e-5 of the record's scale for >= 99.8 %, exact zeros agree."""
+    harness: value within 3e-6 of the record's scale for >= 99.9 % (measured: bit-exact for 90 %, max 6.4e-7), exact zeros agree."""
     from tests.test_gpu_units import OP, check
     r, o = yard["r"], yard["o"]
     o.launch("light trace", 11)
@@ -138,8 +138,8 @@ def test_connections_to_sky_vertices_value_and_weight(yard, pkg, ob):
     for sel, name in ((((lv["pad"] & DIR) != 0), "direction_connect_ZGCBPT"), (((lv["pad"] & LASTDIR) != 0), "general_connection after the sky")):
         live = sel & (np.abs(rgb_o).max(1) > 0)
         assert live.sum() > 300, (name, int(live.sum()))
-        check(name + " RMIS weight", out[live, 3], w_o[live], 5e-5, 0.998)
-        check(name + " value", out[live, :3], rgb_o[live], 5e-5, 0.998)
+        check(name + " RMIS weight", out[live, 3], w_o[live], 3e-6, 0.999, hard=1e-4)      # measured max 6.4e-7
+        check(name + " value", out[live, :3], rgb_o[live], 3e-6, 0.999, hard=1e-4)
     assert ((out[:, :3] == 0).all(1) == (rgb_o == 0).all(1)).mean() >= 0.999
 
 

@@ -34,7 +34,8 @@ def _check(r, o, partition, depths, what):
         for k in range(min(depth, 4)):
             got = _weights(r, ev[:, k], lv[:, k])
             d = np.abs(got - truth[:, 1 + k])
-            assert np.percentile(d, 99.5) < 2e-4 and d.max() < 5e-3, (what, depth, k, np.percentile(d, [50, 99.5, 100]))   # measured: 99.5 % within 3e-5
+            print(what, depth, k, np.percentile(d, [50, 99.5, 100]))
+            assert np.percentile(d, 99.5) < 2e-4 and d.max() < 5e-3, (what, depth, k, np.percentile(d, [50, 99.5, 100]))
             total += got
         assert np.percentile(np.abs(total - 1), 99.5) < 5e-4, (what, depth)
 

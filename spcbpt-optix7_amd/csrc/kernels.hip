@@ -94,7 +94,6 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
     WalkState w;
     EyeVertex cur;
     f3 result = mk3(0.0f);
-    int depth = 0;
     w.done = false; w.seed = 0; w.origin = w.dir = w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
     cur.c.pos = cur.c.n = cur.c.color = cur.c.lastPos = mk3(0.0f); cur.c.lnp = 0.0f; cur.c.mat = 0; cur.c.lld = false;
     cur.flux = cur.R3 = mk3(0.0f); cur.pdf = cur.singlePdf = 1.0f; cur.sub = cur.lastZone = cur.depth = 0; cur.lsub = 0;
@@ -146,7 +145,6 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     w.next_flux = mk3(0.0f);
                     w.next_single_pdf = 1.0f;
                     result = mk3(0.0f);
-                    depth = 0;
                     cn.add(C_PIX); cn.add(C_EYE);
                 }
             }
@@ -169,10 +167,17 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         const uint32_t n_rays = pool_ray_list(w_ray, w_job);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // the vertex's five small integers cross the pass in two registers (the pass needs every register it can get: the kernel spills)
+        const uint32_t ids_a = (uint32_t)cur.sub | ((uint32_t)cur.lastZone << 10) | ((uint32_t)cur.depth << 20);
+        const uint32_t ids_b = (uint32_t)cur.c.mat | ((uint32_t)cur.lsub << 16);
         HitRec h;
-        trace_pool(S, st, alive && has_ray, w.origin, w.dir, h, w_org, w_ray, w_vis, w_next, w_job, n_rays, cn);
+        // (the next segment starts at the path's last vertex -- or at the camera for a path that was started in this iteration, whose
+        // `cur` still holds the parked path's vertex: w.origin would be a copy kept alive across the pass for nothing)
+        trace_pool(S, st, alive && has_ray, fresh ? ld3(p.eye) : cur.c.pos, w.dir, h, w_org, w_ray, w_vis, w_next, w_job, n_rays, cn);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        cur.sub = (int)(ids_a & 1023u); cur.lastZone = (int)((ids_a >> 10) & 1023u); cur.depth = (int)(ids_a >> 20);
+        cur.c.mat = (int)(ids_b & 0xffffu); cur.lsub = (int)(ids_b >> 16);
         SPC_PHASE(C_T_POOL);
         // ---- connect the unoccluded pairs of the previous vertices.  Only ~1/4 of the 192 (lane, connection) slots of a wave
         // hold an unoccluded pair, so the pairs are compacted into a job list and every lane -- whatever the state of its
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         }
         if (fresh) {  // init_EyeSubpath (raygen.cu:216-231)
             fresh = false;
-            cur.c.pos = w.origin; cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = w.origin; cur.c.lnp = 0.0f; cur.c.mat = 0; cur.c.lld = false;
+            cur.c.pos = ld3(p.eye); cur.c.n = w.dir; cur.c.color = mk3(0.0f); cur.c.lastPos = cur.c.pos; cur.c.lnp = 0.0f; cur.c.mat = 0; cur.c.lld = false;
             cur.flux = mk3(1.0f); cur.R3 = mk3(0.0f); cur.pdf = 1.0f; cur.singlePdf = 1.0f; cur.sub = 0; cur.lastZone = 0; cur.depth = 0; cur.lsub = 0;
         }
         has_vertex = false;
@@ -276,7 +281,6 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                 const Geom g = local_geometry(S, h);
                 const bool last_is_origin = cur.depth == 0;
                 const f3 ray_dir = w.dir;
-                depth += 1;
                 if (g.emitter) {
                     result += eye_emitter_hit<COUNT, CACHE>(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
                     finished = true;
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     if (COUNT) cn.add(C_T_SAMPLE, (unsigned)((clock64() - t_s0) >> 4));
                     w_org[lane] = make_float4(cur.c.pos.x, cur.c.pos.y, cur.c.pos.z, cur.c.lnp);
                     // the loop-top test of raygen.cu:361: a path that ends here still connects this vertex (next iteration)
-                    has_ray = !(w.done || depth > 50);
+                    has_ray = !(w.done || cur.depth > 50);   // (cur.depth = the number of segments traced: raygen.cu:361 counts them in payload.depth)
                 }
             }
         }

@@ -1,6 +1,8 @@
 """Helpers shared by the parity tests, smoke() and bench.py (test infrastructure)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 FLT_MAX = np.float32(3.4028234663852886e38)
@@ -61,6 +63,11 @@ def image_parity(a: np.ndarray, b: np.ndarray, rel: float = 2e-3, abs_: float = 
     l2 = np.sqrt((d ** 2).sum(axis=-1))
     out = ~close
     tot = max(float(np.abs(b).sum()), 1e-30)
+    if os.environ.get("SPCBPT_PARITY_REPORT"):   # developer: what the image tests actually measure (run pytest with -s)
+        import inspect
+        fr = inspect.stack()[1]
+        print(f"image_parity {os.path.basename(fr.filename)}:{fr.lineno} {fr.function}: frac_close {close.mean():.5f} mean_rel {abs(a.mean() - b.mean()) / max(b.mean(), 1e-12):.2e} "
+              f"p99_l2 {np.percentile(l2, 99):.2e} pixels {close.size}")
     return dict(frac_close=float(close.mean()), mean_a=float(a.mean()), mean_b=float(b.mean()),
                 mean_rel=float(abs(a.mean() - b.mean()) / max(b.mean(), 1e-12)),
                 rmse=float(np.sqrt((d ** 2).mean())), max_l2=float(l2.max()), p99_l2=float(np.percentile(l2, 99)),

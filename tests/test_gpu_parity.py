@@ -1,11 +1,13 @@
 """Parity of the HIP path (through the C ABI) against the oracle on the same seeded inputs.
 
-Tolerances (all floating point is FP32; the oracle and the kernels differ by transcendental ulps, FMA contraction and
-BVH tie-breaking, so equality is statistical at the path level and tight at the function level):
+Tolerances (all floating point is FP32; since round 3 the device code is compiled without implicit FMA fusion, like the oracle, so
+the two differ by transcendental ulps, the traversal loop's v_rcp_f32 / explicit FMAs and BVH tie-breaking only; equality is still
+statistical at the path level -- one Russian-roulette decision within rounding of its threshold gives a pixel another sample -- and
+tight at the function level):
   * traversal: same triangle, |dt| <= 1e-5 * max(1, t) for >= 99.9 % of rays (ties at shared edges excepted)
   * light-vertex cache: same (path_id, depth) sequence; values within 1e-3 relative for >= 99 % of vertices
   * sampler tables: integers exact; CMFs within 3e-5 absolute (device scan accumulates in double, the reference in float)
-  * images, same seeds: >= 99 % of pixels within 2e-3 relative + 1e-4 absolute per channel when the oracle runs with the
+  * images, same seeds: >= 99.7 % of pixels (measured 99.89 ... 100 %; round 2: 99 %) within 2e-3 relative + 1e-4 absolute per channel when the oracle runs with the
     product's CMF accumulation precision; image mean within 0.5 %; with the reference's float CMFs the per-pixel L2
     difference must stay below 25 % of the Monte-Carlo RMSE at that sample count.
 """
@@ -157,7 +159,7 @@ def test_pt_image_matches_oracle(gpu, pkg, ob, scene_name):
     for f in range(4):
         r.launch("pt", f); o.launch("pt", f)
     s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
-    assert s["frac_close"] >= 0.99 and s["mean_rel"] < 5e-3 and tails_explained(s), s
+    assert s["frac_close"] >= 0.998 and s["mean_rel"] < 5e-3 and tails_explained(s), s
     fa, fb = r.read_frame(), o.read_frame()
     assert (np.abs(fa.astype(int) - fb.astype(int)) <= 1).mean() > 0.99   # tone-mapped sRGB bytes
 
@@ -173,7 +175,7 @@ def test_spcbpt_image_matches_oracle(gpu, pkg, ob, scene_name):
         r.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
     a = r.read_accum()[..., :3]
     s = image_parity(a, o.read_accum()[..., :3])
-    assert s["frac_close"] >= 0.99 and s["mean_rel"] < 5e-3 and tails_explained(s), s
+    assert s["frac_close"] >= 0.997 and s["mean_rel"] < 5e-3 and tails_explained(s), s
     # against the reference-exact float CMFs: differences are far below the Monte-Carlo noise
     o.set_cmf_double(False); o.clear_accum()
     for f in range(4):
@@ -201,7 +203,7 @@ def test_spcbpt_with_multi_leaf_trees_and_textures(gpu, pkg, ob):
     for f in range(2):
         r.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
     s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
-    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2 and tails_explained(s), s
+    assert s["frac_close"] >= 0.997 and s["mean_rel"] < 1e-2 and tails_explained(s), s
     cg, co = r.counters(), o.counters()
     for k in ("closest_rays", "shadow_rays", "surface_vertices", "connections", "textured_hits", "lvc_stores", "cmf_probes",
               "tree_nodes", "gamma_q_reads", "pixel_samples", "eye_paths", "light_paths"):
@@ -441,7 +443,7 @@ def test_cached_vertex_labels_are_the_labels_the_reference_derives(gpu, pkg, ob)
     for f in range(2):
         r.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
     s = image_parity(r.read_accum()[..., :3], o.read_accum()[..., :3])
-    assert s["frac_close"] >= 0.985 and s["mean_rel"] < 1e-2 and tails_explained(s), s
+    assert s["frac_close"] >= 0.997 and s["mean_rel"] < 1e-2 and tails_explained(s), s
     with pytest.raises(pkg.SpcbptError, match="direction"):
         r.launch_eye_batch([0])
 

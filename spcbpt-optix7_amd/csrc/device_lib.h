@@ -95,6 +95,16 @@ SPC_DEV uint32_t lane_id_fresh() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+// The HBM part of the traversal stack (entries past the LDS ones): rare, and kept OUT of line so that its address arithmetic, its
+// bounds logic and the overflow report do not sit in the traversal loop three times over (one copy per push site).
+__device__ __attribute__((noinline)) static void stack_push_slow(uint32_t* spill, int spill_entries, int idx, uint32_t v, uint32_t* diag) {
+    if (spill && idx < spill_entries) spill[idx] = v;
+    else if (diag) atomicAdd(diag, 1u);   // the subtree is lost: never silently (spcbpt_sync and the read-backs fail)
+}
+__device__ __attribute__((noinline)) static uint32_t stack_pop_slow(const uint32_t* spill, int spill_entries, int idx) {
+    if (spill && idx < spill_entries) return spill[idx];
+    return NODE_EMPTY;  // the entry push() had to drop (and counted in diag[0]): a leaf of zero triangles, nothing is read
+}
 template <int BLOCK, int STACK_LDS>
 struct TravStack {
     lds_u32* wave_lds;  // column 0 of this wave inside the BLOCK * STACK_LDS dword array (wave-uniform)
@@ -112,8 +122,7 @@ struct TravStack {
     SPC_DEV lds_u32* column() const { return wave_lds + lane_id_fresh(); }
     SPC_DEV void push(uint32_t v) {
         if (sp < STACK_LDS) column()[sp * BLOCK] = v;
-        else if (spill && sp - STACK_LDS < spill_entries) spill[sp - STACK_LDS] = v;
-        else if (diag) atomicAdd(diag, 1u);   // the subtree is lost: never silently (spcbpt_sync and the read-backs fail)
+        else stack_push_slow(spill, spill_entries, sp - STACK_LDS, v, diag);
         sp++;
     }
     // pushes the (up to three) farther children of a node visit, farthest first; c1 >= c2 >= c3 (hits are sorted to the front)
@@ -135,8 +144,7 @@ struct TravStack {
     SPC_DEV uint32_t pop() {
         sp--;
         if (sp < STACK_LDS) return column()[sp * BLOCK];
-        if (spill && sp - STACK_LDS < spill_entries) return spill[sp - STACK_LDS];
-        return NODE_EMPTY;  // the entry push() had to drop (and counted in diag[0]): a leaf of zero triangles, nothing is read
+        return stack_pop_slow(spill, spill_entries, sp - STACK_LDS);
     }
 };
 

@@ -154,7 +154,7 @@ def frames_per_launch(steps: int, max_batch: int = 32) -> int:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node (default: WORLD_SIZE when launched by torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="bedroom")
@@ -197,6 +197,16 @@ def main():
                          "dist.FrameExchanger (per-frame host syncs; kept for comparison)")
     args = ap.parse_args()
 
+    gpus_given = args.gpus is not None
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if gpus_given and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a launcher (or an outer harness that exported WORLD_SIZE) disagrees with the request: running on WORLD_SIZE GPUs and
+        # labelling the line --gpus would be a wrong number, and so would the reverse
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} in the environment: launch with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}` or unset WORLD_SIZE")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started the plain way: the ranks are fresh children (one per GPU); this process never touches the GPU
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -210,8 +220,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        args.gpus = world
+    assert world == args.gpus
 
     import torch
     pkg = entry.load_package()

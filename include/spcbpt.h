@@ -50,7 +50,13 @@ typedef enum spcbpt_status {
 
 /* Disney-principled material; field set of MaterialData::Pbr
  * (cuda/MaterialData.h:82-100).  albedo_tex is 0 for "none", else texture
- * index + 1 (OptiXPathTracer/scene_shift.cpp:76-79 uses the same 1-based id). */
+ * index + 1 (OptiXPathTracer/scene_shift.cpp:76-79 uses the same 1-based id).
+ * brdf is MaterialData::Pbr::brdf (MaterialData.h:99; `brdf <int>` of a .scene
+ * material block, sceneLoader.cpp:107 -> scene_shift.cpp:75): nonzero makes
+ * the bidirectional programs divide the BSDF value by |N.L| at the five
+ * un-guarded ternaries hit_program.cu:286, 384, raygen.cu:271, 278 and
+ * rmis.h:105 (the `#ifdef BRDF` branches of Eval/Pdf are dead).  "pt"
+ * (hit_program.cu:439-552) has no such division. */
 typedef struct spcbpt_material {
     float base_color[3];
     float metallic;
@@ -63,6 +69,7 @@ typedef struct spcbpt_material {
     float clearcoat;
     float clearcoat_gloss;
     int32_t albedo_tex;
+    int32_t brdf;
 } spcbpt_material;
 
 /* 8-bit RGBA image, row 0 first, sampled bilinear + wrap, then pow(c, 2.2)
@@ -344,6 +351,11 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
 int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[17]);
 /* Hash of the sources this library was built from (csrc/source_hash.py); the Python mirror refuses a stale library. */
 const char* spcbpt_build_source_hash(void);
+/* sizeof of the structs of this header as the library was COMPILED, in declaration order: material, texture, quad_light,
+ * scene_desc, tree_node, light_trace_params, light_vertex, subspace, counters, unit_eye_vertex, pretrace_path,
+ * pretrace_node, viewer_state.  A binding in another language (ctypes / cgo / JNI) checks its mirrors against these instead of
+ * against literals (tests/test_abi.py).  Returns the number of structs (13) and writes min(capacity, 13) sizes. */
+int spcbpt_abi_struct_sizes(int32_t* sizes, int capacity);
 /* Developer probe of the HBM part of the traversal stack.  The per-lane stack holds SPC_STACK_LDS (16) entries in LDS; deeper
  * entries go to a per-thread spill area of 3 * bvh_depth - 16 words, which cannot overflow.  _arm fills every area allocated
  * so far with a word no stack entry can hold, _count returns how many words kernels have overwritten since (tests prove the

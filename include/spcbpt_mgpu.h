@@ -41,7 +41,9 @@ int spcbpt_comm_unique_id(char id[SPCBPT_UNIQUE_ID_BYTES]);
  * the others).  The context must have its light pass configured (spcbpt_set_light_trace) -- the default shard capacity is the
  * largest scratch capacity core_count x core_padding of any rank (agreed with an all-reduce: the ranks' core ranges differ when
  * num_core is not a multiple of world); spcbpt_comm_calibrate tightens it and should be called by every job: the context's caches
- * are sized from a measured pass (spcbpt_lvc_set_capacity), and an exchange whose shard capacity exceeds them is refused. */
+ * are sized from a measured pass (spcbpt_lvc_set_capacity) PER RANK, so an uncalibrated shard capacity may exceed a rank's cache.
+ * Such a rank stages its shard through the communicator's send buffer (one device copy per exchange that calibrate saves); it is
+ * never refused on one rank only -- every condition that fails an exchange is derived from the gathered counts and fails on all. */
 int spcbpt_comm_create(spcbpt_ctx* ctx, int rank, int world, const char id[SPCBPT_UNIQUE_ID_BYTES], spcbpt_comm** out);
 
 /* `world` ranks on ONE device, in one process: out[r] is the communicator of ctxs[r].  Same call sequence as the RCCL form; the

@@ -321,6 +321,7 @@ def material_struct(d):
     m.specular_tint = d.get("specular_tint", 0.0); m.subsurface = d.get("subsurface", 0.0); m.sheen = d.get("sheen", 0.0)
     m.sheen_tint = d.get("sheen_tint", 0.5); m.clearcoat = d.get("clearcoat", 0.0); m.clearcoat_gloss = d.get("clearcoat_gloss", 1.0)
     m.albedo_tex = 0
+    m.brdf = int(d.get("brdf", 0))
     return m
 
 

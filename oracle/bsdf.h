@@ -3,7 +3,9 @@
 //   Onb 81-112, cosine_sample_hemisphere 114-124, SchlickFresnel 686-691,
 //   GTR1 693-699, GTR2 701-706, smithG_GGX 708-713, Eval 735-799,
 //   Sample 826-866, Pdf 868-899.  The `#ifdef BRDF` branches are dead in the
-//   reference (macro never defined) and are not restated.
+//   reference (macro never defined) and are not restated; the LIVE uses of
+//   Pbr::brdf are the five `/ (mat.brdf ? abs(dot(n, L)) : 1.0f)` ternaries at the
+//   call sites of Eval (spcbpt_ref.h, oracle_capi.cpp).
 // Known answer (recorded from the reference's own code):
 //   rough .5, metal 0, base (.8,.5,.3), N=+z, V=norm(.3,.2,.9), seed tea<4>(1,2)
 //   -> L=(0.9040936,-0.304971,0.2993451) f=(0.2700801,0.1705985,0.1042775) pdf=0.06876558
@@ -27,6 +29,7 @@ struct Pbr {
     float clearcoat = 0.0f;
     float clearcoatGloss = 1.0f;
     int albedo_tex = 0;  // 0 none, else texture index + 1
+    bool brdf = false;   // MaterialData.h:99; read by the five un-guarded ternaries (hit_program.cu:286, 384; raygen.cu:271, 278; rmis.h:105)
 };
 
 struct Onb {  // cuProg.h:81-112

@@ -271,7 +271,7 @@ static Pbr pbr_of(const spcbpt_material* m) {
     Pbr p;
     p.base_color = load3(m->base_color); p.metallic = m->metallic; p.roughness = m->roughness; p.specular = m->specular;
     p.specularTint = m->specular_tint; p.subsurface = m->subsurface; p.sheen = m->sheen; p.sheenTint = m->sheen_tint;
-    p.clearcoat = m->clearcoat; p.clearcoatGloss = m->clearcoat_gloss; p.albedo_tex = m->albedo_tex;
+    p.clearcoat = m->clearcoat; p.clearcoatGloss = m->clearcoat_gloss; p.albedo_tex = m->albedo_tex; p.brdf = m->brdf != 0;
     return p;
 }
 // n records: N(3) V(3) L(3) -> f(3), pdf(1)
@@ -492,7 +492,7 @@ extern "C" int orc_debug_env_partition(orc_ctx* c, int depth, int n, unsigned fr
             Pbr pbr = S.materials[Mid.materialId];
             pbr.base_color = Mid.color;
             BDPTVertex& Next = pl.path.nextVertex();
-            Next.flux = Eval(pbr, Mid.normal, -ld, nd);
+            Next.flux = Eval(pbr, Mid.normal, -ld, nd) / (pbr.brdf ? fabsf(dot(Mid.normal, nd)) : 1.0f);   // hit_program.cu:384
             Next.singlePdf = Pdf(pbr, Mid.normal, -ld, nd) * rr_rate_of(Mid.color);
             lo = Mid.position; ld = nd;
         }
@@ -579,7 +579,7 @@ extern "C" int orc_debug_quad_partition(orc_ctx* c, int depth, int n, unsigned f
             Pbr pbr = S.materials[Mid.materialId];
             pbr.base_color = Mid.color;
             BDPTVertex& Next = pl.path.nextVertex();
-            Next.flux = Eval(pbr, Mid.normal, -ld, nd);
+            Next.flux = Eval(pbr, Mid.normal, -ld, nd) / (pbr.brdf ? fabsf(dot(Mid.normal, nd)) : 1.0f);   // hit_program.cu:384
             Next.singlePdf = Pdf(pbr, Mid.normal, -ld, nd) * rr_rate_of(Mid.color);
             lo = Mid.position; ld = nd;
         }

@@ -220,6 +220,7 @@ struct Scene {
             p.specularTint = m.specular_tint; p.subsurface = m.subsurface; p.sheen = m.sheen;
             p.sheenTint = m.sheen_tint; p.clearcoat = m.clearcoat; p.clearcoatGloss = m.clearcoat_gloss;
             p.albedo_tex = m.albedo_tex;
+            p.brdf = m.brdf != 0;   // scene_shift.cpp:75 (int -> bool)
             materials.push_back(p);
             mat_light_id.push_back(-1);
         }

@@ -318,7 +318,7 @@ inline void tracing_update_light(const Params& P, BDPTVertex& Mid, BDPTVertex& L
 }
 inline float3 getFluxMultiplier(const Params& P, const BDPTVertex& v, float3 in_dir, float3 out_dir) {  // 102-112
     Pbr mat = getMat(P, v);
-    float3 flux_ratio = Eval(mat, v.normal, in_dir, out_dir);
+    float3 flux_ratio = Eval(mat, v.normal, in_dir, out_dir) / (mat.brdf ? fabsf(dot(v.normal, out_dir)) : 1.0f);   // 105
     float pdf_ratio = Pdf(mat, v.normal, in_dir, out_dir);
     float rr = getRR(v);
     float cos_theta = fabsf(dot(v.normal, out_dir));
@@ -524,7 +524,7 @@ inline void closesthit_subpath(const Params& P, PayloadBDPTVertex* prd, const Hi
     if (light_side && Last.is_DIRECTION()) pdf_G = fabsf(dot(Mid.normal, ray_direction) * dot(Last.normal, ray_direction));   // hit_program.cu:372-375 (parallel rays: no 1 / t^2)
     if (Last.isOrigin) Mid.flux = Last.flux * pdf_G;
     else Mid.flux = Mid.flux * Last.flux * pdf_G;
-    Next.flux = Eval(currentPbr, N, -ray_direction, prd->ray_direction);
+    Next.flux = Eval(currentPbr, N, -ray_direction, prd->ray_direction) / (currentPbr.brdf ? fabsf(dot(Mid.normal, prd->ray_direction)) : 1.0f);   // hit_program.cu:286 / 384
     if (P.skip_null_connections && !light_side && Next.flux.x == 0.0f && Next.flux.y == 0.0f && Next.flux.z == 0.0f) prd->done = true;  // d11
     Next.singlePdf = prd->pdf;
 
@@ -936,11 +936,11 @@ inline float3 connectVertex_SPCBPT(const Params& P, const BDPTVertex& a, const B
     float3 fa, fb;
     Pbr mat_a = S.materials[a.materialId];
     mat_a.base_color = a.color;
-    fa = Eval(mat_a, a.normal, -connectDir, LA_DIR);
+    fa = Eval(mat_a, a.normal, -connectDir, LA_DIR) / (mat_a.brdf ? fabsf(dot(a.normal, connectDir)) : 1.0f);   // raygen.cu:271
     if (!b.isOrigin) {
         Pbr mat_b = S.materials[b.materialId];
         mat_b.base_color = b.color;
-        fb = Eval(mat_b, b.normal, connectDir, LB_DIR);
+        fb = Eval(mat_b, b.normal, connectDir, LB_DIR) / (mat_b.brdf ? fabsf(dot(b.normal, connectDir)) : 1.0f);   // raygen.cu:278
     } else {
         if (dot(b.normal, -connectDir) > 0.0f) fb = make_float3(0.0f);
         else fb = make_float3(1.0f);

@@ -27,7 +27,7 @@ class Material(C.Structure):
     _fields_ = [("base_color", C.c_float * 3), ("metallic", C.c_float), ("roughness", C.c_float),
                 ("specular", C.c_float), ("specular_tint", C.c_float), ("subsurface", C.c_float),
                 ("sheen", C.c_float), ("sheen_tint", C.c_float), ("clearcoat", C.c_float),
-                ("clearcoat_gloss", C.c_float), ("albedo_tex", C.c_int32)]
+                ("clearcoat_gloss", C.c_float), ("albedo_tex", C.c_int32), ("brdf", C.c_int32)]
 
 
 class Texture(C.Structure):
@@ -155,6 +155,7 @@ class Scene:
             mm.clearcoat = d.get("clearcoat", 0.0)
             mm.clearcoat_gloss = d.get("clearcoat_gloss", 1.0)
             mm.albedo_tex = d.get("albedo_tex", 0)
+            mm.brdf = int(d.get("brdf", 0))   # Pbr::brdf (MaterialData.h:99): `brdf <int>` of a .scene material block
             assert 0 <= mm.albedo_tex <= len(self.textures)
         texs = (Texture * max(1, len(self.textures)))()
         tex_keep = []
@@ -227,7 +228,7 @@ def _scene_from_handle(lib, h, name):
         mats = []
         for k in range(d.n_materials):
             m = d.materials[k]
-            mats.append(dict(color=tuple(m.base_color), metallic=m.metallic, roughness=m.roughness, albedo_tex=m.albedo_tex))
+            mats.append(dict(color=tuple(m.base_color), metallic=m.metallic, roughness=m.roughness, albedo_tex=m.albedo_tex, brdf=m.brdf))
         lights = []
         for k in range(d.n_lights):
             l = d.lights[k]
@@ -573,7 +574,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit",
-    "spcbpt_build_source_hash", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",

@@ -246,6 +246,8 @@ int Context::set_environment(const float* rgba, int w, int h, const float* cente
     }
     V.project_pdf = (float)(1 / (3.14159265358979323846 * V.r * V.r));
     V.valid = 1;
+    kp.scene.general = 1;
+    blocks_per_cu[0] = blocks_per_cu_batch = 0;   // other instantiations from now on: ask again
     kp.scene.lights = d_lights; kp.scene.n_lights = n_lights;
     // every cache traced so far is without sky vertices
     have_sampler = false; pending.clear(); built_sets.clear(); lvc_count = 0;
@@ -774,7 +776,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
         const int generic = kernel_variant();
         if (!blocks_per_cu[generic]) {
-            blocks_per_cu[generic] = spcbpt_blocks_per_cu(generic);
+            blocks_per_cu[generic] = spcbpt_blocks_per_cu(generic, false, kp.scene.general != 0);
             // developer knob (occupancy experiments): fewer resident blocks per CU than the kernel's resources allow
             if (const char* e = getenv("SPCBPT_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < blocks_per_cu[generic]) blocks_per_cu[generic] = v; }
             if (const char* e = getenv("SPCBPT_TILES_PER_WAVE")) tiles_per_wave = std::max(1, atoi(e));
@@ -852,8 +854,8 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     kp.work_counter = d_work_counter + rk;
     kp.result = nullptr; kp.subframe = subframes[0];
     HIP_TRY(this, hipMemsetAsync(d_work_counter + rk, 0, sizeof(uint32_t), rstream));
-    if (!blocks_per_cu[0]) blocks_per_cu[0] = spcbpt_blocks_per_cu(0);
-    int max_blocks = num_cus * blocks_per_cu[0];
+    if (!blocks_per_cu_batch) blocks_per_cu_batch = spcbpt_blocks_per_cu(0, true, kp.scene.general != 0);
+    int max_blocks = num_cus * blocks_per_cu_batch;
     // a batch kernel runs for tens of milliseconds: the light passes of the batches after it need block slots meanwhile -- few,
     // since they run as a thin grid (launch_light_batch): 97 % (64 steps on one GPU: 5.76 ms per step at 94 %, 5.69 at 97, 5.67 at 100;
     // a rank's share of a sharded frame is indifferent: 0.81-0.82 ms per rank-frame at N = 8 with all three)
@@ -1064,6 +1066,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
         d.metallic = m.metallic; d.roughness = m.roughness; d.specular = m.specular; d.specular_tint = m.specular_tint;
         d.subsurface = m.subsurface; d.sheen = m.sheen; d.sheen_tint = m.sheen_tint; d.clearcoat = m.clearcoat;
         d.clearcoat_gloss = m.clearcoat_gloss; d.albedo_tex = m.albedo_tex; d.light_id = -1;
+        d.brdf = m.brdf != 0;   // Pbr::brdf is a bool (MaterialData.h:99) assigned from the scene file's int (scene_shift.cpp:75)
         mats.push_back(d);
     }
     std::vector<DLight> lights;
@@ -1153,6 +1156,8 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     memset(&c->kp, 0, sizeof(c->kp));
     c->kp.scene.nodes = c->d_nodes; c->kp.scene.tris = c->d_tris; c->kp.scene.tri_orig = c->d_tri_orig; c->kp.scene.mats = c->d_mats;
     c->kp.scene.lights = c->d_lights; c->kp.scene.tex = c->d_tex; c->kp.scene.n_lights = c->n_lights; c->kp.scene.n_mats = c->n_mats;
+    c->kp.scene.general = 0;   // no environment map yet; a flagged material (Pbr::brdf) selects the general kernels as well
+    for (const DMaterial& m : mats) if (m.brdf) c->kp.scene.general = 1;
     c->kp.sampler_counts = c->d_sampler_counts;
     c->kp.diag = c->d_diag;
     c->kp.row_step = 1;

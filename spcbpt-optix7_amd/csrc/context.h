@@ -177,7 +177,8 @@ struct Context {
     int check_diag();                  // after a sync: SPCBPT_ERR_STATE if a kernel dropped stack entries since the last check
     // instrumentation
     uint32_t* d_work_counter = nullptr;
-    int num_cus = 0, blocks_per_cu[3] = {0, 0, 0};   // per kernel variant
+    int num_cus = 0, blocks_per_cu[3] = {0, 0, 0};   // per kernel variant (single-frame launches), of the instantiation launched
+    int blocks_per_cu_batch = 0;                       // the batched timed kernel's
     int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 94 with several render streams, else 100 (launch_render)
     int light_blocks = -1;             // persistent grid of the light pass (SPCBPT_LIGHT_BLOCKS; default: one block per CU)
     int light_batch_blocks = -1;       // ... of a batched light pass (SPCBPT_LIGHT_BATCH_BLOCKS; 0 = in proportion to the light paths per pixel, >= 16: launch_light_batch)

@@ -444,6 +444,7 @@ struct Pbr {
     f3 base;
     float metallic, roughness, specular, specularTint, subsurface, sheen, sheenTint, clearcoat, clearcoatGloss;
     int albedo_tex, light_id;
+    int brdf;   // MaterialData::Pbr::brdf: see brdf_div
 };
 SPC_DEV Pbr load_pbr(const DeviceScene& S, int id) {
     const float4* p = reinterpret_cast<const float4*>(S.mats + id);
@@ -452,7 +453,7 @@ SPC_DEV Pbr load_pbr(const DeviceScene& S, int id) {
     m.base = mk3(a.x, a.y, a.z); m.metallic = a.w;
     m.roughness = b.x; m.specular = b.y; m.specularTint = b.z; m.subsurface = b.w;
     m.sheen = c.x; m.sheenTint = c.y; m.clearcoat = c.z; m.clearcoatGloss = c.w;
-    m.albedo_tex = __float_as_int(d.x); m.light_id = __float_as_int(d.y);
+    m.albedo_tex = __float_as_int(d.x); m.light_id = __float_as_int(d.y); m.brdf = __float_as_int(d.z);
     return m;
 }
 SPC_DEV Pbr load_pbr_colored(const DeviceScene& S, int id, f3 color) {  // rmis::getMat (rmis.h:16-21)
@@ -575,6 +576,17 @@ SPC_DEV f3 bsdf_eval(const Pbr& m, f3 N, f3 V, f3 L) {
         out = out + mk3(0.25f * m.clearcoat * Gr * Fr * Dr);
     }
     return out;
+}
+// `Eval(...) / (mat.brdf ? abs(dot(n, dir)) : 1.0f)`: the un-guarded ternary of the bidirectional programs (hit_program.cu:286, 384;
+// raygen.cu:271, 278; rmis.h:105) for a material with `brdf <nonzero>` in its .scene block.  operator/(float3, float) multiplies by
+// the reciprocal (sutil/vec_math.h:483-487) and x * (1.0f / 1.0f) is x, so the division is only executed on the flagged branch.
+// A grazing direction (|n.dir| == 0) gives inf / NaN as upstream: the vertex's later contributions fail ISINVALIDVALUE there and here.
+// ENV = false (the timed kernels of a scene with neither an environment map nor a flagged material, DeviceScene::general == 0)
+// compiles the test away: 0.6 % of the bedroom frame (A/B on one box, profiles/r04_experiments.md).
+template <bool ENV = true>
+SPC_DEV f3 brdf_div(const Pbr& m, f3 f, f3 n, f3 dir) {
+    if (ENV && m.brdf) f = f / fabsf(dot(n, dir));
+    return f;
 }
 SPC_DEV f3 bsdf_sample(const Pbr& m, f3 N, f3 V, uint32_t& seed) {
     const float probability = rnd(seed);
@@ -757,8 +769,9 @@ SPC_DEV float rmis_last_pdf(const Pbr& mat, const VCore& v, f3 in_dir) {
     return pdf * rr_of(v.color);
 }
 // getFluxMultiplier (rmis.h:102-118)
+template <bool ENV = true>
 SPC_DEV f3 rmis_flux_multiplier(const Pbr& mat, const VCore& v, f3 in_dir, f3 out_dir) {
-    const f3 flux_ratio = bsdf_eval(mat, v.n, in_dir, out_dir);
+    const f3 flux_ratio = brdf_div<ENV>(mat, bsdf_eval(mat, v.n, in_dir, out_dir), v.n, out_dir);   // rmis.h:105
     const float pdf_ratio = bsdf_pdf(mat, v.n, in_dir, out_dir);
     const float rr = rr_of(v.color);
     const float cos_theta = fabsf(dot(v.n, out_dir));
@@ -868,7 +881,7 @@ SPC_DEV f3 connect_direction(const KParams& p, const EyeVertex& a, const LightVe
 // connectVertex_SPCBPT (raygen.cu:253-303) with rmis::general_connection / connection_lightSource
 // (rmis.h:212-247 / 281-313) fused: every BSDF lobe is fetched once.
 // ENV = false: the scene has no environment map -- no vertex carries a direction flag, and the two tests fold away (the timed
-// kernels of a scene without a sky are instantiated so: 3 % of the frame)
+// kernels of a scene without a sky are instantiated so: 3 % of the frame) -- and no `brdf`-flagged material (brdf_div)
 template <bool COUNT, bool CACHE = false, bool ENV = true>
 SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVertex& b, Counts<COUNT>& cn, float* w_out = nullptr) {
     if (ENV && (b.pad & SPCBPT_LV_DIRECTION)) return connect_direction<COUNT, CACHE>(p, a, b, cn, w_out);   // raygen.cu:255-258
@@ -880,12 +893,12 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
     const float G = fabsf(dot(a.c.n, connectDir)) * fabsf(dot(bn, connectDir)) / r2;
     const f3 LA_DIR = normalize(a.c.lastPos - a.c.pos);
     const Pbr mat_a = load_pbr_colored(S, a.c.mat, a.c.color);
-    const f3 fa = bsdf_eval(mat_a, a.c.n, -connectDir, LA_DIR);
+    const f3 fa = brdf_div<ENV>(mat_a, bsdf_eval(mat_a, a.c.n, -connectDir, LA_DIR), a.c.n, connectDir);   // raygen.cu:271
     const f3 lflux = bflux / b.pdf;  // `flux` of the rmis functions
 
     // ---- eye side terms shared by both connection kinds
     const float LL_pdf_A = rmis_last_pdf(mat_a, a.c, -connectDir);                 // getLL_pdf(light, eye)
-    const f3 fm0 = rmis_flux_multiplier(mat_a, a.c, -connectDir, LA_DIR);           // getFluxMultiplier(eye, -connect_dir)
+    const f3 fm0 = rmis_flux_multiplier<ENV>(mat_a, a.c, -connectDir, LA_DIR);      // getFluxMultiplier(eye, -connect_dir)
     // the two relabels of the connection (light-tree label of the eye vertex seen from b, eye-tree label of the light vertex
     // seen from a) in one lock-step descent; the first is skipped at depth 1, the second for an emitter vertex, as in rmis.h
     int light_label, eye_label;
@@ -914,9 +927,9 @@ SPC_DEV f3 connect_vertices(const KParams& p, const EyeVertex& a, const LightVer
         const VCore bc = core_of<ENV>(b);
         const Pbr mat_b = load_pbr_colored(S, bc.mat, bc.color);
         const f3 LB_DIR = normalize(bc.lastPos - bc.pos);
-        fb = bsdf_eval(mat_b, bn, connectDir, LB_DIR);
+        fb = brdf_div<ENV>(mat_b, bsdf_eval(mat_b, bn, connectDir, LB_DIR), bn, connectDir);   // raygen.cu:278
         const float pdf_A = rmis_get_pdf(mat_b, bc, a.c.pos, a.c.n, LB_DIR);        // getPdf(light, eye, LA)
-        const f3 fm1 = rmis_flux_multiplier(mat_b, bc, LB_DIR, connectDir);
+        const f3 fm1 = rmis_flux_multiplier<ENV>(mat_b, bc, LB_DIR, connectDir);
         D_A = sum3(D_A_0 * pdf_A * fm1 * lflux / a.singlePdf);
         const float LL_pdf_B = rmis_last_pdf(mat_b, bc, connectDir);               // getLL_pdf(eye, light)
         const float wB = rmis_weight_light_l(p, b.last_zone_id, b.last_lum, eye_label, cn);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -31,14 +32,14 @@ struct RGBe { unsigned char v[4]; };
 
 bool read_flat(std::ifstream& in, RGBe* line, size_t wid) {
     in.read(reinterpret_cast<char*>(line), (std::streamsize)(wid * sizeof(RGBe)));
-    return !in.eof();
+    return (bool)in;
 }
 bool read_scanline(std::ifstream& in, RGBe* line, size_t wid) {
     const size_t MinLen = 8, MaxLen = 0x7fff;
     if (wid < MinLen || wid > MaxLen) return read_flat(in, line, wid);
     char c0, c1, c2, c3;
     in.get(c0); in.get(c1); in.get(c2); in.get(c3);
-    if (in.eof()) return false;
+    if (!in) return false;
     if (c0 != 2 || c1 != 2 || (c2 & 0x80)) {   // an old-format scanline
         in.putback(c3); in.putback(c2); in.putback(c1); in.putback(c0);
         return read_flat(in, line, wid);
@@ -49,18 +50,18 @@ bool read_scanline(std::ifstream& in, RGBe* line, size_t wid) {
         for (size_t x = 0; x < wid;) {
             unsigned char code;
             in.get(reinterpret_cast<char&>(code));
-            if (in.eof()) return false;
+            if (!in) return false;
             if (code > 0x80) {   // run
                 char pix;
                 in.get(pix);
-                if (in.eof()) return false;
+                if (!in) return false;
                 code = code & 0x7f;
                 while (code--) { if (x >= wid) return false; line[x++].v[ch] = (unsigned char)pix; }
             } else {             // literal span
                 while (code--) {
                     if (x >= wid) return false;
                     in.get(reinterpret_cast<char&>(line[x++].v[ch]));
-                    if (in.eof()) return false;
+                    if (!in) return false;
                 }
             }
         }
@@ -92,12 +93,15 @@ extern "C" int spcbpt_hdr_load(const char* path, int* width, int* height, float*
     std::string major, minor;
     long ny = 0, nx = 0;
     in >> minor >> ny >> major >> nx;
-    if (minor != "-Y" || major != "+X" || nx <= 0 || ny <= 0 || nx > 65536 || ny > 65536) return SPCBPT_ERR_IO;
+    if (!in || minor != "-Y" || major != "+X" || nx <= 0 || ny <= 0 || nx > 65536 || ny > 65536) return SPCBPT_ERR_IO;
+    if ((long long)nx * ny > (1ll << 26)) return SPCBPT_ERR_CAPACITY;   // spcbpt_set_environment's own limit: nothing larger can be used
     get_line(in, comment);   // the rest of the resolution line
     *width = (int)nx; *height = (int)ny;
     if (!rgba) return SPCBPT_OK;   // size query
     if (capacity_floats < (size_t)nx * (size_t)ny * 4) return SPCBPT_ERR_CAPACITY;
-    std::vector<RGBe> raster((size_t)nx * (size_t)ny);
+    std::vector<RGBe> raster;
+    try { raster.resize((size_t)nx * (size_t)ny); }   // <= 256 MiB after the check above; still never throw across the C ABI
+    catch (const std::exception&) { return SPCBPT_ERR_CAPACITY; }
     for (long y = 0; y < ny; y++)
         if (!read_scanline(in, raster.data() + (size_t)nx * y, (size_t)nx)) return SPCBPT_ERR_IO;
     const float inv_img_exposure = 1.0f / exposure;

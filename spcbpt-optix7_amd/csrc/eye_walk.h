@@ -15,7 +15,7 @@ struct WalkState {
     bool done;
 };
 
-template <bool COUNT, bool CACHE = false>
+template <bool COUNT, bool CACHE = false, bool ENV = true>   // ENV = false: DeviceScene::general == 0 (brdf_div compiled out)
 SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
                              WalkState& w, EyeVertex& mid, Counts<COUNT>& cn, bool stop_dead_paths = false) {
     const DeviceScene& S = p.scene;
@@ -59,12 +59,12 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
         const f3 in_dir = normalize(mid.c.pos - last.c.pos);
         const float LL_pdf = rmis_last_pdf(mat_last, last.c, in_dir);
         const float wgt = rmis_weight_eye_l(p, last.depth, last.lastZone, light_label, cn);
-        const f3 fm = rmis_flux_multiplier(mat_last, last.c, in_dir, normalize(last.c.lastPos - last.c.pos));
+        const f3 fm = rmis_flux_multiplier<ENV>(mat_last, last.c, in_dir, normalize(last.c.lastPos - last.c.pos));
         mid.R3 = (last.R3 * LL_pdf * fm + mk3(wgt)) / last.singlePdf;
     }
     cn.add(C_VERTEX);
     // next segment + Russian roulette (the vertex itself is kept; hit_program.cu:324-337)
-    w.next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
+    w.next_flux = brdf_div<ENV>(pbr, bsdf_eval(pbr, N, inv_dir, new_dir), N, new_dir);   // hit_program.cu:286
     // a sampled direction whose BSDF value is exactly zero (it points below the surface) gives every later
     // vertex a flux of exactly zero -- emitter hits and connections of the rest of the path contribute 0 (or NaN -> rejected).
     // The render kernels end the path after this vertex's connections; the image is unchanged.
@@ -80,7 +80,7 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
 
 // __closesthit__eyeSubpath_LightSource + rmis::light_hit + lightStraghtHit (hit_program.cu:62-147, rmis.h:359-389,
 // raygen.cu:305-317): contribution of an eye path that runs into an emitter.
-template <bool COUNT, bool CACHE = false>
+template <bool COUNT, bool CACHE = false, bool ENV = true>
 SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_dir, bool last_is_origin, const EyeVertex& last,
                            const WalkState& w, Counts<COUNT>& cn) {
     const DeviceScene& S = p.scene;
@@ -102,7 +102,7 @@ SPC_DEV f3 eye_emitter_hit(const KParams& p, const Geom& g, float t_hit, f3 ray_
         const Pbr mat_e = load_pbr_colored(S, last.c.mat, last.c.color);
         const f3 LB = normalize(last.c.lastPos - last.c.pos);
         const float LL_pdf_A = rmis_last_pdf(mat_e, last.c, -connect_dir);
-        const f3 fm0 = rmis_flux_multiplier(mat_e, last.c, -connect_dir, LB);
+        const f3 fm0 = rmis_flux_multiplier<ENV>(mat_e, last.c, -connect_dir, LB);
         const float wA = CACHE ? rmis_weight_eye_l(p, last.depth, last.lastZone, last.lsub, cn) : rmis_weight_eye(p, last.c, last.depth, last.lastZone, lpos, cn);
         const f3 D_A_0 = last.R3 * LL_pdf_A * fm0 + mk3(wA);
         const float pdf_A = rmis_pdf_from_light(lpos, ln, last.c.pos, last.c.n);

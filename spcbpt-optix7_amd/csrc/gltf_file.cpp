@@ -16,6 +16,8 @@
 // The mesh / transform / camera arithmetic is pinned bit-exactly against the reference's vendored tinygltf + sutil::Matrix4x4 /
 // Quaternion (oracle/_ref/libref_gltf.so, tests/golden/ref_gltf.npz, tests/test_gltf.py).
 #include <cmath>
+#include <new>
+#include <stdexcept>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -281,6 +283,7 @@ struct Gltf {
             m.base_color[0] = m.base_color[1] = m.base_color[2] = 1.0f;
             m.metallic = 1.0f; m.roughness = 1.0f;   // glTF defaults
             m.specular = 0.5f; m.sheen_tint = 0.5f; m.clearcoat_gloss = 1.0f;  // MaterialData() values of the .scene route (q17)
+            m.brdf = 0;   // sutil/Scene.cpp never sets Pbr::brdf: the glTF route keeps MaterialData.h:99's `false`
             if (i < n) {
                 const J* pbr = ms->a[i].get("pbrMetallicRoughness");
                 if (pbr) {
@@ -454,7 +457,7 @@ struct Gltf {
 
 extern "C" {
 
-int spcbpt_gltf_load(const char* path, spcbpt_scene_file** out, char* error, int error_capacity) {
+static int gltf_load_impl(const char* path, spcbpt_scene_file** out, char* error, int error_capacity) {
     if (!path || !out) return SPCBPT_ERR_INVALID_ARG;
     *out = nullptr;
     auto report = [&](const std::string& m) {
@@ -494,6 +497,13 @@ int spcbpt_gltf_load(const char* path, spcbpt_scene_file** out, char* error, int
     for (size_t i = 0; i < s->textures.size(); i++) s->textures[i].rgba = s->tex_pixels[i].data();
     *out = s;
     return SPCBPT_OK;
+}
+
+// never throw across the C ABI (std::bad_alloc from a file that declares more data than memory holds)
+int spcbpt_gltf_load(const char* path, spcbpt_scene_file** out, char* error, int error_capacity) {
+    try { return gltf_load_impl(path, out, error, error_capacity); }
+    catch (const std::bad_alloc&) { if (error && error_capacity > 0) snprintf(error, (size_t)error_capacity, "out of memory"); return SPCBPT_ERR_CAPACITY; }
+    catch (const std::exception& e) { if (error && error_capacity > 0) snprintf(error, (size_t)error_capacity, "%s", e.what()); return SPCBPT_ERR_IO; }
 }
 
 }  // extern "C"

@@ -11,6 +11,8 @@
 //         upsampling centred as JFIF prescribes, and the 12.8 fixed-point YCbCr conversion
 // Binary PPM (P6) stays in scene_file.cpp.  Host code, no GPU.
 #include <cstdint>
+#include <new>
+#include <stdexcept>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -701,7 +703,7 @@ bool load_image(const std::string& path, std::vector<uint8_t>& rgba, int& w, int
 }
 }  // namespace spc_loader
 
-extern "C" int spcbpt_image_load(const char* path, int* width, int* height, uint8_t* rgba, size_t capacity_bytes) {
+static int image_load_impl(const char* path, int* width, int* height, uint8_t* rgba, size_t capacity_bytes) {
     if (!path || !width || !height) return SPCBPT_ERR_INVALID_ARG;
     std::vector<uint8_t> px;
     int w = 0, h = 0;
@@ -712,4 +714,10 @@ extern "C" int spcbpt_image_load(const char* path, int* width, int* height, uint
         memcpy(rgba, px.data(), px.size());
     }
     return SPCBPT_OK;
+}
+
+extern "C" int spcbpt_image_load(const char* path, int* width, int* height, uint8_t* rgba, size_t capacity_bytes) {
+    try { return image_load_impl(path, width, height, rgba, capacity_bytes); }   // never throw across the C ABI
+    catch (const std::bad_alloc&) { return SPCBPT_ERR_CAPACITY; }
+    catch (const std::exception&) { return SPCBPT_ERR_IO; }
 }

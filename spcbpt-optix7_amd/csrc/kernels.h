@@ -9,7 +9,7 @@ namespace spc {
 
 int render_thread_count(const KParams& p);
 void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s);   // 0 timed, 1 reference order + counters (generic), 2 timed + counters
-int spcbpt_blocks_per_cu(int variant);
+int spcbpt_blocks_per_cu(int variant, bool batch, bool general);
 int render_tile_count(const KParams& p);
 void launch_pt(const KParams& p, bool count, hipStream_t s);
 void launch_film_merge(const KParams& p, hipStream_t s);

@@ -49,7 +49,8 @@ static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye
 // CACHE: label caching (device_lib.h).  <false, *, true> are the timed kernels; <true, false, false> evaluates in the reference's
 // order and charges its events (the contract's byte table, and the generic form for classifier trees with direction nodes);
 // <true, false, true> counts the events the TIMED kernels execute (roofline.frac: what runs, not what the reference would run).
-// ENV = false (timed forms only, chosen by the launcher for a scene without an environment map): the direction tests are compiled out.
+// ENV = false (timed forms only, chosen by the launcher for a scene with neither an environment map nor a material flagged
+// `brdf`, DeviceScene::general == 0): the direction tests and the flag's divisions (device_lib.h brdf_div) are compiled out.
 template <bool COUNT, bool BATCH, bool CACHE, bool ENV = true>
 __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
@@ -282,11 +283,11 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                 const bool last_is_origin = cur.depth == 0;
                 const f3 ray_dir = w.dir;
                 if (g.emitter) {
-                    result += eye_emitter_hit<COUNT, CACHE>(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
+                    result += eye_emitter_hit<COUNT, CACHE, ENV>(p, g, h.t, ray_dir, last_is_origin, cur, w, cn);
                     finished = true;
                 } else {
                     EyeVertex mid;
-                    eye_surface_hit<COUNT, CACHE>(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn, true);
+                    eye_surface_hit<COUNT, CACHE, ENV>(p, g, h.t, ray_dir, last_is_origin, cur, w, mid, cn, true);
                     cur = mid;
                     has_vertex = true;
                     long long t_s0 = COUNT ? clock64() : 0;
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                         m.rmis_pointer = (last.rmis_pointer * LL_pdf + wgt) / last.single_pdf;
                     }
                     cn.add(C_VERTEX);
-                    next_flux = bsdf_eval(pbr, N, inv_dir, new_dir);
+                    next_flux = brdf_div(pbr, bsdf_eval(pbr, N, inv_dir, new_dir), N, new_dir);   // hit_program.cu:384
                     next_single_pdf = pdf;
                     origin = g.P;
                     dir = new_dir;
@@ -1322,7 +1323,7 @@ void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s)
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     if (variant == 1) hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
     else if (variant == 2) hipLaunchKernelGGL((k_spcbpt<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else if (p.scene.env.valid) hipLaunchKernelGGL((k_spcbpt<false, false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL((k_spcbpt<false, false, true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }
 // p.frames / p.n_frames describe the batch; p.n_tiles is the tile count of ONE frame
@@ -1336,14 +1337,20 @@ int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
 void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
     const int blocks = spcbpt_batch_blocks(p, max_blocks);
     if (blocks <= 0) return;
-    if (p.scene.env.valid) hipLaunchKernelGGL((k_spcbpt<false, true, true, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
+    if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, true, true, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL((k_spcbpt<false, true, true, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
 }
-int spcbpt_blocks_per_cu(int variant) {
+// resident blocks per CU of the instantiation launch_spcbpt / launch_spcbpt_batch will really launch for (variant, batch, general):
+// the forms differ in registers and scratch (the ENV = false form exists because of that), so each is asked for itself
+int spcbpt_blocks_per_cu(int variant, bool batch, bool general) {
     int n = 0;
-    hipError_t e = variant == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, false>, BLOCK, 0)
-                 : variant == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, true>, BLOCK, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true>, BLOCK, 0);
+    hipError_t e;
+    if (variant == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, false>, BLOCK, 0);
+    else if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, true>, BLOCK, 0);
+    else if (batch) e = general ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, true, true, true>, BLOCK, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, true, true, false>, BLOCK, 0);
+    else e = general ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true, true>, BLOCK, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true, false>, BLOCK, 0);
     return e == hipSuccess && n > 0 ? n : 1;
 }
 int render_tile_count(const KParams& p) {

@@ -37,7 +37,8 @@ struct DMaterial {  // 64 B; MaterialData::Pbr values (cuda/MaterialData.h:82-10
     float sheen, sheen_tint, clearcoat, clearcoat_gloss;
     int32_t albedo_tex;  // 0 none, else texture index + 1
     int32_t light_id;    // >= 0 for the emissive pseudo-materials (scene_shift.cpp:92-103)
-    int32_t pad[2];
+    int32_t brdf;        // MaterialData::Pbr::brdf (MaterialData.h:99): the five |N.L| divisions of the bidirectional programs
+    int32_t pad;
 };
 static_assert(sizeof(DMaterial) == 64, "DMaterial");
 
@@ -108,6 +109,8 @@ struct DeviceScene {
     const DTexture* tex;
     int32_t n_lights;        // QUAD lights, then the ENV light if the scene has an environment map
     int32_t n_mats;
+    int32_t general;         // != 0: the scene has an environment map or a material with `brdf` set -> the timed kernels' ENV = true forms
+    int32_t pad_general;
     DEnv env;
 };
 

@@ -58,12 +58,28 @@ struct LocalGroup {
     std::vector<bool> wants_tuple;
     double running_max = 0.0; int max_calls = 0;
     int calib_max = 0, calib_min_lvc = 0;
+    long long calib_calls = 0;   // every rank calibrates once per round (world calls)
 };
 
 int fail(spcbpt_comm* c, int code, const std::string& msg) {
     if (c) c->error = msg;
     return code;
 }
+void unpost_all(LocalGroup* g);
+// Local transport: the exchange completes in the call of the LAST rank to post.  Whatever way that call ends -- success, a rank
+// that posted another frame count, a failed allocation or HIP call -- every rank is un-posted and the events of the call are
+// destroyed, so the group can exchange again (a call that merely posts keeps its mark: keep()).
+struct PostGuard {
+    LocalGroup* g;
+    bool armed = true;
+    std::vector<hipEvent_t> events;
+    explicit PostGuard(LocalGroup* grp) : g(grp) {}
+    void keep() { armed = false; }
+    ~PostGuard() {
+        for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e);
+        if (armed) unpost_all(g);
+    }
+};
 #define HIPX(c, expr)                                                                                     \
     do {                                                                                                  \
         hipError_t e__ = (expr);                                                                          \
@@ -79,6 +95,8 @@ int fail(spcbpt_comm* c, int code, const std::string& msg) {
         int r__ = (expr);                                                                                 \
         if (r__ != 0) return fail(c, r__, std::string(#expr) + ": " + spcbpt_last_error((c)->ctx));          \
     } while (0)
+
+void unpost_all(LocalGroup* g) { for (spcbpt_comm* s : g->ranks) s->l_posted = false; }
 
 int ensure_gather(spcbpt_comm* c, int frames = 1) {
     const size_t need = (size_t)c->world * (size_t)frames * (size_t)c->shard_cap * kVertexBytes;
@@ -263,8 +281,18 @@ int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
     void *dv = nullptr, *dc = nullptr;
     int cap = 0;
     CTXX(c, spcbpt_lvc_export_on(c->ctx, c->xs, &dv, &dc, &cap));   // xs waits for the light pass on the device
-    if (cap < c->shard_cap) return fail(c, SPCBPT_ERR_CAPACITY, "exchange_lvc: the context's light-vertex cache (" + std::to_string(cap) + " vertices) is smaller than the shard capacity (" +
-                                        std::to_string(c->shard_cap) + "): call spcbpt_comm_calibrate (or spcbpt_comm_set_shard_capacity / spcbpt_lvc_set_capacity) at start-up");
+    if (cap < 1) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc: no light pass has been traced");
+    if (cap < c->shard_cap) {
+        // The caches are sized per rank from each rank's own probe pass, so this test comes out differently on different ranks; a
+        // rank that refused here would leave the others blocked in the all-gather.  A shard is sent as shard_cap slots: a smaller
+        // cache is staged through the communicator's own send buffer instead (the slots behind the cache are never read by the
+        // import: every rank's count is <= its cache, and a count above shard_cap is refused by EVERY rank, from the gathered
+        // counts).  spcbpt_comm_calibrate makes this branch dead by agreeing min(cache) with the shard capacity.
+        rc = ensure_send(c, 1);
+        if (rc) return rc;
+        HIPX(c, hipMemcpyAsync(c->d_send, dv, (size_t)cap * kVertexBytes, hipMemcpyDeviceToDevice, c->xs));
+        dv = c->d_send;
+    }
     if (c->nccl) {
         NCCLX(c, ncclGroupStart());
         NCCLX(c, ncclAllGather(dc, c->d_counts_all, 2, ncclInt32, c->nccl, c->xs));
@@ -277,8 +305,9 @@ int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
     std::lock_guard<std::mutex> lk(g->mu);
     if (c->l_posted) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc (local): this rank already posted; every rank must call before any calls again");
     c->l_send = dv; c->l_counts = dc; c->l_posted = true;
+    PostGuard guard(g);                                               // a failure below un-posts every rank and frees the events
     HIPX(c, hipEventRecord(c->l_ready, c->xs));                       // behind the wait for the light pass
-    for (spcbpt_comm* s : g->ranks) if (!s->l_posted) return SPCBPT_OK;    // completed by the last rank to post
+    for (spcbpt_comm* s : g->ranks) if (!s->l_posted) { guard.keep(); return SPCBPT_OK; }   // completed by the last rank to post
     for (spcbpt_comm* s : g->ranks) { int r2 = ensure_gather(s); if (r2) return r2; }
     // copies first (on every destination's stream), then the imports -- which overwrite the send buffers -- behind all of them
     for (spcbpt_comm* d : g->ranks) {
@@ -289,7 +318,8 @@ int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
             HIPX(d, hipMemcpyAsync(d->d_counts_all + 2 * s->rank, s->l_counts, 2 * sizeof(int), hipMemcpyDeviceToDevice, d->xs));
         }
     }
-    std::vector<hipEvent_t> copied(g->ranks.size());
+    std::vector<hipEvent_t>& copied = guard.events;
+    copied.assign(g->ranks.size(), nullptr);
     for (size_t k = 0; k < g->ranks.size(); k++) {
         HIPX(c, hipEventCreateWithFlags(&copied[k], hipEventDisableTiming));
         HIPX(c, hipEventRecord(copied[k], g->ranks[k]->xs));
@@ -299,10 +329,8 @@ int spcbpt_comm_exchange_lvc(spcbpt_comm* c) {
         for (size_t k = 0; k < copied.size(); k++) (void)hipStreamWaitEvent(d->xs, copied[k], 0);
         int r2 = spcbpt_lvc_import_gathered(d->ctx, d->d_gather, d->d_counts_all, d->world, d->shard_cap, d->xs);
         if (r2 && !result) result = fail(c, r2, std::string("spcbpt_lvc_import_gathered: ") + spcbpt_last_error(d->ctx));
-        d->l_posted = false;
     }
-    for (hipEvent_t e : copied) (void)hipEventDestroy(e);
-    return result;
+    return result;   // the guard un-posts every rank and destroys the events
 }
 
 // One exchange per light batch: the shards of the n oldest pending passes travel as ONE all-gather (plus one of the count pairs),
@@ -330,8 +358,9 @@ int spcbpt_comm_exchange_lvc_batch(spcbpt_comm* c, int n) {
     std::lock_guard<std::mutex> lk(g->mu);
     if (c->l_posted) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc_batch (local): this rank already posted; every rank must call before any calls again");
     c->l_send = c->d_send; c->l_counts = c->d_send_counts; c->l_posted = true; c->l_frames = n;
+    PostGuard guard(g);                                               // a failure below un-posts every rank and frees the events
     HIPX(c, hipEventRecord(c->l_ready, c->xs));
-    for (spcbpt_comm* s : g->ranks) if (!s->l_posted) return SPCBPT_OK;    // completed by the last rank to post
+    for (spcbpt_comm* s : g->ranks) if (!s->l_posted) { guard.keep(); return SPCBPT_OK; }   // completed by the last rank to post
     for (spcbpt_comm* s : g->ranks) if (s->l_frames != n) return fail(c, SPCBPT_ERR_STATE, "exchange_lvc_batch (local): the ranks posted different frame counts");
     for (spcbpt_comm* s : g->ranks) { int r2 = ensure_gather(s, n); if (r2) return r2; }
     const size_t block = (size_t)n * c->shard_cap * kVertexBytes;
@@ -344,7 +373,8 @@ int spcbpt_comm_exchange_lvc_batch(spcbpt_comm* c, int n) {
     }
     // (the send buffers are the communicators' own: a rank's next pack waits on its own stream behind these copies only if it is
     // the destination too, so every destination records an event the senders' streams wait for)
-    std::vector<hipEvent_t> copied(g->ranks.size());
+    std::vector<hipEvent_t>& copied = guard.events;
+    copied.assign(g->ranks.size(), nullptr);
     for (size_t k = 0; k < g->ranks.size(); k++) {
         HIPX(c, hipEventCreateWithFlags(&copied[k], hipEventDisableTiming));
         HIPX(c, hipEventRecord(copied[k], g->ranks[k]->xs));
@@ -354,10 +384,8 @@ int spcbpt_comm_exchange_lvc_batch(spcbpt_comm* c, int n) {
         for (size_t k = 0; k < copied.size(); k++) (void)hipStreamWaitEvent(d->xs, copied[k], 0);
         int r2 = spcbpt_lvc_import_gathered_batch(d->ctx, d->d_gather, d->d_counts_all, d->world, n, d->shard_cap, d->xs);
         if (r2 && !result) result = fail(c, r2, std::string("spcbpt_lvc_import_gathered_batch: ") + spcbpt_last_error(d->ctx));
-        d->l_posted = false;
     }
-    for (hipEvent_t e : copied) (void)hipEventDestroy(e);
-    return result;
+    return result;   // the guard un-posts every rank and destroys the events
 }
 
 int spcbpt_comm_info(const spcbpt_comm* c, int* rank, int* world, int* transport) {
@@ -398,6 +426,8 @@ int spcbpt_comm_calibrate(spcbpt_comm* c, int passes, uint32_t first_frame, floa
         global_max = outv[0]; min_lvc = -outv[1];
     } else {   // local: the ranks calibrate one after the other; the agreed capacity follows the largest shard seen so far
         std::lock_guard<std::mutex> lk(c->grp->mu);
+        if (c->grp->calib_calls % c->world == 0) c->grp->calib_max = c->grp->calib_min_lvc = 0;   // a new round: the caches may have grown since the last one
+        c->grp->calib_calls++;
         c->grp->calib_max = std::max(c->grp->calib_max, own_max);
         c->grp->calib_min_lvc = c->grp->calib_min_lvc == 0 ? own_lvc : std::min(c->grp->calib_min_lvc, own_lvc);
         global_max = c->grp->calib_max; min_lvc = c->grp->calib_min_lvc;

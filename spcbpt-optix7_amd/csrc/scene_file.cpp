@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -58,6 +60,7 @@ const int kMaxLine = 2048;
 struct MatParam {  // MaterialParameter defaults (material_parameters.h:16-32)
     float color[3] = {1, 1, 1};
     float metallic = 0.0f, roughness = 0.5f;
+    int brdf = 0;   // BrdfType DISNEY (material_parameters.h:10-12, 30)
     std::string tex = "None";
 };
 
@@ -217,7 +220,7 @@ bool load_obj(const std::string& path, spcbpt_scene_file& s, int material) {
 
 extern "C" {
 
-int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt_scene_file** out) {
+static int scene_file_load_impl(const char* scene_path, const char* data_root, spcbpt_scene_file** out) {
     if (!scene_path || !out) return SPCBPT_ERR_INVALID_ARG;
     *out = nullptr;
     FILE* file = fopen(scene_path, "r");
@@ -244,6 +247,7 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
                 sscanf(line, " albedoTex %2047s", tex_name);
                 sscanf(line, " metallic %f", &m.metallic);
                 sscanf(line, " roughness %f", &m.roughness);
+                sscanf(line, " brdf %i", &m.brdf);   // sceneLoader.cpp:107; reaches the renderer as Pbr::brdf (scene_shift.cpp:75)
                 (void)dummy;  // emission / subsurface / specular / ... are parsed by the reference but never reach the renderer (q17)
             }
             m.tex = tex_name;
@@ -310,7 +314,7 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
         spcbpt_material m;
         memset(&m, 0, sizeof(m));
         memcpy(m.base_color, p.color, 12);
-        m.metallic = p.metallic; m.roughness = p.roughness;
+        m.metallic = p.metallic; m.roughness = p.roughness; m.brdf = p.brdf;
         m.specular = 0.5f; m.sheen_tint = 0.5f; m.clearcoat_gloss = 1.0f;  // MaterialData() defaults (q17)
         if (p.tex != "None") {
             auto it = texture_ids.find(p.tex);
@@ -359,6 +363,14 @@ int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt
 }
 
 // The scene's environment map (width = 0: none) and the sky.center / sky.r the reference derives from its scene box
+// never throw across the C ABI: a file that asks for more memory than there is (std::bad_alloc from the mesh / texture / raster
+// vectors) is reported like any other unusable file
+int spcbpt_scene_file_load(const char* scene_path, const char* data_root, spcbpt_scene_file** out) {
+    try { return scene_file_load_impl(scene_path, data_root, out); }
+    catch (const std::bad_alloc&) { return SPCBPT_ERR_CAPACITY; }
+    catch (const std::exception&) { return SPCBPT_ERR_IO; }
+}
+
 int spcbpt_scene_file_environment(spcbpt_scene_file* s, const float** rgba, int* width, int* height, float center[3], float* radius) {
     if (!s) return SPCBPT_ERR_INVALID_ARG;
     if (rgba) *rgba = s->env_w ? s->env_rgba.data() : nullptr;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(UBLOCK) void k_unit(const KParams p, int op, const 
         Pbr m;
         m.base = ldw3(r); m.metallic = ldf(r + 3); m.roughness = ldf(r + 4); m.specular = ldf(r + 5); m.specularTint = ldf(r + 6);
         m.subsurface = ldf(r + 7); m.sheen = ldf(r + 8); m.sheenTint = ldf(r + 9); m.clearcoat = ldf(r + 10); m.clearcoatGloss = ldf(r + 11);
-        m.albedo_tex = 0; m.light_id = -1;
+        m.albedo_tex = 0; m.light_id = -1; m.brdf = 0;
         const f3 N = ldw3(r + 12), V = ldw3(r + 15), L = ldw3(r + 18);
         uint32_t seed = r[21];
         const f3 Ls = bsdf_sample(m, N, V, seed);

@@ -365,6 +365,8 @@ def write_scene(scene: Scene, data_root: str, rel_dir: str) -> str:
     for k, m in enumerate(scene.materials):
         lines += [f"material mat{k}", "{", "   color %.9g %.9g %.9g" % tuple(m.get("color", (1, 1, 1))),
                   "   roughness %.9g" % m.get("roughness", 0.5), "   metallic %.9g" % m.get("metallic", 0.0), "   specular 0.5"]
+        if m.get("brdf", 0):
+            lines.append("   brdf %d" % int(m["brdf"]))   # sceneLoader.cpp:107 (the shipped house scene's `Glass`)
         if m.get("albedo_tex", 0) > 0:
             t = m["albedo_tex"] - 1
             name = f"{rel_dir}/tex{t}.ppm"

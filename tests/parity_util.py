@@ -117,3 +117,18 @@ def grid_tree_tuple(pkg, oracle, scene, frames: int = 2, first_frame: int = 20_0
         tot += paths
     _, _, q, gamma = tuple_from_q(pkg, acc / max(tot, 1))
     return et, lt, q, gamma
+
+
+def cornell_with_flagged_box(pkg, roughness: float = 0.0, color=(0.8, 0.8, 0.8), flag_walls: bool = False):
+    """Cornell box whose SHORT box carries a material with `brdf 1` (MaterialData::Pbr::brdf) -- with roughness 0 and colour 0.8 it
+    is the `Glass` block the reference ships (house_uvrefine2.scene:129-136).  flag_walls flags the white wall material too."""
+    scene = pkg.scenes.cornell_box()
+    tri_y = scene.vertices[scene.indices][:, :, 1]
+    box = (tri_y.max(1) <= 0.6 + 1e-6) & (tri_y.max(1) > 0.0)       # sides and top of the short box; the floor lies at y = 0
+    assert box.sum() == 10
+    scene.materials.append(dict(color=tuple(color), roughness=roughness, metallic=0.0, brdf=1))
+    scene.tri_material = scene.tri_material.copy()
+    scene.tri_material[box] = len(scene.materials) - 1
+    if flag_walls:
+        scene.materials[0]["brdf"] = 1
+    return scene

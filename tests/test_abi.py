@@ -24,12 +24,22 @@ def test_every_declared_symbol_is_exported(hip_lib, pkg):
     assert sorted(pkg.api.EXPORTED_SYMBOLS) == names
 
 
-def test_struct_sizes_match_header(pkg):
-    assert pkg.LIGHT_VERTEX_DTYPE.itemsize == 96
-    assert pkg.SUBSPACE_DTYPE.itemsize == 20
-    assert pkg.TREE_NODE_DTYPE.itemsize == 56      # sizeof(classTree::tree_node) in the reference is 56 too
-    assert C.sizeof(pkg.api.Material) == 52 and C.sizeof(pkg.api.QuadLight) == 52
-    assert C.sizeof(pkg.api.Counters) == 14 * 8
+def test_struct_sizes_match_header(hip_lib, pkg, ob):
+    """The ctypes / numpy mirrors against sizeof as the library was COMPILED from include/spcbpt.h (spcbpt_abi_struct_sizes)."""
+    sizes = (C.c_int32 * 32)()
+    n = hip_lib.spcbpt_abi_struct_sizes(sizes, 32)
+    assert n == 13
+    mat, tex, quad, desc, node, ltp, lv, sub, cnt, uev, ppath, pnode, vstate = list(sizes)[:n]
+    assert C.sizeof(pkg.api.Material) == mat == 56         # 13 floats / ints + brdf
+    assert C.sizeof(pkg.api.Texture) == tex and C.sizeof(pkg.api.QuadLight) == quad == 52 and C.sizeof(pkg.api.SceneDesc) == desc
+    assert C.sizeof(pkg.api.TreeNode) == pkg.TREE_NODE_DTYPE.itemsize == node == 56      # sizeof(classTree::tree_node) in the reference is 56 too
+    assert C.sizeof(pkg.api.LightTraceParams) == ltp
+    assert pkg.LIGHT_VERTEX_DTYPE.itemsize == lv == 96
+    assert pkg.SUBSPACE_DTYPE.itemsize == sub == 20
+    assert C.sizeof(pkg.api.Counters) == cnt == 14 * 8
+    assert ob.EYE_VERTEX_DTYPE.itemsize == uev
+    assert pkg.api.PRETRACE_PATH_DTYPE.itemsize == ppath == 48 and pkg.api.PRETRACE_NODE_DTYPE.itemsize == pnode == 96
+    assert C.sizeof(pkg.api.ViewerState) == vstate
 
 
 def test_create_fails_loudly_without_a_gpu(hip_lib, pkg):

@@ -7,6 +7,8 @@ import os
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -80,4 +82,16 @@ def test_inside_a_launcher_bench_does_not_spawn_again(monkeypatch):
             assert "MI355X" in str(e.code)
     finally:
         os.dup2(saved, 1); os.close(saved)
+    assert not called
+
+
+def test_world_size_that_contradicts_gpus_is_refused(monkeypatch):
+    # an outer harness exported WORLD_SIZE=1; `--gpus 8` must neither spawn nor silently run on one GPU
+    called = []
+    monkeypatch.setattr(bench, "spawn_ranks", lambda *a, **k: called.append(a) or 0)
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=1" in str(e.value.code) and "--gpus 8" in str(e.value.code)
     assert not called

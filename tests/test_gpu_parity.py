@@ -79,7 +79,10 @@ def test_light_vertex_cache_matches_oracle(gpu, pkg, ob, lt):
     """(3000, 64, 2): two paths per core, ranges never fill.  (60, 48, 40): the reference's kind of geometry -- many paths per
     core, and most cores end because their padded slot range is full (raygen.cu:652, 676), in the middle of a path or right
     after an origin vertex; the persistent light kernel must cut every core at the same vertex as the per-core loop."""
-    scene = pkg.scenes.cornell_box()
+    check_lvc(pkg, ob, pkg.scenes.cornell_box(), lt)
+
+
+def check_lvc(pkg, ob, scene, lt):
     r, o = _pair(pkg, ob, scene, 8, 8, lt=lt)
     tup = minimal_tuple(o, 2)
     r.set_subspace(*tup); o.set_subspace(*tup)
@@ -101,6 +104,7 @@ def test_light_vertex_cache_matches_oracle(gpu, pkg, ob, lt):
         rel = np.abs(x - y) / (scale + 1e-9)
         assert np.percentile(rel, 99) < 1e-3, k
     assert (np.abs((a["normal"] * b["normal"]).sum(1) - 1) < 1e-5).mean() > 0.999
+    return a, b
 
 
 def test_sampler_tables_exact_on_identical_lvc(gpu, pkg, ob):

@@ -72,11 +72,9 @@ def check(name, a, b, rel, min_frac, scale=None, hard=None):
         assert q[-1] <= hard, msg
 
 
-@pytest.fixture(scope="module")
-def world(gpu, pkg, ob):
-    """Bedroom-class scene (40 k triangles, textured materials) with a TRAINED tuple (multi-leaf trees, non-trivial Gamma / Q),
-    the same tuple and the same light-vertex cache on both sides."""
-    scene = pkg.scenes.bedroom(target_tris=40000, tex_size=64)
+def build_world(pkg, ob, scene):
+    """A renderer / oracle pair on `scene` with a TRAINED tuple (multi-leaf trees, non-trivial Gamma / Q), the same tuple and the
+    same light-vertex cache on both sides."""
     W, H = 128, 72
     r = pkg.Renderer(scene, 0)
     o = ob.Oracle(scene)
@@ -95,6 +93,12 @@ def world(gpu, pkg, ob):
     o.build_sampler()
     r.lvc_import(lvc); r.build_sampler()
     return dict(scene=scene, r=r, o=o, tup=tup, lvc=lvc, W=W, H=H)
+
+
+@pytest.fixture(scope="module")
+def world(gpu, pkg, ob):
+    """Bedroom-class scene (40 k triangles, textured materials)."""
+    return build_world(pkg, ob, pkg.scenes.bedroom(target_tris=40000, tex_size=64))
 
 
 # ---------------------------------------------------------------------------------------------------------------- a7
@@ -298,7 +302,9 @@ def _camera_records(pkg, ob, world, n, rng):
     return rec
 
 
-def _compare_steps(ob, g, o, level):
+def _compare_steps(ob, g, o, level, sharp_materials=()):
+    """sharp_materials: material ids whose GGX lobe is so narrow (roughness below the 0.001 clamp) that Eval / Pdf at each side's OWN
+    freshly sampled direction cannot be compared tightly; those records get the loose bar below."""
     g = g.view(ob.EYE_STEP_OUT_DTYPE).reshape(-1)
     n = len(o)
     same_kind = g["kind"] == o["kind"]
@@ -319,8 +325,12 @@ def _compare_steps(ob, g, o, level):
     same_rr = a["done"] == b["done"]           # r within rounding of rr: one side multiplies NextVertex.singlePdf by rr, the other ends the path
     # Eval / Pdf at the freshly sampled direction (each side at its own): 5e-4 for >= 99.8 % (measured 99.9 % within 2.8e-4); no hard
     # limit -- on the 0.05-roughness metal the GGX peak turns the 1e-7 difference of the two directions into percents (test_bsdf_*)
-    check(f"level {level} NextVertex.flux", a["next_flux"], b["next_flux"], 5e-4, 0.998)
-    check(f"level {level} NextVertex.singlePdf", a["next_single_pdf"][same_rr], b["next_single_pdf"][same_rr], 5e-4, 0.998)
+    sharp = np.isin(b["mid"]["material_id"], list(sharp_materials))
+    check(f"level {level} NextVertex.flux", a["next_flux"][~sharp], b["next_flux"][~sharp], 5e-4, 0.998)
+    check(f"level {level} NextVertex.singlePdf", a["next_single_pdf"][same_rr & ~sharp], b["next_single_pdf"][same_rr & ~sharp], 5e-4, 0.998)
+    if sharp.any():   # alpha = 0.001: the lobe's value moves by percents over the 1e-7 between the two sampled directions
+        check(f"level {level} NextVertex.flux, alpha-clamped lobe", a["next_flux"][sharp], b["next_flux"][sharp], 5e-2, 0.98)
+        check(f"level {level} NextVertex.singlePdf, alpha-clamped lobe", a["next_single_pdf"][same_rr & sharp], b["next_single_pdf"][same_rr & sharp], 5e-2, 0.98)
     emit = same_kind & (o["kind"] == 2)
     if emit.any():
         check(f"level {level} emitter radiance", g["emit"][emit], o["emit"][emit], 1e-4, 0.998, hard=1e-3)   # measured max 6.6e-5
@@ -333,14 +343,18 @@ def test_eye_step_connection_and_emitter_hit_chain(world, pkg, ob):
     """Three levels of the eye walk, every level started from the ORACLE's previous output on both sides: vertex build with the RMIS
     recursion (a8), classification (a12), emitter hits with rmis::light_hit at depth >= 2 (a10) -- then connectVertex_SPCBPT and
     the RMIS connection weights (a15, a16) of those vertices against real light vertices, b.depth == 0 and > 0."""
+    run_chain(world, pkg, ob)
+
+
+def run_chain(world, pkg, ob, sharp_materials=(), seed=8):
     r, o, lvc = world["r"], world["o"], world["lvc"]
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(seed)
     rec = _camera_records(pkg, ob, world, 16384, rng)
     eye_vertices, emit_total = [], 0
     for level in range(1, 5):
         want = o.eye_step(rec)
         got = r.unit(OP["EYE_STEP"], rec.view(np.uint32).reshape(len(rec), -1), 40)
-        n_surf, n_emit = _compare_steps(ob, got, want, level)
+        n_surf, n_emit = _compare_steps(ob, got, want, level, sharp_materials)
         emit_total += n_emit if level > 1 else 0
         go = (want["kind"] == 1) & (want["done"] == 0)
         eye_vertices.append(want["mid"][want["kind"] == 1].copy())
@@ -368,3 +382,4 @@ def test_eye_step_connection_and_emitter_hit_chain(world, pkg, ob):
         check(name + " RMIS weight", out[sel, 3], w_o[sel], 2e-6, 0.999, hard=1e-4)     # measured: bit-exact for 90 %, max 5.0e-7 (round 2, with FMA fusion: 99.93 % within 5e-5)
         check(name + " value", out[sel, :3], rgb_o[sel], 2e-6, 0.999, hard=1e-4)
     assert ((out[:, :3] == 0).all(1) == (rgb_o == 0).all(1)).mean() >= 0.999          # the exact zeros (back-facing pairs, rejected values)
+    return dict(eye=ev, light=lv, rgb=rgb_o, w=w_o)

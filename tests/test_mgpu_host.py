@@ -193,9 +193,12 @@ def test_rccl_batched_exchange_at_world_size_one(gpu, pkg):
 
 
 @pytest.mark.gpu
-def test_an_uncalibrated_shard_capacity_beyond_the_cache_is_refused(gpu, pkg):
-    """The caches are sized from a probe pass (spcbpt_lvc_set_capacity), the default shard capacity is a rank's padded scratch:
-    an exchange that would send more than a cache holds is an error that names the remedy, not an out-of-bounds read."""
+def test_an_uncalibrated_shard_capacity_beyond_the_cache_is_staged_not_refused(gpu, pkg):
+    """The caches are sized per rank from each rank's own probe pass (spcbpt_lvc_set_capacity) while the default shard capacity is
+    the largest padded scratch of any rank: without spcbpt_comm_calibrate a shard of shard_cap slots is more than a cache holds.
+    That used to be refused -- per rank, BEFORE the collective, so one rank could refuse and leave the others in the all-gather.
+    Now such a cache is staged through the communicator's send buffer: every rank always posts, nothing is read out of bounds,
+    and the gathered cache is the single-GPU cache."""
     scene = pkg.scenes.cornell_box()
     ranks = []
     for k in range(2):
@@ -203,14 +206,23 @@ def test_an_uncalibrated_shard_capacity_beyond_the_cache_is_refused(gpu, pkg):
         b, c = pkg.dist.core_range(3000, k, 2)
         r.set_light_trace(3000, 400, 1, core_begin=b, core_count=c)
         ranks.append(r)
-    ranks[0].set_subspace(); ranks[1].set_subspace(*ranks[0].get_subspace())
+    single = _make(pkg, scene, 1, (3000, 400, 1))
+    single.set_subspace()
+    for r in ranks:
+        r.set_subspace(*single.get_subspace())
     comms = pkg.dist.Comm.local(ranks)
     for r in ranks:
         r.launch("light trace", 1)
     v, _ = ranks[0].lvc_capacity()
-    assert 0 < v < 600000
-    with pytest.raises(pkg.SpcbptError, match="calibrate"):
-        comms[0].exchange_lvc()
+    assert 0 < v < 600000 and comms[0].shard_capacity == 600000
+    for c in comms:
+        c.exchange_lvc()
+    single.launch("light trace", 1); single.build_sampler()
+    want = single.sampler_read()
+    for r in ranks:
+        r.build_sampler()
+        sub, cmfs, jump, vc, pc = r.sampler_read()
+        assert (vc, pc) == (want[3], want[4]) and np.array_equal(jump, want[2]) and np.array_equal(cmfs, want[1])
     for c in comms:
         c.close()
 

@@ -16,6 +16,7 @@ def _tri_set(scene):
 @pytest.mark.parametrize("name,kw", [("cornell_box", {}), ("bedroom", {"target_tris": 3000, "tex_size": 16})])
 def test_scene_round_trip(hip_lib, pkg, tmp_path, name, kw):
     scene = getattr(pkg.scenes, name)(**kw)
+    scene.materials[1]["brdf"] = 1     # `brdf <int>` (sceneLoader.cpp:107) travels with the material
     path = pkg.scenes.write_scene(scene, str(tmp_path), name)
     loaded, warn = pkg.load_scene_file(path, str(tmp_path))
     assert warn == "", warn
@@ -26,6 +27,7 @@ def test_scene_round_trip(hip_lib, pkg, tmp_path, name, kw):
         np.testing.assert_allclose(a["color"], b["color"], rtol=1e-6)
         assert abs(a["roughness"] - b["roughness"]) < 1e-6 and abs(a["metallic"] - b["metallic"]) < 1e-6
         assert (a["albedo_tex"] > 0) == (b.get("albedo_tex", 0) > 0)
+        assert a["brdf"] == b.get("brdf", 0)
     for a, b in zip(loaded.lights, scene.lights):
         for k in ("position", "u", "v", "emission"):
             np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-6)
@@ -62,7 +64,7 @@ def test_grammar_quirks(hip_lib, pkg, tmp_path):
     d.mkdir()
     (d / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nf 1/1 2/1 3/1 4/1\nf -4//1 -3//1 -2//1\n")
     (tmp_path / "q.scene").write_text(
-        "#material Commented\n#{\n# color 9 9 9\n#}\nmaterial A\n{\n   color 0.1 0.2 0.3\n   roughness 0.25\n   albedoTex q/none.jpg\n}\n"
+        "#material Commented\n#{\n# color 9 9 9\n#}\nmaterial A\n{\n   color 0.1 0.2 0.3\n   roughness 0.25\n   albedoTex q/none.jpg\n   brdf 0x2\n}\n"
         "mesh\n{\n    file q\\m.obj\n    material A\n}\n"
         "light\n{\n  position 0 0 0\n  type Sphere\n  radius 1\n}\n"
         "light\n{\n  position 0 2 0\n  v1 1 2 0\n  v2 0 2 1\n  emission 5 5 5\n divLevel 3\n  type Quad\n")
@@ -70,6 +72,7 @@ def test_grammar_quirks(hip_lib, pkg, tmp_path):
     # quad fan (2 triangles, 4 v/vt vertices) + a triangle with negative indices and no vt (3 more distinct v/vt pairs)
     assert s.indices.shape[0] == 3 and s.vertices.shape[0] == 7
     assert len(s.materials) == 1 and abs(s.materials[0]["roughness"] - 0.25) < 1e-7 and s.materials[0]["albedo_tex"] == 0
+    assert s.materials[0]["brdf"] == 2                 # `%i` reads 0x2; any nonzero value is `true` in MaterialData::Pbr (scene_shift.cpp:75)
     assert len(s.lights) == 1 and s.lights[0]["div_level"] == 3 and tuple(s.lights[0]["u"]) == (1.0, 0.0, 0.0)
     assert "Sphere" in warn and "none.jpg" in warn
 
@@ -84,8 +87,29 @@ def test_reference_house_scene_parses(hip_lib, pkg):
     np.testing.assert_allclose(s.camera["eye"], (-0.813158, 5.627658, -7.363544), rtol=1e-6)
     assert abs(s.camera["fov"] - 60) < 1e-6
     assert len(s.materials) >= 25 and s.indices.shape[0] > 50000     # 30 meshes, ~67 k faces present
+    # material `Glass` (house_uvrefine2.scene:129-136: roughness 0, `brdf 1`) is the one flagged material of the shipped file, and
+    # the only mesh block that names it is commented out there (lines 306-310).  Materials reach the renderer per mesh block
+    # (scene_shift.cpp:235), so as shipped no flagged material is live; test_house_glass_block_reaches_the_renderer un-comments it.
+    assert not any(m["brdf"] for m in s.materials)
     assert "could not be read" in warn                                 # three referenced OBJs were stripped from the checkout
     assert ".jpg" in warn or ".png" in warn                           # stb_image formats are not decoded here
+
+
+@pytest.mark.skipif(not os.path.exists(HOUSE), reason="reference data not present")
+def test_house_glass_block_reaches_the_renderer(hip_lib, pkg, tmp_path):
+    """The shipped scene's `material Glass` block verbatim (roughness 0, `brdf 1`) on a mesh that names it -- the commented-out
+    block of house_uvrefine2.scene:306-310 restored: the flag arrives in spcbpt_material::brdf (sceneLoader.cpp:107 ->
+    scene_shift.cpp:75 `mtl.pbr.brdf = p.brdf`)."""
+    lines = open(HOUSE, "rb").read().decode("latin-1").splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("material Glass"))
+    end = next(i for i in range(start, len(lines)) if "}" in lines[i])
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "g.scene").write_text("\n".join(lines[start:end + 1]) + "\nmesh\n{\n    file m.obj\n    material Glass\n}\n")
+    s, warn = pkg.load_scene_file(str(tmp_path / "g.scene"), str(tmp_path))
+    assert warn == "", warn
+    (m,) = s.materials
+    assert m["brdf"] == 1 and m["roughness"] == 0.0 and m["metallic"] == 0.0
+    np.testing.assert_allclose(m["color"], (0.8, 0.8, 0.8), rtol=1e-6)
 
 
 # ---- pins against the reference's own vendored loaders (oracle/_ref; vectors in tests/golden/ref_loaders.npz) ------------

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on ONE box (boxes differ by a few percent): bench.py with the library in the tree (B) and with .ab/libA.so (A), alternating.
 # usage (on the GPU box): bash tools/ab_bench.sh [bench args]
+mkdir -p gpurun_out
 for k in 1 2; do
   for v in A B; do
     if [ $v = A ]; then export SPCBPT_LIB=$PWD/.ab/libA.so; else unset SPCBPT_LIB; fi

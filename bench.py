@@ -524,6 +524,8 @@ def main():
         # HBM-side traffic comes from rocprofv3 PMC passes (tools/profile_round.sh -> tools/pmc_summary.py), which cannot run inside
         # this process; the committed summary is quoted only if it profiled THIS code (hash of csrc/) in THIS launch form
         traffic = traffic_low = valu_issue = None
+        unit_fracs = {}
+        pmc_kernel_ms = None
         traffic_note = "no PMC summary for this code and launch form (profiles/traffic_latest.json)"
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile) and world == 1 and ex is None and comm is None and args.light_geometry == "lane" and args.tuple == "trained":
@@ -535,11 +537,29 @@ def main():
                     traffic = t.get("spcbpt_render_hbm_bytes_per_launch") * per
                     traffic_low = t.get("spcbpt_render_hbm_bytes_per_launch_low") * per
                     valu_issue = t.get("valu_issue_frac")
+                    unit_fracs = t.get("unit_fractions") or {}
+                    pmc_kernel_ms = (t.get("hbm_measured_frac") or {}).get("kernel_ms")
                     traffic_note = ("rocprofv3 PMC passes of this kernel code (" + str(t.get("tag")) + f", {t.get('frames_per_launch')} frames per launch, scaled to the {batch} of this run): "
                                     "traffic = 2*FETCH_SIZE + WRITE_SIZE (upper bracket, gfx950 half-count correction for 128-B requests), traffic_low = FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are included in both")
             except Exception:
                 pass
         achieved_actual = bytes_actual_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # Which unit is nearest saturation (round 4): the memory-side byte counters over THIS run's kernel time, and
+        # the unit-busy counters of the PMC passes (tools/pmc_summary.py: unit_fractions; VALU issue priced at the 2.55 cycles per
+        # wave-instruction measured by tools/micro/valu_issue.hip at this kernel's 4 waves per SIMD).  No unit is saturated: the
+        # vector L1 path (TA busy, one 64-B tag lookup per cycle per CU) is nearest, VALU issue next, HBM well below both.
+        hbm_measured = None
+        if traffic is not None and k_ms > 0:
+            hbm_measured = {"low": round(traffic_low / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "high": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        units = {k: round(unit_fracs[k], 4) for k in ("ta_busy_frac", "tcp_tag_lookups_per_cu_cycle", "valu_issue_frac", "tcp_pending_stall_frac", "l1_read_miss_rate",
+                                                       "valu_lane_utilisation", "wave_wait_frac", "wave_active_frac") if k in unit_fracs}
+        if hbm_measured: units["hbm_measured_frac_high"] = hbm_measured["high"]
+        saturating = {k: v for k, v in units.items() if k in ("ta_busy_frac", "tcp_tag_lookups_per_cu_cycle", "valu_issue_frac", "hbm_measured_frac_high")}
+        nearest = max(saturating, key=saturating.get) if saturating else None
+        # bytes no implementation of the path can avoid fetching: per event the LESSER of the reference's order and the order executed
+        # (the executed order reads 66 CMF values per first stage where the bisection probes 10, and 1 tree descent per vertex where
+        # the reference re-descends per connection: neither order is the lesser on every event)
+        bytes_min_per_launch = pkg.algorithmic_bytes({k: min(c_eye[k], c_ref[k]) for k in c_eye}) * batch
         out = {
             "metric": "Mpaths/sec (whole node), SPCBPT, 1920x1080",
             "value": round(value, 3), "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -556,9 +576,16 @@ def main():
                                    f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
                        "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "parallelism": "1 GPU" if world == 1 and comm is None else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu: ' + comm_transport + ' transport, ' + str(comm_world) + ' ranks seen by the communicator' if comm is not None else 'torch.distributed harness (--exchange python)'}" + (f", shard capacity {comm.shard_capacity} vertices, {'one exchange per light batch' if xbatch else 'one exchange per frame'}" if comm is not None else "") + ")",
                        "host": "single context" if dist is None else ("libspcbpt_mgpu" if comm is not None else "torch.distributed harness"), "rccl_ranks": comm_world if comm is not None else (world if dist is not None else 0)},
-            "roofline": {"bound": "hbm", "kernel": "k_spcbpt (spcbpt_render megakernel)",
+            "roofline": {"bound": "latency" if nearest else "hbm",
+                         "bound_note": ("contract roofline = algorithmic HBM bytes / kernel time / 8 TB/s (frac); the kernel is NOT HBM-bound: "
+                                        "hbm_measured_frac is the memory-side counters over the same kernel time, unit_busy the direct counters -- "
+                                        f"nearest saturation: {nearest} = {saturating[nearest]}" if nearest else
+                                        "contract roofline; no PMC summary for this code (profiles/traffic_latest.json), so the nearest unit is not stated"),
+                         "kernel": "k_spcbpt (spcbpt_render megakernel)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "hbm_measured_frac": hbm_measured, "unit_busy": units,
+                         "frac_min_events": round(bytes_min_per_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else 0.0,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "kernel_ms": round(k_ms, 4), "launches": k_n,
                          "events": "as executed by the timed kernel (labels cached per vertex, counting first stage) x the record sizes of SURVEY 8(d)",
                          # the contract as the survey wrote it: the reference algorithm's own event order (its relabels and bisections)

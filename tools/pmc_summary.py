@@ -35,6 +35,49 @@ for k, d in summary.items():
         d["l2_hit_rate"] = h / (h + m)
     if "SQ_WAVE_CYCLES" in d and "SQ_WAIT_ANY" in d:
         d["wait_any_frac"] = d["SQ_WAIT_ANY"]["avg_per_launch"] / d["SQ_WAVE_CYCLES"]["avg_per_launch"]
+# ---- which unit is nearest saturation (round 4: direct counters; tools/profile_round.sh passes sq2, sq3, ta*, tcp*, td) --------------
+# Units: SQ_BUSY_CU_CYCLES = busy cycles summed over the 256 CUs (= 256 x kernel cycles for a kernel that fills the chip; checked against
+# GRBM_GUI_ACTIVE / 8); SQ_ACTIVE_INST_* are quad-cycles of WAVE time (4 cycles per VALU instruction whatever the SIMD could overlap: it
+# is rocprof's VALUBusy, not an issue-port occupancy); TA / TCP / TD *_sum are cycles summed over the per-CU instances.
+# VALU issue: what one wave64 VALU instruction costs a SIMD was MEASURED (tools/micro/valu_issue.hip, profiles/r04_valu_issue.txt):
+# 5.5 cycles for a wave alone, 2.75 per wave-instruction at 2 waves per SIMD, 2.53-2.60 at 4 (k_spcbpt's occupancy), ~2.2 at 8 -- neither
+# the guide's 2 nor the 4 that rounds 1-3 charged; transcendentals (v_rcp_f32 ...) ~10, independent of EXEC.
+VALU_CYCLES_PER_INSTR = 2.55
+def frac_block(d):
+    g = lambda k: d[k]["avg_per_launch"] if k in d else None
+    cu = g("SQ_BUSY_CU_CYCLES")
+    if cu is None and g("SQ_BUSY_CYCLES") is not None: cu = g("SQ_BUSY_CYCLES") * 8.0   # 32 SE counters x 8 CUs each
+    if cu is None: return None
+    out = {"cu_cycles": cu}
+    if g("SQ_INSTS_VALU") is not None:
+        out["valu_issue_frac"] = g("SQ_INSTS_VALU") * VALU_CYCLES_PER_INSTR / (4.0 * cu)
+        out["valu_issue_frac_at_2_cycles_guide"] = g("SQ_INSTS_VALU") * 2.0 / (4.0 * cu)
+        out["valu_issue_frac_at_4_cycles_rounds_1_to_3"] = g("SQ_INSTS_VALU") * 4.0 / (4.0 * cu)
+    if g("SQ_ACTIVE_INST_VALU") is not None:
+        out["valu_busy_rocprof_definition"] = g("SQ_ACTIVE_INST_VALU") * 4.0 / (4.0 * cu)
+        if g("SQ_THREAD_CYCLES_VALU") is not None and g("SQ_ACTIVE_INST_VALU"): out["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0)
+    if g("SQ_INSTS_SALU") is not None and g("SQ_INSTS_VALU"): out["salu_per_valu_instruction"] = g("SQ_INSTS_SALU") / g("SQ_INSTS_VALU")
+    if g("TA_TA_BUSY_sum") is not None: out["ta_busy_frac"] = g("TA_TA_BUSY_sum") / cu
+    if g("TD_TD_BUSY_sum") is not None: out["td_busy_frac"] = g("TD_TD_BUSY_sum") / cu
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        out["tcp_tag_lookups_per_cu_cycle"] = g("TCP_TOTAL_CACHE_ACCESSES_sum") / cu   # the vector L1 looks up one 64-B line per cycle at most
+        if g("SQ_INSTS_VMEM") is not None: out["tcp_tag_lookups_per_vmem_instruction"] = g("TCP_TOTAL_CACHE_ACCESSES_sum") / g("SQ_INSTS_VMEM")
+        if g("TCP_TCC_READ_REQ_sum") is not None: out["l1_read_miss_rate"] = g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+    if g("TCP_PENDING_STALL_CYCLES_sum") is not None: out["tcp_pending_stall_frac"] = g("TCP_PENDING_STALL_CYCLES_sum") / cu
+    if g("TA_ADDR_STALLED_BY_TC_CYCLES_sum") is not None: out["ta_addr_stalled_by_tc_frac"] = g("TA_ADDR_STALLED_BY_TC_CYCLES_sum") / cu
+    if g("TA_DATA_STALLED_BY_TC_CYCLES_sum") is not None: out["ta_data_stalled_by_tc_frac"] = g("TA_DATA_STALLED_BY_TC_CYCLES_sum") / cu
+    if g("SQ_LDS_IDX_ACTIVE"):
+        out["lds_active_frac"] = g("SQ_LDS_IDX_ACTIVE") / cu
+        if g("SQ_LDS_BANK_CONFLICT") is not None: out["lds_bank_conflict_share_of_lds_cycles"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
+        out["wave_wait_frac"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+        if g("SQ_WAIT_INST_ANY") is not None: out["wave_issue_stall_frac"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+        if g("SQ_ACTIVE_INST_ANY") is not None: out["wave_active_frac"] = g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")
+    return out
+for k, d in summary.items():
+    fb = frac_block(d)
+    if fb: d["unit_fractions"] = fb
+
 notes = ("FETCH_SIZE / WRITE_SIZE are in KB per launch, collected in separate --pmc passes (TCC slot limits). "
          "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a wide coalesced 16-B/lane stream and is "
          "uncalibrated for other patterns; this kernel issues scattered 16-B/lane gathers, so hbm bytes are reported as a "
@@ -51,13 +94,23 @@ if key in summary and "FETCH_SIZE" in summary[key] and "WRITE_SIZE" in summary[k
     out["spcbpt_render_hbm_bytes_per_launch_high"] = 2 * f + w
     import __graft_entry__ as g
     d = summary[key]
-    valu = None
-    if "SQ_INSTS_VALU" in d and "SQ_BUSY_CYCLES" in d:
-        # wave-instructions x 4 cycles (one wave's issue cost, MI355X_MICROARCH.md) over the cycles of all 1024 SIMDs
-        # (SQ_BUSY_CYCLES is summed over the 32 shader engines: x 32 SIMDs per engine)
-        valu = d["SQ_INSTS_VALU"]["avg_per_launch"] * 4.0 / (d["SQ_BUSY_CYCLES"]["avg_per_launch"] * 32.0)
+    uf = d.get("unit_fractions", {})
+    valu = uf.get("valu_issue_frac")
+    # kernel duration of the same launch form from the --stats pass: measured HBM-side bytes / duration / 8 TB/s
+    kernel_ns = None
+    if stats:
+        for r in csv.DictReader(open(stats[-1])):
+            if r.get("Name", "").replace("void ", "").startswith(key): kernel_ns = float(r["AverageNs"])
+    hbm = None
+    if kernel_ns:
+        hbm = {"kernel_ms": kernel_ns * 1e-6, "low": (f + w) / (kernel_ns * 1e-9) / 8e12, "high": (2 * f + w) / (kernel_ns * 1e-9) / 8e12}
+        out["spcbpt_render_hbm_measured_frac"] = hbm
+    nearest = {k: uf[k] for k in ("valu_issue_frac", "ta_busy_frac", "tcp_tag_lookups_per_cu_cycle") if k in uf}
+    if hbm: nearest["hbm_measured_frac_high"] = hbm["high"]
+    out["spcbpt_render_unit_fractions"] = nearest
     json.dump({"tag": tag, "kernel": key, "frames_per_launch": frames_per_launch, "spcbpt_render_hbm_bytes_per_launch": 2 * f + w,
                "spcbpt_render_hbm_bytes_per_launch_low": f + w, "source_hash": g.load_package().api.source_hash(), "kernel_hash": g.load_package().api.kernel_hash(), "valu_issue_frac": valu,
+               "valu_cycles_per_instruction": VALU_CYCLES_PER_INSTR, "unit_fractions": uf, "hbm_measured_frac": hbm,
                "definition": "2*FETCH_SIZE + WRITE_SIZE (KB*1024) per k_spcbpt<false> launch, gfx950 FETCH_SIZE half-count correction applied; "
                              "uncorrected lower bound = FETCH_SIZE + WRITE_SIZE = %.4g" % (f + w)},
               open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)

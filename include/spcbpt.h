@@ -397,6 +397,16 @@ enum spcbpt_unit_op { SPCBPT_UNIT_BSDF = 0, SPCBPT_UNIT_TREE = 1, SPCBPT_UNIT_ST
                       SPCBPT_UNIT_UNIFORM = 5, SPCBPT_UNIT_CONNECT = 6, SPCBPT_UNIT_EYE_STEP = 7 };
 int spcbpt_debug_unit(spcbpt_ctx* ctx, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n,
                       const float* aux, int aux_floats);
+
+/* Developer A/B of two traversal schedules on the SAME rays (round 4, csrc/quad_trace.hip): mode 0 = one lane per ray (the loop
+ * of the render kernels), mode 1 = four lanes per ray (one coalesced 64-B node fetch per visit, one child box / one leaf
+ * triangle per lane), modes 2 / 3 = the same with 2 / 4 rays per quad in flight; all persistent and pool-fed.  rays: n x {origin3, tmin, direction3, tmax}; any != 0: terminate on first hit
+ * (visibilityTest semantics, out_visible) else nearest hit with emitter culling (out_t / out_tri / out_uv; the unused outputs may be
+ * NULL).  The launch is repeated `repeat` times on device-resident rays; *avg_ms is the HIP-event mean of one launch.  stats (may be
+ * NULL): [0] node visits, [1] leaf visits, [2] triangle tests, [3] lane slots (64 x wave iterations), [4] lanes holding a ray in them,
+ * from one more, counting launch.  Mode 1 needs 3 x BVH depth <= 64, modes 2 / 3 <= 48 (their per-ray LDS stacks). */
+int spcbpt_debug_trace_bench(spcbpt_ctx* ctx, const float* rays, int n, int mode, int any, int repeat, float* out_t, int32_t* out_tri,
+                             float* out_uv, int32_t* out_visible, double* avg_ms, uint64_t stats[5]);
 /* Event counting in the kernels (off for timed runs).  1: the counting instantiations evaluate in the REFERENCE's order and charge
  * its events (two relabels per connection and one per RMIS update, a ten-probe bisection per first sampling stage): the contract's
  * byte table of SURVEY.md 8(d).  2: the instantiations the timed runs use, with counters -- the events that really execute (labels

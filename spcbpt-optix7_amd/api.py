@@ -503,6 +503,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_debug_phase_clocks": [vp, C.POINTER(C.c_uint64)],
         "spcbpt_set_connection_sampler": [vp, i32],
         "spcbpt_debug_unit": [vp, i32, vp, i32, vp, i32, i32, vp, i32],
+        "spcbpt_debug_trace_bench": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
         "spcbpt_debug_spill_arm": [vp],
         "spcbpt_debug_spill_count": [vp, C.POINTER(C.c_uint64), C.POINTER(i32)],
         "spcbpt_enable_counters": [vp, i32],
@@ -573,7 +574,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_launch_light_batch", "spcbpt_build_sampler",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
-    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit",
+    "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_debug_trace_bench",
     "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
@@ -892,6 +893,26 @@ class Renderer:
         vis = np.zeros(n, dtype=np.int32)
         self._chk(self.lib.spcbpt_trace_any(self.h, r.ctypes.data, n, vis.ctypes.data), "trace_any")
         return vis
+
+    def trace_bench(self, rays: np.ndarray, mode: int, any_hit: bool, repeat: int = 5, stats: bool = True):
+        """spcbpt_debug_trace_bench: the same rays through the lane-per-ray (mode 0) or quad-per-ray (mode 1) pool-fed kernels.
+        Returns (outputs, avg_ms, stats dict or None); outputs = visibility, or (t, tri, uv)."""
+        r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = r.shape[0]
+        ms = C.c_double(0.0)
+        st = (C.c_uint64 * 5)()
+        if any_hit:
+            vis = np.zeros(n, dtype=np.int32)
+            self._chk(self.lib.spcbpt_debug_trace_bench(self.h, r.ctypes.data, n, int(mode), 1, int(repeat), None, None, None, vis.ctypes.data,
+                                                        C.byref(ms), st if stats else None), "debug_trace_bench")
+            out = vis
+        else:
+            t = np.zeros(n, dtype=np.float32); tri = np.zeros(n, dtype=np.int32); uv = np.zeros((n, 2), dtype=np.float32)
+            self._chk(self.lib.spcbpt_debug_trace_bench(self.h, r.ctypes.data, n, int(mode), 0, int(repeat), t.ctypes.data, tri.ctypes.data, uv.ctypes.data, None,
+                                                        C.byref(ms), st if stats else None), "debug_trace_bench")
+            out = (t, tri, uv)
+        sd = dict(zip(("node_visits", "leaf_visits", "tri_tests", "lane_slots", "lanes_busy"), [int(x) for x in st])) if stats else None
+        return out, float(ms.value), sd
 
     # -- the reference's per-frame sequence (optixPathTracer.cpp:791-822) ------
     def render_frame(self, alg: str, subframe: int, launch_frame: Optional[int] = None, rows=None):

@@ -939,7 +939,7 @@ int Context::install_minimal_tuple() {
 Context::~Context() {
     resolve_spans();
     free_preprocess();
-    dev_free(d_nodes); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
+    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
     dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
@@ -1612,6 +1612,64 @@ int spcbpt_set_connection_sampler(spcbpt_ctx* c, int mode) {
     if (c->sync_all()) return SPCBPT_ERR_HIP;
     c->kp.uniform_lvc = mode;
     return SPCBPT_OK;
+}
+
+int spcbpt_debug_trace_bench(spcbpt_ctx* c, const float* rays, int n, int mode, int any, int repeat, float* out_t, int32_t* out_tri, float* out_uv,
+                             int32_t* out_visible, double* avg_ms, uint64_t stats[5]) {
+    CTX_CHECK(c);
+    if (!rays || n < 1 || mode < 0 || mode > 3 || repeat < 1 || (any && !out_visible) || (!any && (!out_t || !out_tri || !out_uv))) { c->error = "debug_trace_bench: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
+    if (mode >= 1 && 3 * c->bvh_depth > (mode == 1 ? 64 : 48)) { c->error = "debug_trace_bench: the quad kernel's per-ray LDS stack holds " + std::to_string(mode == 1 ? 64 : 48) + " entries (3 x BVH depth " + std::to_string(c->bvh_depth) + " needed)"; return SPCBPT_ERR_CAPACITY; }
+    float* d_rays = nullptr; float* d_t = nullptr; int* d_tri = nullptr; float* d_uv = nullptr; int* d_vis = nullptr;
+    uint32_t* d_counter = nullptr; unsigned long long* d_stats = nullptr;
+    int rc = trace_common(c, rays, n, &d_rays);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        dev_free(d_rays); dev_free(d_t); dev_free(d_tri); dev_free(d_uv); dev_free(d_vis); dev_free(d_counter); dev_free(d_stats);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+    if (rc) { cleanup(); return rc; }
+    if (mode >= 1 && !c->d_nodes_q) {   // the quad layout of the same nodes, built once
+        e = dev_alloc(&c->d_nodes_q, (size_t)c->n_nodes * 16);
+        if (e == hipSuccess) { launch_repack_nodes_quad(c->d_nodes, c->d_nodes_q, c->n_nodes, c->stream); e = hipGetLastError(); }
+    }
+    const int per_cu = trace_bench_blocks_per_cu(mode, any != 0);
+    const int rays_per_block = mode == 0 ? 256 : 64 << (mode - 1);
+    const int blocks = std::max(1, std::min(c->num_cus * per_cu, (n + rays_per_block - 1) / rays_per_block));
+    if (e == hipSuccess && mode == 0) { rc = c->ensure_spill((size_t)blocks * 256); if (rc) { cleanup(); return rc; } }
+    if (e == hipSuccess) e = dev_alloc(&d_counter, (size_t)1);
+    if (e == hipSuccess) e = dev_alloc(&d_stats, (size_t)5);
+    if (e == hipSuccess && !any) { e = dev_alloc(&d_t, (size_t)n); if (e == hipSuccess) e = dev_alloc(&d_tri, (size_t)n); if (e == hipSuccess) e = dev_alloc(&d_uv, (size_t)n * 2); }
+    if (e == hipSuccess && any) e = dev_alloc(&d_vis, (size_t)n);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double total_ms = 0.0;
+    for (int k = 0; k <= repeat && e == hipSuccess; k++) {   // launch 0 warms up
+        e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) { launch_trace_bench(c->kp, mode, any != 0, false, c->d_nodes_q, d_rays, n, d_counter, d_t, d_tri, d_uv, d_vis, d_stats, blocks, c->stream); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (k > 0) total_ms += ms;
+    }
+    if (e == hipSuccess && stats) {
+        e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_stats, 0, 5 * sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) { launch_trace_bench(c->kp, mode, any != 0, true, c->d_nodes_q, d_rays, n, d_counter, d_t, d_tri, d_uv, d_vis, d_stats, blocks, c->stream); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(stats, d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    }
+    const int dg = e == hipSuccess ? c->check_diag() : 0;
+    if (e == hipSuccess && !any) { e = hipMemcpy(out_t, d_t, (size_t)n * 4, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemcpy(out_tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost);
+                                   if (e == hipSuccess) e = hipMemcpy(out_uv, d_uv, (size_t)n * 8, hipMemcpyDeviceToHost); }
+    if (e == hipSuccess && any) e = hipMemcpy(out_visible, d_vis, (size_t)n * 4, hipMemcpyDeviceToHost);
+    if (avg_ms) *avg_ms = total_ms / repeat;
+    cleanup();
+    if (e != hipSuccess) { c->error = std::string("debug_trace_bench: ") + hipGetErrorString(e); return SPCBPT_ERR_HIP; }
+    return dg;
 }
 
 int spcbpt_debug_unit(spcbpt_ctx* c, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n, const float* aux, int aux_floats) {

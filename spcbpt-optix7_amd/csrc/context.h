@@ -107,6 +107,7 @@ struct Context {
     KParams kp;
     // scene
     float* d_nodes = nullptr;
+    float* d_nodes_q = nullptr;            // the same nodes in the quad-lane layout (quad_trace.hip), built on first use
     float* d_tris = nullptr;
     int32_t* d_tri_orig = nullptr;
     DMaterial* d_mats = nullptr;

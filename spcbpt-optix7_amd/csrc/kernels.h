@@ -44,6 +44,12 @@ void launch_trace_any(const KParams& p, const float* rays, int n, int* vis, hipS
 // "SPCBPT_no_rmis": the full-path-MIS variant (full_mis.hip)
 void launch_spcbpt_no_rmis(const KParams& p, hipStream_t s);
 
+// traversal schedule A/B (quad_trace.hip): mode 0 lane per ray, 1 quad per ray; persistent, pool-fed
+void launch_repack_nodes_quad(const float* nodes, float* out, int n_nodes, hipStream_t s);
+int trace_bench_blocks_per_cu(int mode, bool any);
+void launch_trace_bench(const KParams& p, int mode, bool any, bool stats, const float* nodes_q, const float* rays, int n, uint32_t* counter, float* t, int* tri,
+                        float* uv, int* vis, unsigned long long* stat_out, int blocks, hipStream_t s);
+
 // per-function harness (unit.hip)
 void launch_unit(const KParams& p, int op, const uint32_t* in, int in_words, uint32_t* out, int out_words, int n, const float* aux, hipStream_t s);
 

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(QBLOCK) void k_trace_lane(const KParams p, const Qu
                     o = mk3(ra.x, ra.y, ra.z); d = mk3(rb.x, rb.y, rb.z);
                     tmin = ra.w; best_t = rb.w;
                     inv = safe_inv(d); ood = o * inv;
-                    node = 0; st.sp = 0; leaf_count = 0; best_tri = -1;
+                    node = 0; st.sp = 0; leaf_count = 0; best_tri = -1; best_u = best_v = 0.0f;
                 }
             }
         }

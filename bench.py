@@ -474,6 +474,7 @@ def main():
             ms_long = float(t.item())
     ms_sync_each = None
     ms_sync_each_ahead = None
+    ms_viewer = None
     if args.sync_each_frames > 0 and ex is None:
         # optixPathTracer.cpp:791-822: launchLVCTrace (light pass + LVC_Process) then launchSubframe, a device sync after each
         # (513, 634) -- one frame in flight, nothing batched, nothing ahead
@@ -510,6 +511,17 @@ def main():
                 r.sync()
             ms_sync_each_ahead = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
             r.set_light_ahead(False)
+            # the interactive loop as the library's viewer runs it by default (csrc/viewer.cpp, pipeline 2): every call shows one
+            # complete frame -- the reference loop's frame, bit for bit (tests/test_viewer.py) -- and the next one is traced meanwhile
+            v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width, args.height)
+            for f in range(args.sync_each_frames + 3):
+                if f == 3:
+                    t1 = time.perf_counter()
+                v.frame()
+            ms_viewer = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
+            v.set_pipeline(0)   # drops what was traced ahead
+            r.sync()
+            v.close()
 
     eye_paths = args.width * args.height
     total_paths = (eye_paths + M) * args.steps
@@ -567,8 +579,10 @@ def main():
             "ms_per_step_long": None if ms_long is None else round(ms_long, 3),
             "ms_per_frame_sync_each": None if ms_sync_each is None else round(ms_sync_each, 3),
             "ms_per_frame_sync_each_light_ahead": None if ms_sync_each_ahead is None else round(ms_sync_each_ahead, 3),
+            "ms_per_frame_viewer": None if ms_viewer is None else round(ms_viewer, 3),
             "notes": {"ms_per_step_long": f"the same loop over {args.long_steps} more steps (steady state; value / ms_per_step are the contract's {args.steps} steps)",
-                      "ms_per_frame_sync_each": "the reference's loop form (optixPathTracer.cpp:791-822): one light pass, one sampler build, one eye launch and a device sync per frame"},
+                      "ms_per_frame_sync_each": "the reference's loop form (optixPathTracer.cpp:791-822): one light pass, one sampler build, one eye launch and a device sync per frame",
+                      "ms_per_frame_viewer": "spcbpt_viewer_frame in its default mode: one complete, displayable frame per call (the same frames as the reference's loop), the next frame traced while this one is shown"},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "

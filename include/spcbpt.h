@@ -421,6 +421,17 @@ int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 int spcbpt_stream(spcbpt_ctx* ctx, void** stream);
 int spcbpt_sync(spcbpt_ctx* ctx);
 int spcbpt_sync_light(spcbpt_ctx* ctx);
+/* A frame ahead in the interactive loop (no reference counterpart; optixPathTracer.cpp:791-822 renders and displays strictly in
+ * turn).  spcbpt_launch_deferred is spcbpt_launch("pt" | "SPCBPT_eye", ...) WITHOUT the film merge: the kernel renders into a buffer
+ * of its own, accum / frame are untouched.  spcbpt_merge_deferred(ctx, 1) queues that merge -- from then on the frame is exactly
+ * what spcbpt_launch would have produced -- and (ctx, 0) drops the frame (the camera moved: its samples belong to no image).  One
+ * frame may be outstanding; every other render launch is refused until it is merged or dropped (spcbpt_resize drops it).
+ * spcbpt_sync_film makes the host wait for the LAST QUEUED film merge only: the frame to display is complete, work queued behind it
+ * (the next frame's light pass, sampler build, deferred eye launch) keeps running.  csrc/viewer.cpp builds its default loop on
+ * these: frame f+1 is traced while frame f is shown, and every displayed frame is the reference loop's frame. */
+int spcbpt_launch_deferred(spcbpt_ctx* ctx, const char* alg, uint32_t subframe_index, int row_begin, int row_end, int row_step);
+int spcbpt_merge_deferred(spcbpt_ctx* ctx, int keep);
+int spcbpt_sync_film(spcbpt_ctx* ctx);
 /* Batched eye launch (no reference counterpart): renders the samplers of the last n_frames spcbpt_build_sampler calls -- one
  * frame each, oldest first, subframe index subframes[k] -- with ONE persistent kernel whose tile queue spans the frames, and
  * merges them into the film in that order.  The result is that of n_frames spcbpt_launch("SPCBPT_eye") calls; the point is the
@@ -578,10 +589,18 @@ int spcbpt_viewer_window_size(spcbpt_viewer* v, int width, int height);
 int spcbpt_viewer_iconify(spcbpt_viewer* v, int iconified);
 int spcbpt_viewer_key(spcbpt_viewer* v, int key, int action);
 int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps);
-/* Opt-in (the reference has no such mode): with "SPCBPT_eye" the loop launches the NEXT frame's light pass right after this
- * frame's eye launch, before the sync, so that it runs beside the eye kernel instead of in front of the next one (light sub-paths
- * do not depend on the camera).  Same launch frames, same caches, same images -- one frame takes the eye launch's time instead of
- * light pass + build + eye launch.  Sets spcbpt_set_light_ahead on the context. */
+/* How far the loop runs ahead of what it shows (the reference has no such modes; every mode shows the SAME frames -- same launch
+ * frames, same caches, same images, tests/test_viewer.py):
+ *   0  the reference's order: light pass, sampler build, eye launch, device sync, strictly in turn (optixPathTracer.cpp:791-822);
+ *   1  with "SPCBPT_eye" the NEXT frame's light pass is launched right after this frame's eye launch, before the sync, so that it
+ *      runs beside the eye kernel (light sub-paths do not depend on the camera);
+ *   2  (default) the next frame is traced while this one is shown: its sampler build and its eye launch WITHOUT the film merge
+ *      (spcbpt_launch_deferred) are queued before spcbpt_viewer_frame returns, which waits for the shown frame's merge only
+ *      (spcbpt_sync_film).  The next call merges that frame if nothing it depends on has changed since -- camera, size, algorithm,
+ *      subframe restart -- and drops it otherwise; light pass and sampler are kept either way, so the k-th "SPCBPT_eye" frame
+ *      always uses the k-th light pass.  A call after an event costs what mode 1 costs; a steady view costs the eye kernel.
+ * Modes 1 and 2 set spcbpt_set_light_ahead on the context.  spcbpt_viewer_set_light_ahead(v, on) = set_pipeline(v, on ? 1 : 0). */
+int spcbpt_viewer_set_pipeline(spcbpt_viewer* v, int mode);
 int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on);
 int spcbpt_viewer_frame(spcbpt_viewer* v);
 int spcbpt_viewer_get_state(spcbpt_viewer* v, spcbpt_viewer_state* state);

@@ -352,6 +352,10 @@ class Viewer:
     def set_light_ahead(self, on):
         self._chk(self.lib.spcbpt_viewer_set_light_ahead(self.h, int(on)), "viewer_set_light_ahead")
 
+    def set_pipeline(self, mode: int):
+        """0 the reference's order, 1 next light pass beside the eye kernel, 2 (default) next frame traced while this one is shown."""
+        self._chk(self.lib.spcbpt_viewer_set_pipeline(self.h, int(mode)), "viewer_set_pipeline")
+
     def frame(self):
         self._chk(self.lib.spcbpt_viewer_frame(self.h), "viewer_frame")
 
@@ -508,7 +512,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_debug_spill_count": [vp, C.POINTER(C.c_uint64), C.POINTER(i32)],
         "spcbpt_enable_counters": [vp, i32],
         "spcbpt_stream": [vp, C.POINTER(vp)],
-        "spcbpt_sync": [vp],
+        "spcbpt_sync": [vp], "spcbpt_sync_film": [vp], "spcbpt_merge_deferred": [vp, i32], "spcbpt_launch_deferred": [vp, C.c_char_p, u32, i32, i32, i32],
         "spcbpt_sync_light": [vp],
         "spcbpt_set_light_ahead": [vp, i32],
         "spcbpt_lvc_import_wait": [vp],
@@ -536,7 +540,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_viewer_iconify": [vp, i32],
         "spcbpt_viewer_key": [vp, i32, i32],
         "spcbpt_viewer_set_fps": [vp, C.c_float],
-        "spcbpt_viewer_set_light_ahead": [vp, i32],
+        "spcbpt_viewer_set_light_ahead": [vp, i32], "spcbpt_viewer_set_pipeline": [vp, i32],
         "spcbpt_viewer_frame": [vp],
         "spcbpt_viewer_get_state": [vp, C.POINTER(ViewerState)],
         "spcbpt_image_load": [C.c_char_p, C.POINTER(i32), C.POINTER(i32), vp, C.c_size_t],
@@ -575,14 +579,14 @@ EXPORTED_SYMBOLS = [
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_debug_trace_bench",
-    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
     "spcbpt_get_gamma", "spcbpt_gltf_load", "spcbpt_scene_file_load", "spcbpt_scene_file_desc", "spcbpt_scene_file_camera",
     "spcbpt_scene_file_warnings", "spcbpt_scene_file_environment", "spcbpt_scene_file_free",
     "spcbpt_viewer_create", "spcbpt_viewer_destroy", "spcbpt_viewer_mouse_button", "spcbpt_viewer_cursor_pos", "spcbpt_viewer_scroll",
-    "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_set_light_ahead", "spcbpt_viewer_frame",
+    "spcbpt_viewer_window_size", "spcbpt_viewer_iconify", "spcbpt_viewer_key", "spcbpt_viewer_set_fps", "spcbpt_viewer_set_light_ahead", "spcbpt_viewer_set_pipeline", "spcbpt_viewer_frame",
     "spcbpt_viewer_get_state", "spcbpt_viewer_alg_name",
     "spcbpt_image_load", "spcbpt_checkpoint_write", "spcbpt_checkpoint_read", "spcbpt_gamma_to_cmf", "spcbpt_checkpoint_save", "spcbpt_checkpoint_load",
 ]
@@ -687,6 +691,16 @@ class Renderer:
     def sync(self):
         self._chk(self.lib.spcbpt_sync(self.h), "sync")
 
+    def launch_deferred(self, alg: str, subframe: int, rows=None):
+        r0, r1, rs = rows if rows is not None else (0, self.height, 1)
+        self._chk(self.lib.spcbpt_launch_deferred(self.h, alg.encode(), int(subframe), r0, r1, rs), "launch_deferred")
+
+    def merge_deferred(self, keep: bool):
+        self._chk(self.lib.spcbpt_merge_deferred(self.h, 1 if keep else 0), "merge_deferred")
+
+    def sync_film(self):
+        self._chk(self.lib.spcbpt_sync_film(self.h), "sync_film")
+
     def preprocess(self, target_paths=2_000_000, target_q_paths=2_000_000, train=True):
         self._chk(self.lib.spcbpt_preprocess(self.h, target_paths, target_q_paths, int(train)), "preprocess")
 
@@ -728,12 +742,21 @@ class Renderer:
         return g
 
     # -- readback -----------------------------------------------------------
+    def image_size(self):
+        """(width, height) as the library holds them (the viewer resizes the context itself)."""
+        w, h = C.c_int32(), C.c_int32()
+        self._chk(self.lib.spcbpt_image_size(self.h, C.byref(w), C.byref(h)), "image_size")
+        self.width, self.height = int(w.value), int(h.value)
+        return self.width, self.height
+
     def read_accum(self):
+        self.image_size()
         out = np.zeros((self.height, self.width, 4), dtype=np.float32)
         self._chk(self.lib.spcbpt_read_accum(self.h, out.ctypes.data), "read_accum")
         return out
 
     def read_frame(self):
+        self.image_size()
         out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
         self._chk(self.lib.spcbpt_read_frame(self.h, out.ctypes.data), "read_frame")
         return out

@@ -741,7 +741,9 @@ int Context::export_batch_on(hipStream_t xs, int nf, void* send, int* send_count
     return 0;
 }
 
-int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis) {
+int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis, bool defer_merge) {
+    if (deferred.active) { error = "a deferred frame is outstanding: spcbpt_merge_deferred(ctx, keep) first"; return SPCBPT_ERR_STATE; }
+    if (defer_merge && (full_mis || counting)) { error = "launch_deferred: plain \"pt\" / \"SPCBPT_eye\" launches only"; return SPCBPT_ERR_INVALID_ARG; }
     if (!d_accum) { error = "render before spcbpt_resize"; return SPCBPT_ERR_STATE; }
     if (!have_camera) { error = "render before spcbpt_set_camera"; return SPCBPT_ERR_STATE; }
     if (spcbpt_alg && (!have_sampler || !have_subspace)) { error = "SPCBPT_eye needs a subspace tuple and a built sampler"; return SPCBPT_ERR_STATE; }
@@ -808,7 +810,31 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
         ev_render_set[eset] = true;
     }
+    if (defer_merge) {
+        deferred.active = true; deferred.rk = rk; deferred.subframe = kp.subframe; deferred.result = kp.result;
+        deferred.row_begin = kp.row_begin; deferred.row_end = kp.row_end; deferred.row_step = kp.row_step;
+        return 0;
+    }
     return finish_frame();
+}
+
+// The film merge of the deferred frame, now (keep) or never.  Dropping costs nothing but the kernel time already spent: the
+// render kernel wrote its own `result` buffer only.
+int Context::merge_deferred(bool keep) {
+    if (!deferred.active) { error = "merge_deferred: no deferred frame"; return SPCBPT_ERR_STATE; }
+    deferred.active = false;
+    if (!keep) return 0;
+    rk = deferred.rk;
+    rstream = rstreams[rk];
+    kp.subframe = deferred.subframe; kp.result = deferred.result;
+    kp.row_begin = deferred.row_begin; kp.row_end = deferred.row_end; kp.row_step = deferred.row_step;
+    return finish_frame();
+}
+// Host wait for the last film merge only (the frame to be displayed), not for work queued behind it (the next frame's light
+// pass, sampler build and speculative eye launch).
+int Context::sync_film() {
+    if (last_merge_k >= 0 && ev_merge_set[last_merge_k]) HIP_TRY(this, hipEventSynchronize(ev_merge[last_merge_k]));
+    return check_diag();
 }
 
 int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, int rs) {
@@ -1210,6 +1236,7 @@ int spcbpt_resize(spcbpt_ctx* c, int w, int h) {
     CTX_CHECK(c);
     if (w < 1 || h < 1 || (long long)w * h > (1ll << 28)) { c->error = "bad image size"; return SPCBPT_ERR_INVALID_ARG; }
     if (c->sync_all()) return SPCBPT_ERR_HIP;
+    c->deferred.active = false;   // a deferred frame of the old size is dropped with its buffer
     dev_free(c->d_accum); dev_free(c->d_frame);
     HIP_TRY(c, dev_alloc(&c->d_accum, (size_t)w * h * 4));
     HIP_TRY(c, dev_alloc(&c->d_frame, (size_t)w * h));
@@ -1281,6 +1308,18 @@ int spcbpt_launch(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r
     c->error = "unknown algorithm '" + alg + "' (expected \"pt\", \"light trace\", \"SPCBPT_eye\", \"pretrace\" or \"SPCBPT_no_rmis\")";
     return SPCBPT_ERR_UNKNOWN_ALG;
 }
+
+int spcbpt_launch_deferred(spcbpt_ctx* c, const char* name, uint32_t frame, int r0, int r1, int rs) {
+    CTX_CHECK(c);
+    if (!name) { c->error = "null algorithm name"; return SPCBPT_ERR_INVALID_ARG; }
+    const std::string alg(name);
+    if (alg == "SPCBPT_eye") return c->launch_render("spcbpt_render", true, frame, r0, r1, rs, false, true);
+    if (alg == "pt") return c->launch_render("pt", false, frame, r0, r1, rs, false, true);
+    c->error = "launch_deferred: \"pt\" or \"SPCBPT_eye\"";
+    return SPCBPT_ERR_UNKNOWN_ALG;
+}
+int spcbpt_merge_deferred(spcbpt_ctx* c, int keep) { CTX_CHECK(c); return c->merge_deferred(keep != 0); }
+int spcbpt_sync_film(spcbpt_ctx* c) { CTX_CHECK(c); return c->sync_film(); }
 
 int spcbpt_launch_eye_batch(spcbpt_ctx* c, int n_frames, const uint32_t* subframes, int r0, int r1, int rs) {
     CTX_CHECK(c);

@@ -206,7 +206,12 @@ struct Context {
     int fetch_counts();           // counts of the latest light pass's set (lset) -> lvc_count, path_count
     int fetch_counts_of(int set);
     int build_sampler();
-    int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis = false);
+    int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis = false, bool defer_merge = false);
+    // spcbpt_launch_deferred: a render launch whose film merge (running mean + tone map from its `result` buffer) has not been queued:
+    // the frame is either merged later (merge_deferred(true)) or never (false) -- the interactive loop's speculative next frame
+    struct Deferred { bool active = false; int rk = 0; uint32_t subframe = 0; int row_begin = 0, row_end = 0, row_step = 1; float* result = nullptr; } deferred;
+    int merge_deferred(bool keep);
+    int sync_film();
     // Batched eye launch (spcbpt_launch_eye_batch): the last n built samplers, one per frame, rendered by ONE persistent kernel
     // whose tile queue spans the frames (kernels.hip: BATCH).  A rank's share of a sharded frame is a few thousand tiles --
     // about one per resident wave, i.e. all drain phase; four frames in one queue regenerate like one frame four times the size.

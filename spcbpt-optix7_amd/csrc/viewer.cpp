@@ -122,8 +122,20 @@ struct spcbpt_viewer {
     uint32_t subframe_index = 0, lt_launch_frame = 0;
     double cursor_x = 0, cursor_y = 0;  // what glfwGetCursorPos returns inside mouseButtonCallback
     bool fixed_fps = false;
-    bool light_ahead = false, light_pending = false;   // spcbpt_viewer_set_light_ahead: the next frame's light pass is already in flight
-    long long frames = 0;
+    // How far the loop runs ahead of what it shows (spcbpt_viewer_set_pipeline; every mode displays the same frames):
+    //   0  the reference's order: light pass, sampler build, eye launch, device sync -- strictly in turn (optixPathTracer.cpp:791-822)
+    //   1  the NEXT frame's light pass is launched beside this frame's eye kernel
+    //   2  (default) ... and the next frame is traced speculatively while this one is shown: its sampler build and eye launch are
+    //      queued before this call returns (spcbpt_launch_deferred); the next call merges it if nothing it depends on changed
+    //      (camera, size, algorithm, subframe restart) and drops it otherwise -- the light pass and the sampler are kept either
+    //      way, they do not depend on the camera, so the k-th "SPCBPT_eye" frame always uses the k-th light pass.
+    int pipeline = 2;
+    bool light_pending = false;       // a light pass has been launched whose sampler is not built yet
+    bool sampler_ready = false;       // the sampler of the NEXT frame to show is built (its light pass consumed)
+    bool spec_in_flight = false;      // a deferred eye / pt launch is outstanding ...
+    int spec_alg = -1;                // ... of this algorithm
+    uint32_t spec_subframe = 0;       // ... and subframe index
+    long long frames = 0, spec_hits = 0, spec_drops = 0;
 };
 
 extern "C" {
@@ -145,6 +157,10 @@ int spcbpt_viewer_create(spcbpt_ctx* ctx, const float eye[3], const float lookat
     v->trackball.moveSpeed = 10.0f;
     v->trackball.setReferenceFrame(mk(1.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), mk(0.0f, 1.0f, 0.0f));
     v->trackball.gimbalLock = true;
+    if (ctx) {   // the default loop runs a frame ahead (pipeline 2): light passes may then be launched before their sampler is built
+        const int rc = spcbpt_set_light_ahead(ctx, 1);
+        if (rc) { delete v; return rc; }
+    }
     *out = v;
     return SPCBPT_OK;
 }
@@ -248,20 +264,29 @@ int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps) {
     return SPCBPT_OK;
 }
 
-int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on) {
-    if (!v) return SPCBPT_ERR_INVALID_ARG;
-    if (v->ctx) { const int rc = spcbpt_set_light_ahead(v->ctx, on != 0); if (rc) return rc; }   // (drops a pass launched ahead)
-    v->light_ahead = on != 0;
-    v->light_pending = false;
+int spcbpt_viewer_set_pipeline(spcbpt_viewer* v, int mode) {
+    if (!v || mode < 0 || mode > 2) return SPCBPT_ERR_INVALID_ARG;
+    if (v->ctx) {
+        if (v->spec_in_flight) { const int rc = spcbpt_merge_deferred(v->ctx, 0); if (rc) return rc; }
+        const int rc = spcbpt_set_light_ahead(v->ctx, mode != 0);   // (drops a pass launched ahead)
+        if (rc) return rc;
+    }
+    // what was launched ahead is gone; the light-pass counter is wound back over it, so that the k-th frame keeps the k-th pass
+    if (v->light_pending) v->lt_launch_frame--;
+    if (v->sampler_ready) v->lt_launch_frame--;
+    v->pipeline = mode;
+    v->light_pending = v->sampler_ready = v->spec_in_flight = false;
     return SPCBPT_OK;
 }
+int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on) { return spcbpt_viewer_set_pipeline(v, on ? 1 : 0); }   // (the round-3 name)
 
 // One pass of the render loop (791-822): updateState -> [SPCBPT_eye: launchLVCTrace] -> launchSubframe -> ++subframe_index.
 int spcbpt_viewer_frame(spcbpt_viewer* v) {
     if (!v) return SPCBPT_ERR_INVALID_ARG;
     const auto t0 = std::chrono::steady_clock::now();
     // updateState (372-379)
-    if (v->camera_changed || v->resize_dirty || v->one_frame_render_only) v->subframe_index = 0;
+    const bool state_changed = v->camera_changed || v->resize_dirty || v->one_frame_render_only;   // what a frame traced ahead did not know
+    if (state_changed) v->subframe_index = 0;
     int rc = SPCBPT_OK;
     if (v->camera_changed) {  // handleCameraUpdate (352-370)
         v->camera_changed = false;
@@ -277,21 +302,56 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
         if (rc) return rc;
     }
     if (v->ctx) {
-        if (v->render_alg_id == 1) {  // launchLVCTrace (515-522)
-            if (!v->light_pending) rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);   // (else: launched ahead by the previous frame)
+        const bool spcbpt = v->render_alg_id == 1;
+        // ---- the frame to show: the speculative one if it is still this frame, else render it now
+        bool have = false;
+        if (v->spec_in_flight) {
+            have = !state_changed && v->spec_alg == v->render_alg_id && v->spec_subframe == v->subframe_index;
+            rc = spcbpt_merge_deferred(v->ctx, have ? 1 : 0);
             if (rc) return rc;
-            v->light_pending = false;
-            rc = spcbpt_build_sampler(v->ctx);
+            v->spec_in_flight = false;
+            if (have) v->spec_hits++; else v->spec_drops++;
+        }
+        if (!have) {
+            if (spcbpt && !v->sampler_ready) {  // launchLVCTrace (515-522)
+                if (!v->light_pending) rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);   // (else: launched ahead by the previous frame)
+                if (rc) return rc;
+                v->light_pending = false;
+                rc = spcbpt_build_sampler(v->ctx);
+                if (rc) return rc;
+            }
+            rc = spcbpt_launch(v->ctx, kAlgs[v->render_alg_id], v->subframe_index, 0, v->height, 1);  // launchSubframe (609-635)
             if (rc) return rc;
         }
-        rc = spcbpt_launch(v->ctx, kAlgs[v->render_alg_id], v->subframe_index, 0, v->height, 1);  // launchSubframe (609-635)
-        if (rc) return rc;
-        if (v->light_ahead && v->render_alg_id == 1) {   // the next frame's light pass, beside this frame's eye kernel
+        if (spcbpt) v->sampler_ready = false;   // consumed by the frame being shown
+        // ---- ahead of the display
+        if (v->pipeline == 1 && spcbpt && !v->light_pending) {   // the next frame's light pass, beside this frame's eye kernel
             rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);
             if (rc) return rc;
             v->light_pending = true;
         }
-        rc = spcbpt_sync(v->ctx);  // CUDA_SYNC_CHECK: the interactive loop shows every subframe
+        if (v->pipeline == 2 && !v->one_frame_render_only) {
+            // frame f + 1, assuming that nothing changes: sampler build (its light pass was launched a call ago and ran beside the
+            // eye kernel of f), eye launch without the film merge, and the light pass of f + 2 beside it
+            if (spcbpt) {
+                if (!v->light_pending) { rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1); if (rc) return rc; }
+                v->light_pending = false;
+                rc = spcbpt_build_sampler(v->ctx);
+                if (rc) return rc;
+                v->sampler_ready = true;
+            }
+            rc = spcbpt_launch_deferred(v->ctx, kAlgs[v->render_alg_id], v->subframe_index + 1, 0, v->height, 1);
+            if (rc) return rc;
+            v->spec_in_flight = true; v->spec_alg = v->render_alg_id; v->spec_subframe = v->subframe_index + 1;
+            if (spcbpt) {
+                rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);
+                if (rc) return rc;
+                v->light_pending = true;
+            }
+            rc = spcbpt_sync_film(v->ctx);   // the frame to show is complete; what was queued behind it keeps running
+        } else {
+            rc = spcbpt_sync(v->ctx);  // CUDA_SYNC_CHECK: the interactive loop shows every subframe
+        }
         if (rc) return rc;
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -1,0 +1,87 @@
+"""Guard of the code generation the measured numbers depend on.
+
+csrc/Makefile builds the kernels with LLVM-internal switches (-fno-slp-vectorize, -ffp-contract=off, -mllvm -enable-pre=false
+-enable-load-pre=false -disable-machine-licm) that are worth ~20 % of the eye megakernel.  Nothing in the test suite noticed if a
+ROCm update changed what they do -- the images would stay right and the bench would quietly lose.  This test reads the gfx950 code
+object the library actually carries (llvm-objdump --offloading on a copy, llvm-readelf --notes, llvm-objdump -d) and pins, for the
+timed instantiations of k_spcbpt, the resources that decide occupancy and the two symptoms the switches exist to prevent:
+  * 128 VGPRs (4 waves per SIMD) and <= 40 960 B of LDS (4 blocks per CU) -- the occupancy the launch sizes its persistent grid for;
+  * private segment (scratch) <= 160 B per lane -- spills are the kernel's writes to HBM (profiles/r03_experiments.md); SLP
+    vectorisation or loop-invariant hoisting in the traversal loop pushed it to 264-384 B;
+  * packed-float instructions: only the 12 hand-written v_pk_fma_f32 of the slab test -- the SLP vectoriser made 6 900 of them;
+  * instruction count of the kernel within 10 % of what was profiled.
+Needs no GPU (hipcc cross-compiles; the tools ship with ROCm)."""
+import collections
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+ARGS = "EEEvNS_7KParamsE"
+# <COUNT, BATCH, CACHE, ENV>: the timed forms (COUNT = false, CACHE = true)
+TIMED = {"single frame, plain scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS, "batched, plain scene (bench.py)": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS,
+         "single frame, general scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS, "batched, general scene": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS}
+PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 12182, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 11313,
+                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 14345, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 13501}
+
+
+@pytest.fixture(scope="module")
+def code_object(hip_lib, pkg, tmp_path_factory):
+    if not (os.path.exists(os.path.join(LLVM, "llvm-objdump")) and os.path.exists(os.path.join(LLVM, "llvm-readelf"))):
+        pytest.skip("ROCm's llvm-objdump / llvm-readelf not present")
+    d = tmp_path_factory.mktemp("co")
+    lib = shutil.copy(pkg.api.LIB_PATH, d)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+    meta, disasm = {}, {}
+    for f in sorted(os.listdir(d)):
+        if "amdgcn-amd-amdhsa--gfx950" not in f:
+            continue
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(d, f)], stdout=subprocess.PIPE, text=True, check=True).stdout
+        if "k_spcbpt" not in notes:
+            continue
+        for blk in notes.split("  - .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            meta[name] = {k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
+                          for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count")}
+        cur = None
+        n, pk = collections.Counter(), collections.Counter()
+        out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(d, f)], stdout=subprocess.PIPE, text=True, check=True).stdout
+        for line in out.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+            elif cur and re.match(r"^\s+[a-z_0-9]+", line):
+                n[cur] += 1
+                pk[cur] += "v_pk_" in line
+        disasm.update({k: dict(instructions=n[k], packed=pk[k]) for k in n})
+    assert meta, "no gfx950 code object with k_spcbpt found in the library"
+    return meta, disasm
+
+
+@pytest.mark.parametrize("form", list(TIMED))
+def test_timed_megakernel_resources(code_object, form):
+    meta, disasm = code_object
+    name = TIMED[form]
+    assert name in meta, (form, [k for k in meta if "k_spcbpt" in k])
+    m, d = meta[name], disasm[name]
+    report = dict(m, **d)
+    assert m["vgpr_count"] <= 128, report                          # 4 waves per SIMD (SPC_EYE_WAVES)
+    assert m["group_segment_fixed_size"] <= 40960, report           # 4 blocks per CU in 160 KB of LDS
+    assert m["private_segment_fixed_size"] <= 160, report           # scratch per lane: the kernel's HBM writes
+    assert d["packed"] <= 16, report                                # the slab test's 12 v_pk_fma_f32; SLP vectorisation made thousands
+    want = PROFILED_INSTRUCTIONS[name]
+    assert abs(d["instructions"] - want) <= 0.10 * want, report     # the code the profiles/ numbers were measured on
+
+
+def test_library_exports_only_the_c_abi(hip_lib, pkg):
+    """-fvisibility=hidden: the library's dynamic symbol table holds the spcbpt_* entry points (and the kernels' host stubs the HIP
+    runtime looks up by address, not by name) -- no mangled spc:: internals a second copy of the library, or a host with its own
+    `spc` namespace, could collide with."""
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.api.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    stray = [n for n in names if not n.startswith("spcbpt_") and not n.startswith("__hip_") and n not in ("_init", "_fini")]
+    assert not [n for n in stray if "spc" in n], stray[:10]
+    assert len([n for n in names if n.startswith("spcbpt_")]) >= len(pkg.api.EXPORTED_SYMBOLS)

@@ -127,30 +127,81 @@ def test_viewer_loop_renders_what_the_plain_loop_renders(gpu, pkg):
 
 
 @pytest.mark.gpu
-def test_viewer_light_ahead_renders_the_same_frames(gpu, pkg):
-    """spcbpt_viewer_set_light_ahead: the next frame's light pass is launched beside this frame's eye kernel -- same launch frames, same
-    caches, the same images bit for bit, also across a camera drag and an algorithm switch back and forth."""
+def test_viewer_pipeline_modes_render_the_same_frames(gpu, pkg):
+    """spcbpt_viewer_set_pipeline: 0 = the reference's order, 1 = the next frame's light pass beside this frame's eye kernel, 2 (the
+    default) = the next frame traced speculatively while this one is shown (deferred film merge; dropped when the camera, the size,
+    the algorithm or the subframe counter changed under it).  Same launch frames, same caches, the same images bit for bit after
+    EVERY call -- steady views, a camera drag, a scroll, the W key, an algorithm switch and back, a resize, the P key (every frame
+    restarts) and out of it again."""
     scene = pkg.scenes.cornell_box()
     cam = scene.camera
     W = H = 96
-    imgs = []
-    for ahead in (False, True):
+    runs, stats = [], []
+    for mode in (0, 1, 2):
         r = pkg.Renderer(scene, 0)
         r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
         r.resize(W, H)
         r.set_light_trace(3000, 64, 1)
         r.set_subspace()
         v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], W, H)
-        v.set_light_ahead(ahead)
+        v.set_fps(60.0)                                     # the W key's step divides by the frame rate: fixed, not measured
+        if mode != 2:
+            v.set_pipeline(mode)                            # 2 is what a new viewer does
         shots = []
-        for _ in range(3): v.frame()
-        shots.append(r.read_accum().copy())
+
+        def show(n=1):
+            for _ in range(n):
+                v.frame()
+                shots.append((v.state()["subframe_index"], v.state()["alg"], r.read_accum().copy(), r.read_frame().copy()))
+
+        show(4)
         v.mouse_button("left", 1, 40, 40); v.cursor_pos(60, 50); v.mouse_button("left", 0, 60, 50)
-        for _ in range(2): v.frame()
-        shots.append(r.read_accum().copy())
-        v.key("SPACE"); v.frame()                          # "pt": no light pass; one may still be pending from the frame before
-        shots.append(r.read_accum().copy())
+        show(3)
+        v.scroll(1); show(2)
+        v.key("W", 1); show(2)
+        v.key("SPACE"); show(3)                             # "pt": no light pass; one (and a built sampler) may be held from before
         assert v.state()["alg"] == "pt"
-        imgs.append(shots)
-    for a, b in zip(*imgs):
-        assert np.array_equal(a, b)
+        v.key("SPACE"); show(3)                             # back: the held sampler is the next light pass in sequence
+        v.window_size(80, 64); show(3)
+        v.key("P"); show(3)                                 # one_frame_render_only: subframe 0 every frame, nothing to speculate on
+        v.key("P"); show(3)
+        runs.append(shots)
+    for k, (a, b, c) in enumerate(zip(*runs)):
+        assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1], k
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[2], c[2]), k          # linear accumulation buffer
+        assert np.array_equal(a[3], b[3]) and np.array_equal(a[3], c[3]), k          # tone-mapped frame
+
+
+@pytest.mark.gpu
+def test_deferred_launch_is_the_plain_launch_once_merged(gpu, pkg):
+    """spcbpt_launch_deferred + spcbpt_merge_deferred(1) = spcbpt_launch; (0) leaves accum and frame untouched; a second render launch
+    while one is outstanding is refused; spcbpt_sync_film returns with the shown frame complete."""
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+
+    def make():
+        r = pkg.Renderer(scene, 0)
+        r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+        r.resize(64, 64)
+        r.set_light_trace(3000, 64, 1)
+        r.set_subspace()
+        return r
+
+    a, b = make(), make()
+    for f in range(3):
+        a.render_frame("SPCBPT_eye", f)
+        b.launch("light trace", f + 1); b.build_sampler()
+        b.launch_deferred("SPCBPT_eye", f)
+        with pytest.raises(pkg.SpcbptError, match="deferred"):
+            b.launch("pt", 0)
+        b.merge_deferred(True)
+        b.sync_film()
+    a.sync()
+    assert np.array_equal(a.read_accum(), b.read_accum())
+    before = b.read_accum().copy()
+    b.launch_deferred("pt", 3)
+    b.merge_deferred(False)
+    b.sync()
+    assert np.array_equal(before, b.read_accum())
+    with pytest.raises(pkg.SpcbptError, match="no deferred"):
+        b.merge_deferred(True)

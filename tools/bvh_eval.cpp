@@ -25,7 +25,7 @@ static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 static V3 norm(V3 a) { float l = std::sqrt(dot(a, a)); return a * (1.0f / l); }
 
-struct Stats { double nodes = 0, tris = 0, leaves = 0, rays = 0, hits = 0; };
+struct Stats { double nodes = 0, tris = 0, leaves = 0, rays = 0, hits = 0, leaves_exact = 0, tris_exact = 0; };   // *_exact: leaf visits / tests left if the leaf's child box were the exact bounds of its triangles
 
 static bool tri_hit(const float* q, V3 o, V3 d, float tmin, float tmax, float& t) {
     V3 v0{q[0], q[1], q[2]}, v1{q[4], q[5], q[6]}, v2{q[8], q[9], q[10]};
@@ -57,6 +57,15 @@ static bool traverse(const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any
             if (cur != 0x80000000u) {
                 const int first = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
                 st.leaves++;
+                {   // would the EXACT box of the leaf's triangles have been entered?  (upper bound of what tighter leaf boxes can save)
+                    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+                    for (int t = first; t < first + cnt; t++)
+                        for (int v = 0; v < 3; v++)
+                            for (int k = 0; k < 3; k++) { const float x = B.tris[(size_t)t * 16 + 4 * v + k]; lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x); }
+                    float t0 = tmin, t1 = best;
+                    for (int k = 0; k < 3; k++) { float a = (lo[k] - oo[k]) * inv[k], b = (hi[k] - oo[k]) * inv[k]; if (a > b) std::swap(a, b); t0 = std::max(t0, a); t1 = std::min(t1, b); }
+                    if (t0 <= t1 * 1.0000004f) { st.leaves_exact++; st.tris_exact += cnt; }
+                }
                 for (int t = first; t < first + cnt; t++) {
                     st.tris++;
                     float th;
@@ -150,7 +159,7 @@ int main(int argc, char** argv) {
         if (len > 1e-4f) traverse(B, P, dv * (1.0f / len), 1e-3f, len - 1e-3f, true, ss);
     }
     printf("nodes %zu  depth %d  build %.2f s\n", B.nodes.size() / 16, B.depth, build_s);
-    printf("closest: node visits %.2f  leaf visits %.2f  triangle tests %.2f  hit rate %.3f\n", sc.nodes / sc.rays, sc.leaves / sc.rays, sc.tris / sc.rays, sc.hits / sc.rays);
-    printf("shadow : node visits %.2f  leaf visits %.2f  triangle tests %.2f  occluded %.3f\n", ss.nodes / ss.rays, ss.leaves / ss.rays, ss.tris / ss.rays, ss.hits / ss.rays);
+    printf("closest: node visits %.2f  leaf visits %.2f  triangle tests %.2f  hit rate %.3f   with exact leaf boxes: leaf visits %.2f  tests <= %.2f\n", sc.nodes / sc.rays, sc.leaves / sc.rays, sc.tris / sc.rays, sc.hits / sc.rays, sc.leaves_exact / sc.rays, sc.tris_exact / sc.rays);
+    printf("shadow : node visits %.2f  leaf visits %.2f  triangle tests %.2f  occluded %.3f   with exact leaf boxes: leaf visits %.2f  tests <= %.2f\n", ss.nodes / ss.rays, ss.leaves / ss.rays, ss.tris / ss.rays, ss.hits / ss.rays, ss.leaves_exact / ss.rays, ss.tris_exact / ss.rays);
     return 0;
 }

@@ -457,7 +457,10 @@ int Context::launch_light(uint32_t frame) {
     else if (keys_set == lset) keys_ready = false;   // the set was rewritten by the other lane: lane 0's keys no longer describe it
     lvc_count = -1;  // known on the device only until the next host read
     set_count_host[lset] = -1;
-    have_sampler = false;
+    // With passes running ahead (spcbpt_set_light_ahead) the sampler the eye launches read (set `eset`) stays valid while later
+    // passes fill OTHER sets of the ring -- an interactive loop that drops a speculative frame renders it again from that sampler
+    // (csrc/viewer.cpp); without, a new light pass means "build before you render", as in the reference's loop.
+    if (!light_ahead || eset == lset) have_sampler = false;
     // (vertex_count, path_count) to pinned host memory, inside the event: the sampler build reads them after waiting for
     // THIS pass only, not for whatever else has been queued on the stream since
     HIP_TRY(this, hipMemcpyAsync(h_light_counts + 2 * lset, d_sampler_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, ls));

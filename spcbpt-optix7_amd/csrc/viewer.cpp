@@ -288,6 +288,12 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
     const bool state_changed = v->camera_changed || v->resize_dirty || v->one_frame_render_only;   // what a frame traced ahead did not know
     if (state_changed) v->subframe_index = 0;
     int rc = SPCBPT_OK;
+    // the frame traced ahead: still this frame, or overtaken by an event (dropped before the size or the camera change)
+    bool have = false;
+    if (v->spec_in_flight && v->ctx) {
+        have = !state_changed && v->spec_alg == v->render_alg_id && v->spec_subframe == v->subframe_index;
+        if (!have) { rc = spcbpt_merge_deferred(v->ctx, 0); if (rc) return rc; v->spec_in_flight = false; v->spec_drops++; }
+    }
     if (v->camera_changed) {  // handleCameraUpdate (352-370)
         v->camera_changed = false;
         v->camera.aspect = (float)v->width / (float)v->height;
@@ -304,13 +310,11 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
     if (v->ctx) {
         const bool spcbpt = v->render_alg_id == 1;
         // ---- the frame to show: the speculative one if it is still this frame, else render it now
-        bool have = false;
-        if (v->spec_in_flight) {
-            have = !state_changed && v->spec_alg == v->render_alg_id && v->spec_subframe == v->subframe_index;
-            rc = spcbpt_merge_deferred(v->ctx, have ? 1 : 0);
+        if (have) {
+            rc = spcbpt_merge_deferred(v->ctx, 1);
             if (rc) return rc;
             v->spec_in_flight = false;
-            if (have) v->spec_hits++; else v->spec_drops++;
+            v->spec_hits++;
         }
         if (!have) {
             if (spcbpt && !v->sampler_ready) {  // launchLVCTrace (515-522)

@@ -15,7 +15,10 @@
       calibrated shard capacity, one exchange per light batch, device-count sampler build, band gather -- device copies stand in
       for RCCL): the gathered film equals the film ONE context renders, bit for bit.  What stays the driver's is hardware N > 1.
 
-Tolerances are written next to each assertion.  (C1, C2 and the reduced C3 live in test_gpu_parity.py; the N-GPU host loop is
+  C5 at full size (78 k triangles, 1920 x 1080, tuple trained on 2 M paths): equal-time variance of the trained sampler against
+      plain BDPT and PT as assertions; C2 with the TRAINED tuple at 1024 x 1024 + oracle parity with that tuple (last two tests).
+
+Tolerances are written next to each assertion.  (C1, C2 with the minimal tuple and the reduced C3 live in test_gpu_parity.py; the N-GPU host loop is
 also covered by test_gpu_pipeline.py, test_distributed_cpu.py and tests/test_mgpu_host.py.)
 """
 import os
@@ -469,3 +472,74 @@ def test_f4_full_path_mis_variant_matches_oracle_and_agrees_with_rmis(gpu, pkg, 
     # (a few 1e-4 of the energy in this scene) and pdfCompute leaves the Russian-roulette rate unclamped -- tolerance 0.7 %
     assert abs(means["SPCBPT_no_rmis"] - means["SPCBPT_eye"]) / means["SPCBPT_eye"] < 7e-3, means
     assert abs(means["SPCBPT_no_rmis"] - means["pt"]) / means["pt"] < 7e-3, means
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def test_c5_full_size_hallway_equal_time_variance_against_plain_bdpt_and_pt(gpu, pkg, monkeypatch):
+    """BASELINE config 5 at its own terms: the full hallway / door-ajar scene (78 k triangles: scenes.hallway() at its default tessellation), 1920 x 1080, a 1000-subspace tuple
+    trained on 2 M paths, and the config's actual claim as assertions -- at EQUAL TIME the trained subspace sampler has less
+    variance than "plain BDPT" (uniformSample over the cache, cuProg.h:283-289; measured 5.6 x) and than PT + NEE (measured 23 x).
+    RMSE against a 512-spp reference that shares no sample with the images under test (tools/rmse_lib.py).  Also: every pixel of
+    every estimator written and finite, and the three estimators agree in the mean.
+    (What stays the driver's of this config: the 8 GPUs -- tests/test_gpu_configs.py::test_c5_eight_local_ranks_* covers the
+    partition on one.)"""
+    import sys
+    monkeypatch.setenv("SPCBPT_EYE_BATCH", "4")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from rmse_lib import rmse_study
+    scene = pkg.scenes.hallway()
+    assert len(scene.indices) > 70_000                                                       # the full hallway (hallway() at its default tessellation: 78 k triangles)
+    out = rmse_study(pkg, scene, 1920, 1080, 16, 2_000_000)
+    print("C5 full size:", {k: out[k] for k in ("rmse_pt", "rmse_spcbpt_trained", "rmse_plain_bdpt", "eye_subspaces", "light_subspaces", "ms_per_frame", "equal_time")})
+    assert all(out["every_pixel_written_and_finite"].values()), out["every_pixel_written_and_finite"]
+    assert out["eye_subspaces"] >= 500 and out["light_subspaces"] >= 300                   # a real 1000 / 800-centroid tuple (classTree_host.h)
+    # unbiasedness at 256 spp per reference: measured 0.4 % apart (heavy-tailed: PT sees the caustic paths by chance); bound 2.5 %
+    assert abs(out["mean_pt_ref"] - out["mean_spcbpt_ref"]) < 0.025 * out["mean_pt_ref"], (out["mean_pt_ref"], out["mean_spcbpt_ref"])
+    # 16-spp means of the bidirectional estimators against the 512-spp reference mean: a few per cent
+    ref_mean = 0.5 * (out["mean_pt_ref"] + out["mean_spcbpt_ref"])
+    for k in ("mean_spcbpt_trained", "mean_plain_bdpt"):
+        assert abs(out[k] - ref_mean) < 0.05 * ref_mean, (k, out[k], ref_mean)
+    eq = out["equal_time"]
+    assert eq["spp"]["plain_bdpt"] >= 16 and eq["spp"]["pt"] >= 16                          # the comparators get MORE samples in the same time
+    assert eq["variance_ratio_plain_bdpt_over_trained"] > 2.5, eq                           # measured 5.6 (profiles/r02_rmse_hallway.json)
+    assert eq["variance_ratio_pt_over_trained"] > 8.0, eq                                   # measured 23
+    assert out["rmse_spcbpt_trained"] <= out["rmse_spcbpt_minimal"] * 1.02                  # training does not hurt at equal spp
+
+
+def test_c2_cornell_1024_trained_tuple_properties_and_oracle_parity(gpu, pkg, ob):
+    """BASELINE config 2 "with the minimal valid subspace tuple AND with the trained Gamma" (SURVEY 8(d) C2): the trained half.
+    Cornell box 1024 x 1024, M = 100 000 light paths, a tuple trained on the device; 16 spp of "SPCBPT_eye": every pixel written
+    and finite, mean = PT's within 1 %, the running mean is the running mean (a frame rendered again on a converged buffer of
+    itself leaves it unchanged).  Then the SAME trained tuple on both sides at 128 x 128: image parity against the oracle."""
+    scene = pkg.scenes.cornell_box()
+    r = _renderer(pkg, scene, 1024, 1024, (100000, 52, 1))
+    r.set_pretrace(20000, 10)
+    r.preprocess(target_paths=400000, target_q_paths=400000, train=True)
+    tup = r.get_subspace()
+    et, lt, q, cmf = tup
+    assert len(set(et["label"][et["leaf"] == 1].tolist())) > 300 and len(set(lt["label"][lt["leaf"] == 1].tolist())) > 100
+    for f in range(16):
+        r.render_frame("SPCBPT_eye", f)
+    sp = r.read_accum()
+    assert (sp[..., 3] == 1.0).all() and np.isfinite(sp).all()
+    r.clear_accum()
+    for f in range(16):
+        r.launch("pt", f)
+    pt = r.read_accum()
+    assert (pt[..., 3] == 1.0).all() and np.isfinite(pt).all()
+    assert abs(sp[..., :3].mean() - pt[..., :3].mean()) / pt[..., :3].mean() < 0.01, (sp[..., :3].mean(), pt[..., :3].mean())
+    r.clear_accum()
+    r.render_frame("SPCBPT_eye", 0); a = r.read_accum().copy()
+    r.render_frame("SPCBPT_eye", 0); b = r.read_accum()                          # lerp(prev, cur, 1) with cur == prev's only sample
+    np.testing.assert_array_equal(a, b)
+    W = H = 128
+    r2 = _renderer(pkg, scene, W, H, (100000, 52, 1))
+    o = ob.Oracle(scene)
+    _setup(o, scene, W, H, (100000, 52, 1))
+    r2.set_subspace(*tup); o.set_subspace(*tup)
+    o.set_cmf_double(True)
+    for f in range(4):
+        r2.render_frame("SPCBPT_eye", f); o.render_frame("SPCBPT_eye", f)
+    s = image_parity(r2.read_accum()[..., :3], o.read_accum()[..., :3])
+    print("C2 trained tuple, 128 x 128:", s)
+    assert s["frac_close"] >= 0.995 and s["mean_rel"] < 5e-3 and tails_explained(s), s

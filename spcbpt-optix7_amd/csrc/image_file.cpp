@@ -502,55 +502,60 @@ struct JpegDecoder {
         return !bad;
     }
 
-    // 8x8 inverse DCT on dequantised coefficients: jidctint "islow" (13-bit constants), two extra bits after the column pass,
-    // level shift +128 and rounding folded into the row pass, results clamped to 0..255
+    // 8x8 inverse DCT on dequantised coefficients.  The decoded bytes must be the reference's (its vendored stb_image, itself the
+    // IJG "islow" integer transform), so the INTEGERS are fixed: the Loeffler-Ligtenberg-Moschytz factorisation with 12-bit
+    // constants, a column pass that keeps two extra bits (rounding 512, shift 10) and a row pass that folds the +128 level shift
+    // and the rounding into one bias (shift 17).  Integer sums are exact, so the formulation is free; this one writes the 1-D
+    // transform as an even half E[0..3] (inputs 0, 2, 4, 6) and an odd half O[0..3] (inputs 1, 3, 5, 7) with the outputs
+    // y[k] = E[k] + O[k], y[7 - k] = E[k] - O[k], each odd output as its own dot product over shared pair sums.
+    struct Lane8 { int even[4], odd[4]; };
+    static int fix12(double x) { return (int)(x * 4096 + 0.5); }
+    static Lane8 idct_1d(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7) {
+        // rotation constants: sqrt(2) cos(k pi / 16) combinations of the LLM flow graph
+        static const int r6 = fix12(0.5411961f), r2m6 = fix12(0.765366865f), r2p6 = fix12(-1.847759065f), r3 = fix12(1.175875602f);
+        static const int k7 = fix12(0.298631336f), k5 = fix12(2.053119869f), k3 = fix12(3.072711026f), k1 = fix12(1.501321110f);
+        static const int m17 = fix12(-0.899976223f), m35 = fix12(-2.562915447f), m37 = fix12(-1.961570560f), m15 = fix12(-0.390180644f);
+        Lane8 y;
+        // even half: a rotation of (x2, x6) around the butterfly of (x0, x4)
+        const int rot = (x2 + x6) * r6;
+        const int lo = rot + x2 * r2m6, hi = rot + x6 * r2p6;
+        const int sum = (x0 + x4) * 4096, dif = (x0 - x4) * 4096;
+        y.even[0] = sum + lo; y.even[3] = sum - lo;
+        y.even[1] = dif + hi; y.even[2] = dif - hi;
+        // odd half: pair sums shared between the four outputs
+        const int s17 = x1 + x7, s35 = x3 + x5, s37 = x3 + x7, s15 = x1 + x5;
+        const int all = (s37 + s15) * r3;
+        const int a17 = all + s17 * m17, a35 = all + s35 * m35, b37 = s37 * m37, b15 = s15 * m15;
+        y.odd[0] = x1 * k1 + a17 + b15;
+        y.odd[1] = x3 * k3 + a35 + b37;
+        y.odd[2] = x5 * k5 + a35 + b15;
+        y.odd[3] = x7 * k7 + a17 + b37;
+        return y;
+    }
     static void idct(const int16_t* d, uint8_t* out, int stride) {
-        auto f = [](double x) { return (int)(x * 4096 + 0.5); };
-        static const int c0 = f(0.5411961f), c1 = f(-1.847759065f), c2 = f(0.765366865f), c3 = f(1.175875602f), c4 = f(0.298631336f),
-                         c5 = f(2.053119869f), c6 = f(3.072711026f), c7 = f(1.501321110f), c8 = f(-0.899976223f), c9 = f(-2.562915447f),
-                         c10 = f(-1.961570560f), c11 = f(-0.390180644f);
-        int v[64];
-        auto pass = [&](int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int& x0, int& x1, int& x2, int& x3, int& t0, int& t1,
-                        int& t2, int& t3) {
-            int p1 = (s2 + s6) * c0;
-            const int e2 = p1 + s6 * c1, e3 = p1 + s2 * c2;
-            const int e0 = (s0 + s4) * 4096, e1 = (s0 - s4) * 4096;
-            x0 = e0 + e3; x3 = e0 - e3; x1 = e1 + e2; x2 = e1 - e2;
-            t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-            int p3 = t0 + t2, p4 = t1 + t3, p2 = t1 + t2;
-            p1 = t0 + t3;
-            const int p5 = (p3 + p4) * c3;
-            t0 *= c4; t1 *= c5; t2 *= c6; t3 *= c7;
-            p1 = p5 + p1 * c8; p2 = p5 + p2 * c9; p3 *= c10; p4 *= c11;
-            t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
-        };
-        for (int i = 0; i < 8; i++) {
-            const int16_t* s = d + i;
-            if (!s[8] && !s[16] && !s[24] && !s[32] && !s[40] && !s[48] && !s[56]) {
-                const int dc = s[0] * 4;
-                for (int k = 0; k < 8; k++) v[i + 8 * k] = dc;
+        int mid[64];   // after the column pass, scaled by 4
+        for (int col = 0; col < 8; col++) {
+            const int16_t* s = d + col;
+            if (!(s[8] | s[16] | s[24] | s[32] | s[40] | s[48] | s[56])) {   // a DC-only column is flat: (4096 dc + 512) >> 10 = 4 dc
+                for (int k = 0; k < 8; k++) mid[col + 8 * k] = s[0] * 4;
                 continue;
             }
-            int x0, x1, x2, x3, t0, t1, t2, t3;
-            pass(s[0], s[8], s[16], s[24], s[32], s[40], s[48], s[56], x0, x1, x2, x3, t0, t1, t2, t3);
-            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-            v[i] = (x0 + t3) >> 10; v[i + 56] = (x0 - t3) >> 10;
-            v[i + 8] = (x1 + t2) >> 10; v[i + 48] = (x1 - t2) >> 10;
-            v[i + 16] = (x2 + t1) >> 10; v[i + 40] = (x2 - t1) >> 10;
-            v[i + 24] = (x3 + t0) >> 10; v[i + 32] = (x3 - t0) >> 10;
+            const Lane8 y = idct_1d(s[0], s[8], s[16], s[24], s[32], s[40], s[48], s[56]);
+            for (int k = 0; k < 4; k++) {
+                mid[col + 8 * k] = (y.even[k] + y.odd[k] + 512) >> 10;
+                mid[col + 8 * (7 - k)] = (y.even[k] - y.odd[k] + 512) >> 10;
+            }
         }
-        auto clamp = [](int x) -> uint8_t { return (uint8_t)(x < 0 ? 0 : x > 255 ? 255 : x); };
-        for (int i = 0; i < 8; i++) {
-            const int* s = v + 8 * i;
-            uint8_t* o = out + (size_t)i * stride;
-            int x0, x1, x2, x3, t0, t1, t2, t3;
-            pass(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], x0, x1, x2, x3, t0, t1, t2, t3);
-            const int bias = 65536 + (128 << 17);
-            x0 += bias; x1 += bias; x2 += bias; x3 += bias;
-            o[0] = clamp((x0 + t3) >> 17); o[7] = clamp((x0 - t3) >> 17);
-            o[1] = clamp((x1 + t2) >> 17); o[6] = clamp((x1 - t2) >> 17);
-            o[2] = clamp((x2 + t1) >> 17); o[5] = clamp((x2 - t1) >> 17);
-            o[3] = clamp((x3 + t0) >> 17); o[4] = clamp((x3 - t0) >> 17);
+        const int bias = 65536 + (128 << 17);   // rounding of the final shift by 17 + the level shift, in one constant
+        for (int row = 0; row < 8; row++) {
+            const int* s = mid + 8 * row;
+            uint8_t* o = out + (size_t)row * stride;
+            const Lane8 y = idct_1d(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+            for (int k = 0; k < 4; k++) {
+                const int a = (y.even[k] + y.odd[k] + bias) >> 17, b = (y.even[k] - y.odd[k] + bias) >> 17;
+                o[k] = (uint8_t)(a < 0 ? 0 : a > 255 ? 255 : a);
+                o[7 - k] = (uint8_t)(b < 0 ? 0 : b > 255 ? 255 : b);
+            }
         }
     }
 

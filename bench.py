@@ -513,15 +513,27 @@ def main():
             r.set_light_ahead(False)
             # the interactive loop as the library's viewer runs it by default (csrc/viewer.cpp, pipeline 2): every call shows one
             # complete frame -- the reference loop's frame, bit for bit (tests/test_viewer.py) -- and the next one is traced meanwhile
-            v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width, args.height)
+            # ... on a context of its own, created the way an interactive host creates one (two render streams: the library's
+            # default; the bench context above runs ONE stream for its 32-frame launches) with the same tuple installed
+            os.environ["SPCBPT_RENDER_STREAMS"] = "2"; os.environ["SPCBPT_EYE_BATCH"] = "1"
+            try:
+                rv = pkg.Renderer(scene, local_rank)
+            finally:
+                os.environ["SPCBPT_RENDER_STREAMS"] = str(streams); os.environ["SPCBPT_EYE_BATCH"] = str(batch)
+            rv.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
+            rv.resize(args.width, args.height)
+            rv.set_light_trace(ncore, pad, mpc)
+            rv.set_subspace(*tup)
+            v = pkg.api.Viewer(rv, cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width, args.height)
             for f in range(args.sync_each_frames + 3):
                 if f == 3:
                     t1 = time.perf_counter()
                 v.frame()
             ms_viewer = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
             v.set_pipeline(0)   # drops what was traced ahead
-            r.sync()
+            rv.sync()
             v.close()
+            rv.close()
 
     eye_paths = args.width * args.height
     total_paths = (eye_paths + M) * args.steps

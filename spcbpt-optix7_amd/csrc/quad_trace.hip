@@ -60,24 +60,25 @@ struct QuadArgs {
     uint32_t* counter;       // pool cursor (zeroed before the launch)
     float* out_t; int* out_tri; float* out_uv;   // closest
     int* out_visible;                            // any
+    uint32_t chunk;                              // rays a wave claims per atomic (launch_trace_bench: a quarter of a wave's fair share, 64 .. 1024)
     unsigned long long* stats;                   // [0] node visits, [1] leaf visits, [2] triangle tests, [3] wave iterations (x 64 lane slots), [4] lanes busy in them
 };
 
-// Ray acquisition.  A wave claims the launch's rays in chunks of kChunk (ONE global atomic per chunk) and hands them to its lanes /
+// Ray acquisition.  A wave claims the launch's rays in chunks of A.chunk (ONE global atomic per chunk; the chunk is a quarter of a
+// wave's fair share of the launch, so that every resident wave gets work and the tail stays short) and hands them to its lanes /
 // quads from a wave-uniform cursor with ballot arithmetic.  (First version: one atomicAdd on the launch's single counter per
 // refill, i.e. in nearly every iteration of every wave -- 8 192 waves serialised on one L2 atomic and BOTH schedules measured that,
 // not their traversal: lane 660, quad 195 Mrays/s on the primary rays.)  All lanes of the wave call this together; `want` = the
 // lanes that take a ray (one per lane / per quad), `rank` = number of takers before this lane.  Returns the ray index or 0xffffffff
 // (no ray this time: the chunk ran out -- the next call claims a new one -- or the launch has no more rays).
-static constexpr uint32_t kChunk = 1024;
 SPC_DEV uint32_t pool_take(const QuadArgs& A, uint32_t& chunk_next, uint32_t& chunk_end, bool& exhausted, unsigned long long want, uint32_t rank) {
     if (chunk_next >= chunk_end) {
         uint32_t base = 0;
-        if ((threadIdx.x & 63u) == 0u) base = atomicAdd(A.counter, kChunk);
+        if ((threadIdx.x & 63u) == 0u) base = atomicAdd(A.counter, A.chunk);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (base >= (uint32_t)A.n) { exhausted = true; return 0xffffffffu; }
         chunk_next = base;
-        chunk_end = min(base + kChunk, (uint32_t)A.n);
+        chunk_end = min(base + A.chunk, (uint32_t)A.n);
     }
     const uint32_t mine = chunk_next + rank;
     chunk_next = min(chunk_next + (uint32_t)__popcll(want), chunk_end);
@@ -464,6 +465,8 @@ void launch_trace_bench(const KParams& p, int mode, bool any, bool stats, const 
     QuadArgs A;
     A.nodes_q = reinterpret_cast<const float4*>(nodes_q); A.rays = rays; A.n = n; A.counter = counter;
     A.out_t = t; A.out_tri = tri; A.out_uv = uv; A.out_visible = vis; A.stats = stat_out;
+    const long long waves = (long long)blocks * (QBLOCK / 64);
+    A.chunk = (uint32_t)std::max(64LL, std::min(1024LL, (long long)n / std::max(1LL, waves * 4)));
     if (mode == 2) quadk_launch<2>(any, stats, blocks, s, p.scene, A);
     else if (mode == 3) quadk_launch<4>(any, stats, blocks, s, p.scene, A);
     else if (mode == 1) {

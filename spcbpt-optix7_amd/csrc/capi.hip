@@ -15,6 +15,7 @@
 #include "../../include/spcbpt.h"
 #include "context.h"
 #include "kernels.h"
+namespace spc { void launch_repack_nodes_quad2(const float* nodes_q, float* out, int n_nodes, hipStream_t s); }   // quad_trace.hip (declared here: kernels.h is part of the megakernel's source hash)
 #include "lbvh.h"
 #include "env_host.h"
 
@@ -968,7 +969,7 @@ int Context::install_minimal_tuple() {
 Context::~Context() {
     resolve_spans();
     free_preprocess();
-    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
+    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_nodes_q2); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
     dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
@@ -1659,8 +1660,8 @@ int spcbpt_set_connection_sampler(spcbpt_ctx* c, int mode) {
 int spcbpt_debug_trace_bench(spcbpt_ctx* c, const float* rays, int n, int mode, int any, int repeat, float* out_t, int32_t* out_tri, float* out_uv,
                              int32_t* out_visible, double* avg_ms, uint64_t stats[5]) {
     CTX_CHECK(c);
-    if (!rays || n < 1 || mode < 0 || mode > 3 || repeat < 1 || (any && !out_visible) || (!any && (!out_t || !out_tri || !out_uv))) { c->error = "debug_trace_bench: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
-    if (mode >= 1 && 3 * c->bvh_depth > (mode == 1 ? 64 : 48)) { c->error = "debug_trace_bench: the quad kernel's per-ray LDS stack holds " + std::to_string(mode == 1 ? 64 : 48) + " entries (3 x BVH depth " + std::to_string(c->bvh_depth) + " needed)"; return SPCBPT_ERR_CAPACITY; }
+    if (!rays || n < 1 || mode < 0 || mode > 4 || repeat < 1 || (any && !out_visible) || (!any && (!out_t || !out_tri || !out_uv))) { c->error = "debug_trace_bench: bad arguments"; return SPCBPT_ERR_INVALID_ARG; }
+    if (mode >= 1 && 3 * c->bvh_depth > (mode == 1 || mode == 4 ? 64 : 48)) { c->error = "debug_trace_bench: the quad kernel's per-ray LDS stack holds " + std::to_string(mode == 1 || mode == 4 ? 64 : 48) + " entries (3 x BVH depth " + std::to_string(c->bvh_depth) + " needed)"; return SPCBPT_ERR_CAPACITY; }
     float* d_rays = nullptr; float* d_t = nullptr; int* d_tri = nullptr; float* d_uv = nullptr; int* d_vis = nullptr;
     uint32_t* d_counter = nullptr; unsigned long long* d_stats = nullptr;
     int rc = trace_common(c, rays, n, &d_rays);
@@ -1676,8 +1677,13 @@ int spcbpt_debug_trace_bench(spcbpt_ctx* c, const float* rays, int n, int mode, 
         e = dev_alloc(&c->d_nodes_q, (size_t)c->n_nodes * 16);
         if (e == hipSuccess) { launch_repack_nodes_quad(c->d_nodes, c->d_nodes_q, c->n_nodes, c->stream); e = hipGetLastError(); }
     }
+    if (e == hipSuccess && mode == 4 && !c->d_nodes_q2) {   // ... and the same with the scale exponents as signed bytes
+        e = dev_alloc(&c->d_nodes_q2, (size_t)c->n_nodes * 16);
+        if (e == hipSuccess) { launch_repack_nodes_quad2(c->d_nodes_q, c->d_nodes_q2, c->n_nodes, c->stream); e = hipGetLastError(); }
+    }
+    const float* nodes_q = mode == 4 ? c->d_nodes_q2 : c->d_nodes_q;
     const int per_cu = trace_bench_blocks_per_cu(mode, any != 0);
-    const int rays_per_block = mode == 0 ? 256 : 64 << (mode - 1);
+    const int rays_per_block = mode == 0 ? 256 : (mode == 4 ? 64 : 64 << (mode - 1));
     const int blocks = std::max(1, std::min(c->num_cus * per_cu, (n + rays_per_block - 1) / rays_per_block));
     if (e == hipSuccess && mode == 0) { rc = c->ensure_spill((size_t)blocks * 256); if (rc) { cleanup(); return rc; } }
     if (e == hipSuccess) e = dev_alloc(&d_counter, (size_t)1);
@@ -1690,7 +1696,7 @@ int spcbpt_debug_trace_bench(spcbpt_ctx* c, const float* rays, int n, int mode, 
     for (int k = 0; k <= repeat && e == hipSuccess; k++) {   // launch 0 warms up
         e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
-        if (e == hipSuccess) { launch_trace_bench(c->kp, mode, any != 0, false, c->d_nodes_q, d_rays, n, d_counter, d_t, d_tri, d_uv, d_vis, d_stats, blocks, c->stream); e = hipGetLastError(); }
+        if (e == hipSuccess) { launch_trace_bench(c->kp, mode, any != 0, false, nodes_q, d_rays, n, d_counter, d_t, d_tri, d_uv, d_vis, d_stats, blocks, c->stream); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.0f;
@@ -1700,7 +1706,7 @@ int spcbpt_debug_trace_bench(spcbpt_ctx* c, const float* rays, int n, int mode, 
     if (e == hipSuccess && stats) {
         e = hipMemsetAsync(d_counter, 0, sizeof(uint32_t), c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_stats, 0, 5 * sizeof(unsigned long long), c->stream);
-        if (e == hipSuccess) { launch_trace_bench(c->kp, mode, any != 0, true, c->d_nodes_q, d_rays, n, d_counter, d_t, d_tri, d_uv, d_vis, d_stats, blocks, c->stream); e = hipGetLastError(); }
+        if (e == hipSuccess) { launch_trace_bench(c->kp, mode, any != 0, true, nodes_q, d_rays, n, d_counter, d_t, d_tri, d_uv, d_vis, d_stats, blocks, c->stream); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = hipMemcpy(stats, d_stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     }

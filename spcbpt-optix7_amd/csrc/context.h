@@ -108,6 +108,7 @@ struct Context {
     // scene
     float* d_nodes = nullptr;
     float* d_nodes_q = nullptr;            // the same nodes in the quad-lane layout (quad_trace.hip), built on first use
+    float* d_nodes_q2 = nullptr;           // ... with the scale exponents as signed bytes (the lean quad kernel)
     float* d_tris = nullptr;
     int32_t* d_tri_orig = nullptr;
     DMaterial* d_mats = nullptr;

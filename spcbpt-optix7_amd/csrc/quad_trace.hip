@@ -216,6 +216,159 @@ __global__ __launch_bounds__(QBLOCK) void k_trace_quad(const DeviceScene S, cons
     }
 }
 
+// ---- four lanes per ray, lean node step ("quad2") --------------------------------------------------------------------------------
+// k_trace_quad is instruction-bound (VALU issue 0.70, 2.3 x the lane form's instructions): this form attacks the count.
+//   * the near / far plane bytes of the lane's child are picked by two v_perm_b32 whose selectors are per-RAY constants (the signs of
+//     the direction), then six byte->float converts: 8 instructions instead of 6 converts + 3 compares + 6 selects;
+//   * the node's scale exponents are stored as signed bytes (k_repack_nodes_quad2) and applied with v_ldexp_f32: 2 instead of 3 per axis;
+//   * which children were hit comes from ONE ballot (the compare's own result) and a shift, the nearest from two DPP min steps, and the
+//     other hits are pushed in SLOT order (a popcount), not sorted: the traversal is correct in any order, only the nearest child
+//     matters much for the visit count (measured below);
+//   * 32-bit node offsets from a scalar base.
+__global__ void k_repack_nodes_quad2(const float4* __restrict__ q1, float4* __restrict__ out, int n_nodes) {   // in: the quad layout; out: exponents as signed bytes
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    for (int r = 0; r < 4; r++) {
+        float4 v = q1[(size_t)i * 4 + r];
+        if (r == 3) {
+            const uint32_t e = __float_as_uint(v.w);
+            const uint32_t s = ((e & 255u) - 127u) & 255u, t = (((e >> 8) & 255u) - 127u) & 255u, u = (((e >> 16) & 255u) - 127u) & 255u;
+            v.w = __uint_as_float(s | (t << 8) | (u << 16));
+        }
+        out[(size_t)i * 4 + r] = v;
+    }
+}
+template <bool ANY, bool STATS>
+__global__ __launch_bounds__(QBLOCK) void k_trace_quad2(const DeviceScene S, const QuadArgs A) {
+    __shared__ uint32_t s_stack[QRAYS * QSTRIDE];
+    const uint32_t lane = threadIdx.x & 63u, r = lane & 3u;
+    uint32_t* stack = s_stack + (threadIdx.x >> 2) * QSTRIDE;
+    const uint32_t below = (1u << r) - 1u, quad_shift = lane & 60u;
+    const char* const node_base = reinterpret_cast<const char*>(A.nodes_q);
+    int sp = 0;
+    int node = kTravDone, leaf_count = 0;
+    int ray = -1;
+    f3 o = mk3(0.f), d = mk3(0.f), inv = mk3(1.f), ood = mk3(0.f);
+    uint32_t sel_n = 0, sel_f = 0;                     // v_perm selectors of the near / far plane bytes (from the direction's signs)
+    float tmin = 0.f, best_t = 0.f;
+    float my_t = 1e30f, my_u = 0.f, my_v = 0.f;
+    int my_tri = -1;
+    bool occluded = false, exhausted = false;
+    uint32_t chunk_next = 0, chunk_end = 0;
+    unsigned long long n_node = 0, n_leaf = 0, n_tri = 0, n_iter = 0, n_busy = 0;
+    while (true) {
+        const bool need = node == kTravDone;
+        if (!exhausted) {
+            const unsigned long long want = __ballot(need && r == 0u);
+            if (want) {
+                const uint32_t mine = pool_take(A, chunk_next, chunk_end, exhausted, want, (uint32_t)__popcll(want & ((1ull << quad_shift) - 1ull)));
+                if (need && mine != 0xffffffffu) {
+                    ray = (int)mine;
+                    const float4 ra = ldq(A.rays, (size_t)ray * 2), rb = ldq(A.rays, (size_t)ray * 2 + 1);
+                    o = mk3(ra.x, ra.y, ra.z); d = mk3(rb.x, rb.y, rb.z);
+                    tmin = ra.w; best_t = rb.w;
+                    inv = safe_inv(d); ood = o * inv;
+                    // record bytes: x = [lo.x, lo.y, lo.z, hi.x] (perm indices 0..3), y = [hi.y, hi.z, -, -] (indices 4, 5)
+                    const uint32_t sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+                    sel_n = (sx ? 3u : 0u) | ((sy ? 4u : 1u) << 8) | ((sz ? 5u : 2u) << 16) | ((sx ? 0u : 3u) << 24);   // near x, y, z, far x
+                    sel_f = (sy ? 1u : 4u) | ((sz ? 2u : 5u) << 8) | (0x0cu << 16) | (0x0cu << 24);                     // far y, z, 0, 0
+                    node = 0; sp = 0; leaf_count = 0;
+                    my_t = 1e30f; my_tri = -1; occluded = false;
+                }
+            }
+        }
+        if (!__any(node != kTravDone)) break;
+        if (STATS) { n_iter += lane == 0 ? 1 : 0; n_busy += node != kTravDone ? 1 : 0; }
+        if (node != kTravDone) {
+            bool finished = false;
+            if (node >= 0) {
+                const float4 rec = *reinterpret_cast<const float4*>(node_base + ((uint32_t)node * 64u + r * 16u));
+                if (STATS && r == 0u) n_node++;
+                const float ox = qpermf<kBcast0>(rec.w), oy = qpermf<kBcast1>(rec.w), oz = qpermf<kBcast2>(rec.w);
+                const int e = (int)qperm<kBcast3>(__float_as_uint(rec.w));
+                const float ax = ldexpf(inv.x, (int)(signed char)(e & 255)), ay = ldexpf(inv.y, (int)(signed char)((e >> 8) & 255)),
+                            az = ldexpf(inv.z, (int)(signed char)((e >> 16) & 255));
+                const float bx = fmaf(ox, inv.x, -ood.x), by = fmaf(oy, inv.y, -ood.y), bz = fmaf(oz, inv.z, -ood.z);
+                const uint32_t pa = __float_as_uint(rec.x), pb = __float_as_uint(rec.y);
+                const uint32_t nn = __builtin_amdgcn_perm(pb, pa, sel_n), ff = __builtin_amdgcn_perm(pb, pa, sel_f);
+                const float tnx = fmaf((float)(nn & 255u), ax, bx), tny = fmaf((float)((nn >> 8) & 255u), ay, by), tnz = fmaf((float)((nn >> 16) & 255u), az, bz);
+                const float tfx = fmaf((float)(nn >> 24), ax, bx), tfy = fmaf((float)(ff & 255u), ay, by), tfz = fmaf((float)((ff >> 8) & 255u), az, bz);
+                const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, best_t));
+                const bool hit = t0 <= t1 * 1.0000004f;
+                const uint32_t key = hit ? ((__float_as_uint(t0) & ~3u) | r) : 0xffffffffu;
+                const uint32_t ref = __float_as_uint(rec.z);
+                const uint32_t nib = (uint32_t)(__ballot(hit) >> quad_shift) & 15u;       // the quad's four hit flags
+                uint32_t next;
+                if (nib == 0u) {
+                    if (sp == 0) next = 0xffffffffu; else next = stack[--sp];
+                } else {
+                    uint32_t kmin = min(key, qperm<kXor1>(key));
+                    kmin = min(kmin, qperm<kRot2>(kmin));
+                    const bool nearest = key == kmin;
+                    const uint32_t others = nib & ~(1u << (kmin & 3u));
+                    if (hit && !nearest) stack[sp + (int)__popc(others & below)] = ref;
+                    sp += (int)__popc(others);
+                    uint32_t mine = nearest ? ref : 0u;
+                    mine |= qperm<kXor1>(mine);
+                    next = mine | qperm<kRot2>(mine);
+                }
+                if (next == 0xffffffffu) { node = kTravDone; finished = true; }
+                else if (next & 0x80000000u) { node = ~(int)((next & 0x7fffffffu) >> 3); leaf_count = (int)(next & 7u); }
+                else node = (int)next;
+            }
+            if (!finished && node < 0) {
+                float t = 1e30f, u = 0.f, v = 0.f;
+                bool h = false;
+                const int tri = ~node + (int)r;
+                if ((int)r < leaf_count) {
+                    const size_t base = (size_t)tri * 4;
+                    const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
+                    bool cull = false;
+                    if (!ANY) cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
+                    h = tri_test(a, b, c, o, d, tmin, best_t, cull, t, u, v);
+                    if (!h) t = 1e30f;
+                    if (STATS) n_tri++;
+                }
+                if (STATS && r == 0u) n_leaf++;
+                if (h && t < my_t) { my_t = t; my_tri = tri; my_u = u; my_v = v; }
+                float tq = fminf(t, qpermf<kXor1>(t));
+                tq = fminf(tq, qpermf<kRot2>(tq));
+                if (ANY) {
+                    if (tq < 1e30f) { occluded = true; node = kTravDone; finished = true; }
+                } else best_t = fminf(best_t, tq);
+                if (!finished) {
+                    if (sp == 0) { node = kTravDone; finished = true; }
+                    else {
+                        const uint32_t w = stack[--sp];
+                        if (w & 0x80000000u) { node = ~(int)((w & 0x7fffffffu) >> 3); leaf_count = (int)(w & 7u); }
+                        else node = (int)w;
+                    }
+                }
+            }
+            if (finished) {
+                if (ANY) {
+                    if (r == 0u) A.out_visible[ray] = occluded ? 0 : 1;
+                } else {
+                    const uint32_t cand = (my_tri >= 0 && my_t == best_t) ? r : 4u;
+                    uint32_t w = min(cand, qperm<kXor1>(cand));
+                    w = min(w, qperm<kRot2>(w));
+                    if (w == 4u) { if (r == 0u) { A.out_t[ray] = best_t; A.out_tri[ray] = -1; A.out_uv[2 * ray] = 0.f; A.out_uv[2 * ray + 1] = 0.f; } }
+                    else if (w == r) { A.out_t[ray] = my_t; A.out_tri[ray] = S.tri_orig[my_tri]; A.out_uv[2 * ray] = my_u; A.out_uv[2 * ray + 1] = my_v; }
+                }
+            }
+        }
+    }
+    if (STATS) {
+        const unsigned long long v[5] = {n_node, n_leaf, n_tri, n_iter * 64ull, n_busy};
+        for (int k = 0; k < 5; k++) {
+            unsigned long long x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0 && x) atomicAdd(&A.stats[k], x);
+        }
+    }
+}
+
 // ---- four lanes per ray, K rays per quad -------------------------------------------------------------------------------------------
 // k_trace_quad keeps 16 rays per wave in flight where the lane kernel keeps 64: with one dependent fetch per ray per iteration it is
 // latency-bound at a quarter of the lane kernel's memory-level parallelism (measured: 0.29-0.36 x its speed, section 3 of
@@ -437,6 +590,9 @@ __global__ __launch_bounds__(QBLOCK) void k_trace_lane(const KParams p, const Qu
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+void launch_repack_nodes_quad2(const float* nodes_q, float* out, int n_nodes, hipStream_t s) {
+    hipLaunchKernelGGL(k_repack_nodes_quad2, dim3((n_nodes + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float4*>(nodes_q), reinterpret_cast<float4*>(out), n_nodes);
+}
 void launch_repack_nodes_quad(const float* nodes, float* out, int n_nodes, hipStream_t s) {
     hipLaunchKernelGGL(k_repack_nodes_quad, dim3((n_nodes + 255) / 256), dim3(256), 0, s, reinterpret_cast<const float4*>(nodes), reinterpret_cast<float4*>(out), n_nodes);
 }
@@ -454,6 +610,10 @@ static void quadk_launch(bool any, bool stats, int blocks, hipStream_t s, const 
 int trace_bench_blocks_per_cu(int mode, bool any) {
     int n = 0;
     hipError_t e;
+    if (mode == 4) {
+        hipError_t e4 = any ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_quad2<true, false>, QBLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_quad2<false, false>, QBLOCK, 0);
+        return e4 == hipSuccess && n > 0 ? n : 1;
+    }
     if (mode == 2) return quadk_blocks<2>(any);
     if (mode == 3) return quadk_blocks<4>(any);
     if (mode == 1) e = any ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_quad<true, false>, QBLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_quad<false, false>, QBLOCK, 0);
@@ -467,7 +627,11 @@ void launch_trace_bench(const KParams& p, int mode, bool any, bool stats, const 
     A.out_t = t; A.out_tri = tri; A.out_uv = uv; A.out_visible = vis; A.stats = stat_out;
     const long long waves = (long long)blocks * (QBLOCK / 64);
     A.chunk = (uint32_t)std::max(64LL, std::min(1024LL, (long long)n / std::max(1LL, waves * 4)));
-    if (mode == 2) quadk_launch<2>(any, stats, blocks, s, p.scene, A);
+    if (mode == 4) {
+        if (any) { if (stats) hipLaunchKernelGGL((k_trace_quad2<true, true>), dim3(blocks), dim3(QBLOCK), 0, s, p.scene, A); else hipLaunchKernelGGL((k_trace_quad2<true, false>), dim3(blocks), dim3(QBLOCK), 0, s, p.scene, A); }
+        else { if (stats) hipLaunchKernelGGL((k_trace_quad2<false, true>), dim3(blocks), dim3(QBLOCK), 0, s, p.scene, A); else hipLaunchKernelGGL((k_trace_quad2<false, false>), dim3(blocks), dim3(QBLOCK), 0, s, p.scene, A); }
+    }
+    else if (mode == 2) quadk_launch<2>(any, stats, blocks, s, p.scene, A);
     else if (mode == 3) quadk_launch<4>(any, stats, blocks, s, p.scene, A);
     else if (mode == 1) {
         if (any) { if (stats) hipLaunchKernelGGL((k_trace_quad<true, true>), dim3(blocks), dim3(QBLOCK), 0, s, p.scene, A); else hipLaunchKernelGGL((k_trace_quad<true, false>), dim3(blocks), dim3(QBLOCK), 0, s, p.scene, A); }

@@ -24,7 +24,7 @@ def test_quad_traversal_matches_lane_traversal_and_oracle(gpu, pkg, ob, scene_na
     v0, _, _ = r.trace_bench(rays2, 0, True, repeat=1)
     assert np.array_equal(v0, r.trace_any(rays2))
     vo = o.trace_any(rays2)
-    for mode in (1, 2, 3):                                                  # one, two, four rays per quad in flight
+    for mode in (1, 2, 3, 4):                                               # one, two, four rays per quad in flight; 4 = the lean node step
         (t1, tri1, uv1), _, st1 = r.trace_bench(rays, mode, False, repeat=1)
         same = tri1 == tri0
         assert same.mean() >= 0.9995, (mode, same.mean())
@@ -33,7 +33,10 @@ def test_quad_traversal_matches_lane_traversal_and_oracle(gpu, pkg, ob, scene_na
         ok = tri1 == trio
         assert (np.abs(t1 - to)[ok] <= 1e-5 * np.maximum(1.0, to[ok])).all(), mode
         # the schedules visit the same nodes (ranking the four keys across the quad IS the sort of the lane kernel)
-        assert abs(st1["node_visits"] - st0["node_visits"]) <= 0.002 * st0["node_visits"], mode
+        if mode != 4:
+            assert abs(st1["node_visits"] - st0["node_visits"]) <= 0.002 * st0["node_visits"], mode
+        else:   # the lean form continues with the nearest child but pushes the other hits in slot order, not sorted: a few more visits
+            assert st0["node_visits"] * 0.998 <= st1["node_visits"] <= 1.12 * st0["node_visits"], (st0["node_visits"], st1["node_visits"])
         assert st1["tri_tests"] <= st0["tri_tests"] * 1.6, mode             # a leaf is tested whole: a hit cannot skip its later triangles
         v1, _, _ = r.trace_bench(rays2, mode, True, repeat=1)
         assert (v1 == v0).mean() >= 0.9995, mode
@@ -54,7 +57,7 @@ def test_quad_traversal_edge_cases(gpu, pkg, ob):
     for n in (3, 17, 63, 65, 1001):
         rays = _rays(np.random.default_rng(n), n, lo, hi)
         (t0, tri0, _), _, _ = r.trace_bench(rays, 0, False, repeat=1)
-        for mode in (1, 2, 3):
+        for mode in (1, 2, 3, 4):
             (t1, tri1, _), _, _ = r.trace_bench(rays, mode, False, repeat=1)
             assert np.array_equal(tri0, tri1) and np.array_equal(t0, t1), (n, mode)
     # single-sided emitters for path rays, opaque to shadow rays (q16), in the quad kernel too

@@ -73,10 +73,10 @@ def main():
     report = {"scene": dict(r.scene_info(), name="bedroom"), "sets": {}}
     for name, (rs, any_hit) in ray_sets(pkg, scene, r, a.width, a.height).items():
         res, outs, nr = {}, [], len(rs)
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4):
             out, ms, st = r.trace_bench(rs, mode, any_hit, repeat=a.repeat)
             outs.append(out)
-            res[("lane", "quad", "quad_x2", "quad_x4")[mode]] = dict(
+            res[("lane", "quad", "quad_x2", "quad_x4", "quad_lean")[mode]] = dict(
                 ms=round(ms, 4), mrays_per_s=round(nr / ms / 1e3, 1), node_visits_per_ray=round(st["node_visits"] / nr, 2),
                 leaf_visits_per_ray=round(st["leaf_visits"] / nr, 2), tri_tests_per_ray=round(st["tri_tests"] / nr, 2),
                 lane_utilisation=round(st["lanes_busy"] / max(st["lane_slots"], 1), 4))
@@ -87,7 +87,7 @@ def main():
                                     max_dt=[float(np.abs(outs[0][0] - o[0])[outs[0][1] == o[1]].max()) for o in outs[1:]],
                                     hit_share=float((outs[0][1] >= 0).mean()))
         res["rays"] = nr
-        res["speedup_over_lane"] = {k: round(res["lane"]["ms"] / res[k]["ms"], 3) for k in ("quad", "quad_x2", "quad_x4")}
+        res["speedup_over_lane"] = {k: round(res["lane"]["ms"] / res[k]["ms"], 3) for k in ("quad", "quad_x2", "quad_x4", "quad_lean")}
         report["sets"][name] = res
         print(name, json.dumps(res))
     if a.out:

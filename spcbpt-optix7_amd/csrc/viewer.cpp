@@ -292,7 +292,7 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
     bool have = false;
     if (v->spec_in_flight && v->ctx) {
         have = !state_changed && v->spec_alg == v->render_alg_id && v->spec_subframe == v->subframe_index;
-        if (!have) { rc = spcbpt_merge_deferred(v->ctx, 0); if (rc) return rc; v->spec_in_flight = false; v->spec_drops++; }
+        if (!have) { v->spec_in_flight = false; v->spec_drops++; rc = spcbpt_merge_deferred(v->ctx, 0); if (rc) return rc; }   // (whatever the call says, the context holds no deferred frame afterwards)
     }
     if (v->camera_changed) {  // handleCameraUpdate (352-370)
         v->camera_changed = false;
@@ -311,10 +311,10 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
         const bool spcbpt = v->render_alg_id == 1;
         // ---- the frame to show: the speculative one if it is still this frame, else render it now
         if (have) {
-            rc = spcbpt_merge_deferred(v->ctx, 1);
-            if (rc) return rc;
             v->spec_in_flight = false;
             v->spec_hits++;
+            rc = spcbpt_merge_deferred(v->ctx, 1);
+            if (rc) return rc;
         }
         if (!have) {
             if (spcbpt && !v->sampler_ready) {  // launchLVCTrace (515-522)

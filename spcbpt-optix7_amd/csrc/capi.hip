@@ -1186,6 +1186,12 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     memset(&c->kp, 0, sizeof(c->kp));
     c->kp.scene.nodes = c->d_nodes; c->kp.scene.tris = c->d_tris; c->kp.scene.tri_orig = c->d_tri_orig; c->kp.scene.mats = c->d_mats;
     c->kp.scene.lights = c->d_lights; c->kp.scene.tex = c->d_tex; c->kp.scene.n_lights = c->n_lights; c->kp.scene.n_mats = c->n_mats;
+    // the same nodes, one record per child: the quad tail of the pooled traversal pass (device_lib.h) and the traversal A/B harness
+    CREATE_TRY(dev_alloc(&c->d_nodes_q, (size_t)c->n_nodes * 16));
+    launch_repack_nodes_quad(c->d_nodes, c->d_nodes_q, c->n_nodes, c->stream);
+    CREATE_TRY(hipGetLastError());
+    CREATE_TRY(hipStreamSynchronize(c->stream));
+    c->kp.scene.nodes_q = getenv("SPCBPT_NO_QUAD_TAIL") ? nullptr : c->d_nodes_q;
     c->kp.scene.general = 0;   // no environment map yet; a flagged material (Pbr::brdf) selects the general kernels as well
     for (const DMaterial& m : mats) if (m.brdf) c->kp.scene.general = 1;
     c->kp.sampler_counts = c->d_sampler_counts;

@@ -203,6 +203,9 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 // "while-while" traversal: all lanes first descend through internal nodes (lanes that already sit on a leaf wait), then
 // the wave processes leaves together, so the two code paths are not interleaved per iteration inside a divergent wave.
 static constexpr int kTravDone = 0x7fffffff;
+#ifndef SPC_QUAD_TAIL
+#define SPC_QUAD_TAIL 1   // the last <= 16 rays of a pooled pass continue on four lanes each (trace_pool); 0 = the lane loop to the end
+#endif
 // pop the next stack entry into (node, leaf_count); leaf refs carry their count: 1<<31 | first<<3 | count (count <= 4).
 // A macro, not a lambda: a by-reference capture keeps node / leaf_count in scratch memory inside the loop.
 #define SPC_TRAV_POP()                                                                              \
@@ -337,6 +340,14 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     return best_tri >= 0;
 }
 
+// ---- DPP quad_perm helpers (four consecutive lanes) ---------------------------------------------------------------------
+static constexpr int kQBcast0 = 0x00, kQBcast1 = 0x55, kQBcast2 = 0xAA, kQBcast3 = 0xFF;
+static constexpr int kQRot1 = 0x39, kQRot2 = 0x4E, kQRot3 = 0x93, kQXor1 = 0xB1;   // [1,2,3,0] [2,3,0,1] [3,0,1,2] [1,0,3,2]
+template <int CTRL>
+SPC_DEV uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+SPC_DEV float quad_permf(float v) { return __uint_as_float(quad_perm<CTRL>(__float_as_uint(v))); }
+
 // ---- wave-cooperative traversal: one closest-hit ray per lane + a pool of shadow rays -----------------------------------
 // Per iteration of the megakernel a wave has up to 64 closest-hit rays (the next path segments) and up to 192 shadow rays
 // (CONNECTION_N per eye vertex of the previous segment).  Neither depends on the other, so both are traced in ONE pass:
@@ -372,6 +383,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                         Counts<COUNT>& cn) {
     uint32_t r = 0;
     bool closest = own, done = false;
+    unsigned long long quad_live = 0ull;   // != 0: the lanes whose rays the quad tail takes over
     f3 o = own_o, d = own_d;
     f3 inv = safe_inv(d), ood = o * inv;
     float best_t = 1e16f, best_u = 0.0f, best_v = 0.0f;
@@ -395,7 +407,11 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             cn.add(C_SHADOW);
             }
         }
-        if (!__any(node != kTravDone)) break;
+        const unsigned long long live__ = __ballot(node != kTravDone);
+        if (live__ == 0ull) break;
+        // The pool is dry (some lane found it empty; the cursor only grows) and at most 16 rays are still in flight: the rest of the
+        // pass is the tail that used to run these iterations at a fifth of the lanes.  Hand each ray to FOUR lanes (quad tail below).
+        if (SPC_QUAD_TAIL && S.nodes_q && __popcll(live__) <= 16 && __any(done)) { quad_live = live__; break; }
         const bool tail = COUNT && __any(done);   // (counting build) some lane found the pool empty: what follows is the pass's tail
         if (node != kTravDone) {
             bool finished = false, occluded = false;
@@ -436,6 +452,147 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                 }
             }
         }
+    }
+    if (SPC_QUAD_TAIL && quad_live != 0ull) {
+        // ---- quad tail: the k-th ray still in flight continues on lanes 4 k .. 4 k + 3 -------------------------------------------
+        // Lane r of a quad loads record r of the node (one coalesced 64-B line per ray), tests ITS child, and the four entry
+        // distances are ranked across the quad: the same keys, the same order, the same pushes as SPC_NODE_STEP -- onto the SAME
+        // stack, the owner lane's LDS column (and its HBM part) -- so the ray visits what it would have visited.  At a leaf lane r
+        // tests triangle r.  An iteration is ~100 instructions instead of ~275 and serves up to 16 rays, which is all there are.
+        const uint32_t lane = lane_id_fresh(), qr = lane & 3u;
+        uint8_t* list = const_cast<uint8_t*>(s_list);   // the ray list of the pass is used up: the owners' lane ids go there
+        if (node != kTravDone) list[__popcll(quad_live & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n_live = (int)__popcll(quad_live);
+        const bool has = (int)(lane >> 2) < n_live;
+        const int owner = has ? (int)list[lane >> 2] : (int)lane;
+        // the ray's state, from its owner
+        const f3 qo = mk3(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+        const f3 qd = mk3(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+        float q_best = __shfl(best_t, owner, 64);
+        int q_node = __shfl(node, owner, 64), q_leaf = __shfl(leaf_count, owner, 64), q_sp = __shfl(st.sp, owner, 64);
+        const bool q_closest = __shfl((int)closest, owner, 64) != 0;
+        const uint32_t q_r = (uint32_t)__shfl((int)r, owner, 64);
+        // the owner's best hit so far continues as lane 0's (a closest-hit ray may have found one before the hand-over)
+        float my_t = 1e30f, my_u = 0.0f, my_v = 0.0f;
+        int my_tri = -1;
+        {
+            const int bt = __shfl(best_tri, owner, 64);
+            const float bu = __shfl(best_u, owner, 64), bv = __shfl(best_v, owner, 64);
+            if (qr == 0u && bt >= 0) { my_t = q_best; my_tri = bt; my_u = bu; my_v = bv; }
+        }
+        if (!has) q_node = kTravDone;
+        const f3 qinv = safe_inv(qd), qood = qo * qinv;
+        lds_u32* const col = st.wave_lds + owner;
+        uint32_t* const q_spill = st.spill ? st.spill + ((long long)owner - (long long)lane) * (long long)st.spill_entries : nullptr;
+        bool q_occluded = false, q_done = !has;
+        while (__any(q_node != kTravDone)) {
+            if (q_node != kTravDone) {
+                bool finished = false;
+                if (q_node >= 0) {
+                    const float4 rec = ldq(S.nodes_q, (size_t)q_node * NODE_QUADS + qr);
+                    if (qr == 0u) cn.add(C_NODE);
+                    if (COUNT) { cn.add(C_U_NODE_LANES); cn.add(q_closest ? C_U_TAIL_CLOSEST : C_U_TAIL_SHADOW); if ((int)lane == __ffsll((long long)__ballot(1)) - 1) { cn.add(C_U_NODE_SLOTS, 64); cn.add(C_U_TAIL_SLOTS, 64); } }
+                    const float ox = quad_permf<kQBcast0>(rec.w), oy = quad_permf<kQBcast1>(rec.w), oz = quad_permf<kQBcast2>(rec.w);
+                    const uint32_t e = quad_perm<kQBcast3>(__float_as_uint(rec.w));
+                    const float ax = __uint_as_float((e & 0xffu) << 23) * qinv.x, ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * qinv.y,
+                                az = __uint_as_float(((e >> 16) & 0xffu) << 23) * qinv.z;
+                    const float bx = fmaf(ox, qinv.x, -qood.x), by = fmaf(oy, qinv.y, -qood.y), bz = fmaf(oz, qinv.z, -qood.z);
+                    const uint32_t pa = __float_as_uint(rec.x), pb = __float_as_uint(rec.y);
+                    const float lx = (float)(pa & 255u), ly = (float)((pa >> 8) & 255u), lz = (float)((pa >> 16) & 255u), hx = (float)(pa >> 24),
+                                hy = (float)(pb & 255u), hz = (float)((pb >> 8) & 255u);
+                    const bool sx = qinv.x < 0.0f, sy = qinv.y < 0.0f, sz = qinv.z < 0.0f;
+                    const float tnx = fmaf(sx ? hx : lx, ax, bx), tfx = fmaf(sx ? lx : hx, ax, bx);
+                    const float tny = fmaf(sy ? hy : ly, ay, by), tfy = fmaf(sy ? ly : hy, ay, by);
+                    const float tnz = fmaf(sz ? hz : lz, az, bz), tfz = fmaf(sz ? lz : hz, az, bz);
+                    const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, kEps));
+                    const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, q_best));
+                    const uint32_t key = (t0 <= t1 * 1.0000004f) ? ((__float_as_uint(t0) & ~3u) | qr) : 0xffffffffu;
+                    const uint32_t ref = __float_as_uint(rec.z);
+                    const uint32_t k1 = quad_perm<kQRot1>(key), k2 = quad_perm<kQRot2>(key), k3 = quad_perm<kQRot3>(key);
+                    const bool hit = key != 0xffffffffu;
+                    const int rank = (k1 < key ? 1 : 0) + (k2 < key ? 1 : 0) + (k3 < key ? 1 : 0);
+                    const int nh = (hit ? 1 : 0) + (k1 != 0xffffffffu ? 1 : 0) + (k2 != 0xffffffffu ? 1 : 0) + (k3 != 0xffffffffu ? 1 : 0);
+                    uint32_t next;
+                    if (nh == 0) {
+                        if (q_sp == 0) next = 0xffffffffu;
+                        else { q_sp--; next = q_sp < STACK_LDS ? col[q_sp * BLOCK] : stack_pop_slow(q_spill, st.spill_entries, q_sp - STACK_LDS); }
+                    } else {
+                        if (hit && rank > 0) {   // farthest deepest, second nearest on top: push_far's order
+                            const int e2 = q_sp + nh - 1 - rank;
+                            if (e2 < STACK_LDS) col[e2 * BLOCK] = ref;
+                            else stack_push_slow(q_spill, st.spill_entries, e2 - STACK_LDS, ref, st.diag);
+                        }
+                        q_sp += nh - 1;
+                        const uint32_t mine = (hit && rank == 0) ? ref : 0u;
+                        next = mine | quad_perm<kQRot1>(mine) | quad_perm<kQRot2>(mine) | quad_perm<kQRot3>(mine);
+                    }
+                    if (next == 0xffffffffu) { q_node = kTravDone; finished = true; }
+                    else if (next & 0x80000000u) { q_node = ~(int)((next & 0x7fffffffu) >> 3); q_leaf = (int)(next & 7u); }
+                    else q_node = (int)next;
+                }
+                if (!finished && q_node < 0) {
+                    float t = 1e30f, u = 0.0f, v = 0.0f;
+                    bool h = false;
+                    const int tri = ~q_node + (int)qr;
+                    if ((int)qr < q_leaf) {
+                        const size_t base = (size_t)tri * 4;
+                        const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
+                        cn.add(C_TRI);
+                        bool cull = false;
+                        if (q_closest) cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
+                        h = tri_test(a, b, c, qo, qd, kEps, q_best, cull, t, u, v);
+                        if (!h) t = 1e30f;
+                    }
+                    if (COUNT) { if ((int)qr < q_leaf) cn.add(C_U_TRI_LANES); if ((int)lane == __ffsll((long long)__ballot(1)) - 1) cn.add(C_U_TRI_SLOTS, 64); }
+                    if (h && t < my_t) { my_t = t; my_tri = tri; my_u = u; my_v = v; }
+                    float tq = fminf(t, quad_permf<kQXor1>(t));
+                    tq = fminf(tq, quad_permf<kQRot2>(tq));
+                    if (!q_closest) {
+                        if (tq < 1e30f) { q_occluded = true; q_node = kTravDone; finished = true; }
+                    } else q_best = fminf(q_best, tq);
+                    if (!finished) {
+                        if (q_sp == 0) { q_node = kTravDone; finished = true; }
+                        else {
+                            q_sp--;
+                            const uint32_t w = q_sp < STACK_LDS ? col[q_sp * BLOCK] : stack_pop_slow(q_spill, st.spill_entries, q_sp - STACK_LDS);
+                            if (w & 0x80000000u) { q_node = ~(int)((w & 0x7fffffffu) >> 3); q_leaf = (int)(w & 7u); }
+                            else q_node = (int)w;
+                        }
+                    }
+                }
+                if (finished) {
+                    q_done = true;
+                    if (!q_closest && qr == 0u) s_vis[q_r] = q_occluded ? (uint8_t)0 : (uint8_t)1;
+                }
+            }
+        }
+        // ---- closest-hit rays of the tail: the winner's record goes back to the owner lane through the owner's stack column, which is
+        // empty again (a finished ray has popped everything).  The lane that holds the quad's nearest hit is the lowest lane with
+        // my_t == q_best (= the lower triangle index on a tie; lane 0 carries a hit found before the hand-over, which a later equal
+        // distance does not replace: strict <, as in the lane loop).
+        {
+            const uint32_t cand = (has && q_closest && my_tri >= 0 && my_t == q_best) ? qr : 4u;
+            uint32_t wq = min(cand, quad_perm<kQXor1>(cand));
+            wq = min(wq, quad_perm<kQRot2>(wq));
+            if (has && q_closest && (wq == 4u ? qr == 0u : wq == qr)) {
+                col[0 * BLOCK] = __float_as_uint(wq == 4u ? q_best : my_t);
+                col[1 * BLOCK] = (uint32_t)(wq == 4u ? -1 : my_tri);
+                col[2 * BLOCK] = __float_as_uint(wq == 4u ? 0.0f : my_u);
+                col[3 * BLOCK] = __float_as_uint(wq == 4u ? 0.0f : my_v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (((quad_live >> lane) & 1ull) != 0ull && closest) {
+                const lds_u32* mine = st.wave_lds + lane;
+                own_hit.t = __uint_as_float(mine[0 * BLOCK]); own_hit.tri = (int)mine[1 * BLOCK];
+                own_hit.u = __uint_as_float(mine[2 * BLOCK]); own_hit.v = __uint_as_float(mine[3 * BLOCK]);
+            }
+        }
+        (void)q_done;
     }
 }
 

@@ -102,6 +102,7 @@ enum CounterSlot {
 
 struct DeviceScene {
     const float* nodes;      // float4 x NODE_QUADS per 4-wide node
+    const float* nodes_q;    // the same nodes, one 16-B record per CHILD (device_lib.h: quad tail of trace_pool); null = no quad tail
     const float* tris;       // float4 x TRI_QUADS per triangle (BVH order)
     const int32_t* tri_orig; // BVH order -> caller's triangle index (quad-light triangles follow the scene's)
     const DMaterial* mats;

@@ -10,7 +10,7 @@ timed instantiations of k_spcbpt, the resources that decide occupancy and the tw
     vectorisation or loop-invariant hoisting in the traversal loop pushed it to 264-384 B;
   * packed-float instructions: only the 12 hand-written v_pk_fma_f32 of the slab test -- the SLP vectoriser made 6 900 of them;
   * instruction count of the kernel within 10 % of what was profiled;
-  * no scratch access inside the traversal loop, whose size is pinned too (675 instructions).
+  * no spill inside the traversal loop nor inside the quad tail's loop; the loops' sizes are pinned too.
 Needs no GPU (hipcc cross-compiles; the tools ship with ROCm)."""
 import collections
 import os
@@ -25,13 +25,14 @@ ARGS = "EEEvNS_7KParamsE"
 # <COUNT, BATCH, CACHE, ENV>: the timed forms (COUNT = false, CACHE = true)
 TIMED = {"single frame, plain scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS, "batched, plain scene (bench.py)": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS,
          "single frame, general scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS, "batched, general scene": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS}
-PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 12182, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 11313,
-                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 14345, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 13501}
+PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 12809, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 11983,
+                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 14817, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 14006}   # profiles/r04c_*
 
 
-def _traversal_loops(lines):
+def _traversal_loops(lines, quad=False):
     """The traversal loop of a kernel -- the smallest loop around four global_load_dwordx4 in a row (SPC_NODE_STEP's node fetch) -- as
-    [(instructions, scratch stores, scratch loads)].  A loop = a backward branch; addresses come from the `// 0000000012AB:` column."""
+    [(instructions, scratch stores, scratch loads)]; with quad=True the quad tail's loop instead (the smallest loop that holds a
+    quad_perm DPP instruction and a global_load_dwordx4).  A loop = a backward branch; addresses come from the `// 0000000012AB:` column."""
     addr = {}
     for i, l in enumerate(lines):
         m = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", l)
@@ -49,7 +50,11 @@ def _traversal_loops(lines):
     best = None   # the smallest loop around a four-quad fetch: the traversal iteration
     for a, b in loops:
         blk = lines[a:b + 1]
-        if any(all("global_load_dwordx4" in x for x in blk[j:j + 4]) for j in range(len(blk) - 3)) and (best is None or b - a < best[1] - best[0]):
+        if quad:
+            ok = any("quad_perm" in x for x in blk) and any("global_load_dwordx4" in x for x in blk)
+        else:
+            ok = any(all("global_load_dwordx4" in x for x in blk[j:j + 4]) for j in range(len(blk) - 3))
+        if ok and (best is None or b - a < best[1] - best[0]):
             best = (a, b)
     if best is None:
         return []
@@ -88,7 +93,8 @@ def code_object(hip_lib, pkg, tmp_path_factory):
                 pk[cur] += "v_pk_" in line
                 if "k_spcbpt" in cur:
                     body[cur].append(line)
-        disasm.update({k: dict(instructions=n[k], packed=pk[k], traversal_loops=_traversal_loops(body[k]) if k in body else None) for k in n})
+        disasm.update({k: dict(instructions=n[k], packed=pk[k], traversal_loops=_traversal_loops(body[k]) if k in body else None,
+                              quad_tail_loop=_traversal_loops(body[k], quad=True) if k in body else None) for k in n})
     assert meta, "no gfx950 code object with k_spcbpt found in the library"
     return meta, disasm
 
@@ -102,7 +108,7 @@ def test_timed_megakernel_resources(code_object, form):
     report = dict(m, **d)
     assert m["vgpr_count"] <= 128, report                          # 4 waves per SIMD (SPC_EYE_WAVES)
     assert m["group_segment_fixed_size"] <= 40960, report           # 4 blocks per CU in 160 KB of LDS
-    assert m["private_segment_fixed_size"] <= 160, report           # scratch per lane: the kernel's HBM writes
+    assert m["private_segment_fixed_size"] <= (176 if "general" in form else 160), report   # scratch per lane: the kernel's HBM writes
     assert d["packed"] <= 16, report                                # the slab test's 12 v_pk_fma_f32; SLP vectorisation made thousands
     want = PROFILED_INSTRUCTIONS[name]
     assert abs(d["instructions"] - want) <= 0.10 * want, report     # the code the profiles/ numbers were measured on
@@ -115,7 +121,10 @@ def test_timed_megakernel_resources(code_object, form):
     size, stores, loads = loops[0]
     assert stores == 0, report                                       # nothing is spilled inside the loop ...
     assert loads <= 6, report                                        # ... and the only reloads are the HBM stack area's base in the (rare) sp >= 16 path
-    assert 600 <= size <= 760, report                                # 655-678 instructions per traversal iteration (node step + triangle step)
+    assert 600 <= size <= 800, report                                # 702-725 instructions per traversal iteration (node step + triangle step)
+    # ... and the quad tail's loop (four lanes per ray: the loop around a DPP quad_perm and a single node-record fetch) spills nothing either
+    tail = d["quad_tail_loop"]
+    assert tail and tail[0][1] == 0 and tail[0][2] == 0 and tail[0][0] <= 480, report   # 425-432 instructions (node + leaf step of up to 16 rays)
 
 
 def test_library_exports_only_the_c_abi(hip_lib, pkg):

@@ -1192,6 +1192,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     CREATE_TRY(hipGetLastError());
     CREATE_TRY(hipStreamSynchronize(c->stream));
     c->kp.scene.nodes_q = getenv("SPCBPT_NO_QUAD_TAIL") ? nullptr : c->d_nodes_q;
+    c->kp.scene.fan_tail = getenv("SPCBPT_NO_FAN_TAIL") ? 0 : 1;
     c->kp.scene.general = 0;   // no environment map yet; a flagged material (Pbr::brdf) selects the general kernels as well
     for (const DMaterial& m : mats) if (m.brdf) c->kp.scene.general = 1;
     c->kp.sampler_counts = c->d_sampler_counts;

@@ -205,6 +205,7 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_QUAD_TAIL
 #define SPC_QUAD_TAIL 1   // the last <= 16 rays of a pooled pass continue on four lanes each (trace_pool); 0 = the lane loop to the end
+#define SPC_FAN_TAIL 1    // ... and its shadow rays on as many quads as the wave has idle (fan_tail); 0 = one quad per ray to the end
 #endif
 // pop the next stack entry into (node, leaf_count); leaf refs carry their count: 1<<31 | first<<3 | count (count <= 4).
 // A macro, not a lambda: a by-reference capture keeps node / leaf_count in scratch memory inside the loop.
@@ -348,6 +349,170 @@ SPC_DEV uint32_t quad_perm(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_d
 template <int CTRL>
 SPC_DEV float quad_permf(float v) { return __uint_as_float(quad_perm<CTRL>(__float_as_uint(v))); }
 
+// ---- fan-out tail: the last shadow rays of a wave's pass, each on as many quads as the wave has to spare -----------------
+// A shadow ray asks one question (is ANY triangle in the way), so the order in which its nodes are visited is free: the
+// traversal stack is a bag.  Once at most 16 rays are left (the quad tail of trace_pool) and none of them is a closest-hit ray,
+// ray k's bag moves to ROW k of the wave's stack array (64 entries; what the owner lane had in HBM stays there as the bag's
+// second part) and the ray is worked on by G = 4, 8, .. 64 lanes -- the wave's 64 divided by the rays still alive, regrouped each
+// time their number halves.  Every quad of a group holds one node: it slab-tests the node's four children, continues with the
+// nearest hit and throws the others into the bag; a quad without a node takes one out.  Measured before this existed: 47 % of
+// the quad-tail iterations ran with one or two rays -- 56 lanes waiting for a dependent chain of fetches that they can now share.
+// An unoccluded ray visits exactly the nodes it visited before (all that its segment touches); an occluded one may find its
+// occluder earlier or later.  s_vis gets the same answers either way, so the film does not change.
+template <bool COUNT, int BLOCK, int STACK_LDS>
+SPC_DEV void fan_tail(const DeviceScene& S, const TravStack<BLOCK, STACK_LDS>& st, bool live, f3 o, f3 d, float tmax, uint32_t cur, int sp,
+                      int owner, uint32_t vis_slot, uint8_t* s_vis, uint8_t* list, Counts<COUNT>& cn) {
+    static_assert(STACK_LDS == 16, "one bag row per ray of the quad tail, four entries per lane in the move");
+    constexpr uint32_t NONE = 0xffffffffu;
+    const uint32_t lane = lane_id_fresh(), qr = lane & 3u;
+    // ---- the owner's LDS entries (rows 0 .. 15 of ITS column) become row (lane >> 2), columns 0 .. 15 -----------------------------
+    int row = (int)(lane >> 2);
+    const int lcnt = sp < STACK_LDS ? sp : STACK_LDS;
+    int hb = sp - lcnt;
+    {
+        const lds_u32* col = st.wave_lds + owner;
+        uint32_t e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = (live && (int)qr + 4 * j < lcnt) ? col[((int)qr + 4 * j) * BLOCK] : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lds_u32* dst = st.wave_lds + row * BLOCK;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (live && (int)qr + 4 * j < lcnt) dst[(int)qr + 4 * j] = e[j];
+    }
+    sp = lcnt;
+    f3 inv = safe_inv(d), ood = o * inv;
+    uint32_t gsh = 2u;   // log2 of the lanes per ray (wave-uniform)
+    bool first = true;
+    while (true) {
+        const uint32_t G = 1u << gsh;
+        const unsigned long long leaders = __ballot(live && (lane & (G - 1u)) == 0u);
+        if (leaders == 0ull) break;
+        const uint32_t n = (uint32_t)__popcll(leaders);
+        uint32_t gn = gsh;
+        while ((n << (gn + 1u)) <= 64u) gn++;
+        if (first || gn != gsh) {   // regroup: the j-th ray alive gets lanes j * Gn .. (j + 1) * Gn - 1; its quads keep their nodes
+            if (live && (lane & (G - 1u)) == 0u) list[__builtin_amdgcn_mbcnt_hi((uint32_t)(leaders >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)leaders, 0u))] = (uint8_t)lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t grp = lane >> gn, in_g = lane & ((1u << gn) - 1u);
+            const bool has = grp < n;
+            const int lead = has ? (int)list[grp] : (int)lane;
+            const uint32_t c2 = (uint32_t)__shfl((int)cur, lead + (int)(in_g < G ? in_g : 0u), 64);
+            cur = (has && in_g < G) ? c2 : NONE;
+            o = mk3(__shfl(o.x, lead, 64), __shfl(o.y, lead, 64), __shfl(o.z, lead, 64));
+            d = mk3(__shfl(d.x, lead, 64), __shfl(d.y, lead, 64), __shfl(d.z, lead, 64));
+            tmax = __shfl(tmax, lead, 64);
+            sp = __shfl(sp, lead, 64); hb = __shfl(hb, lead, 64); row = __shfl(row, lead, 64); owner = __shfl(owner, lead, 64);
+            vis_slot = (uint32_t)__shfl((int)vis_slot, lead, 64);
+            live = has;
+            inv = safe_inv(d); ood = o * inv;
+            gsh = gn;
+            first = false;
+            __builtin_amdgcn_wave_barrier();   // the list is read before the next regroup writes it
+        }
+        if (live) {
+            const uint32_t Gc = 1u << gsh, gbase = lane & ~(Gc - 1u);
+            const unsigned long long gm = (gsh == 6u ? ~0ull : ((1ull << Gc) - 1ull)) << gbase;
+            lds_u32* const bag = st.wave_lds + row * BLOCK;
+            // (the owner's HBM area is addressed only inside the two rare paths that use it: no pointer is kept across the loop)
+#define SPC_FAN_SPILL__ (st.spill ? st.spill + ((long long)owner - (long long)lane) * (long long)st.spill_entries : nullptr)
+            if (sp == 0 && hb > 0) {   // the LDS part is empty: the HBM part (the owner's spilled entries, or this bag's overflow) refills it
+                const int nf = hb < (int)Gc ? hb : (int)Gc;
+                const int in_g = (int)(lane - gbase);
+                if (in_g < nf) bag[in_g] = stack_pop_slow(SPC_FAN_SPILL__, st.spill_entries, hb - 1 - in_g);
+                sp = nf; hb -= nf;
+            }
+            // How many quads may work this step.  A node visit adds up to three entries, and the bag's room is what the ORDERED traversal
+            // was given (STACK_LDS + spill_entries >= 3 x depth: what one quad needs from any starting point) plus the 48 entries this
+            // layout adds in LDS: k quads need 3 k of those 48; with less left only quad 0 works -- a depth-first descent again, which
+            // fits by the host's sizing.  A quad that is held back keeps its node.
+            const int a_max = (48 - sp - hb) >= 6 ? (48 - sp - hb) / 3 : 1;
+            const bool en = (int)((lane - gbase) >> 2) < a_max;
+            // enabled quads without a node take one from the bag
+            {
+                const unsigned long long nm = __ballot(en && cur == NONE && qr == 0u) & gm;
+                const int want = (int)__popcll(nm), take = want < sp ? want : sp;
+                const int rk = (int)__popcll(nm & ((1ull << (lane & ~3u)) - 1ull));
+                if (en && cur == NONE && rk < take) cur = bag[sp - 1 - rk];
+                sp -= take;
+            }
+            // node part
+            bool hit = false;
+            uint32_t key = NONE, cref = 0u;
+            const bool internal = en && (cur & 0x80000000u) == 0u;   // NONE has the leaf bit
+            if (internal) {
+                const float4 rec = ldq(S.nodes_q, (size_t)cur * NODE_QUADS + qr);
+                if (qr == 0u) cn.add(C_NODE);
+                if (COUNT) { cn.add(C_U_NODE_LANES); cn.add(C_U_TAIL_SHADOW); }
+                const float ox = quad_permf<kQBcast0>(rec.w), oy = quad_permf<kQBcast1>(rec.w), oz = quad_permf<kQBcast2>(rec.w);
+                const uint32_t e = quad_perm<kQBcast3>(__float_as_uint(rec.w));
+                const float ax = __uint_as_float((e & 0xffu) << 23) * inv.x, ay = __uint_as_float(((e >> 8) & 0xffu) << 23) * inv.y,
+                            az = __uint_as_float(((e >> 16) & 0xffu) << 23) * inv.z;
+                const float bx = fmaf(ox, inv.x, -ood.x), by = fmaf(oy, inv.y, -ood.y), bz = fmaf(oz, inv.z, -ood.z);
+                const uint32_t pa = __float_as_uint(rec.x), pb = __float_as_uint(rec.y);
+                const float lx = (float)(pa & 255u), ly = (float)((pa >> 8) & 255u), lz = (float)((pa >> 16) & 255u), hx = (float)(pa >> 24),
+                            hy = (float)(pb & 255u), hz = (float)((pb >> 8) & 255u);
+                const bool sx = inv.x < 0.0f, sy = inv.y < 0.0f, sz = inv.z < 0.0f;
+                const float tnx = fmaf(sx ? hx : lx, ax, bx), tfx = fmaf(sx ? lx : hx, ax, bx);
+                const float tny = fmaf(sy ? hy : ly, ay, by), tfy = fmaf(sy ? ly : hy, ay, by);
+                const float tnz = fmaf(sz ? hz : lz, az, bz), tfz = fmaf(sz ? lz : hz, az, bz);
+                const float t0 = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, kEps));
+                const float t1 = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+                hit = t0 <= t1 * 1.0000004f;
+                key = hit ? ((__float_as_uint(t0) & ~3u) | qr) : NONE;
+                cref = __float_as_uint(rec.z);
+            }
+            if (COUNT && (int)lane == __ffsll((long long)__ballot(1)) - 1) { cn.add(C_U_NODE_SLOTS, 64); cn.add(C_U_TAIL_SLOTS, 64); }
+            {
+                uint32_t km = min(key, quad_perm<kQXor1>(key));
+                km = min(km, quad_perm<kQRot2>(km));
+                const bool cont = hit && key == km;
+                uint32_t nx = cont ? cref : 0u;
+                nx |= quad_perm<kQXor1>(nx);
+                nx |= quad_perm<kQRot2>(nx);
+                if (internal) cur = km != NONE ? nx : NONE;   // the nearest hit child stays with the quad
+                const bool push = hit && !cont;
+                const unsigned long long pm = __ballot(push) & gm;
+                const int pos = sp + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                if (push) {
+                    if (pos < 64) bag[pos] = cref;
+                    else stack_push_slow(SPC_FAN_SPILL__, st.spill_entries, hb + pos - 64, cref, st.diag);
+                }
+                sp += (int)__popcll(pm);
+                if (sp > 64) { hb += sp - 64; sp = 64; }
+            }
+            // leaf part: lane r tests triangle r of the quad's leaf (one that was taken from the bag, or the nearest child just found)
+            bool occl = false;
+            if (en && cur != NONE && (cur & 0x80000000u) != 0u) {
+                const int tri = (int)((cur & 0x7fffffffu) >> 3) + (int)qr;
+                if ((int)qr < (int)(cur & 7u)) {
+                    const size_t base = (size_t)tri * 4;
+                    const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
+                    cn.add(C_TRI);
+                    if (COUNT) cn.add(C_U_TRI_LANES);
+                    float t, u, v;
+                    occl = tri_test(a, b, c, o, d, kEps, tmax, false, t, u, v);
+                }
+                cur = NONE;
+            }
+            if (COUNT && (int)lane == __ffsll((long long)__ballot(1)) - 1) cn.add(C_U_TRI_SLOTS, 64);
+            const bool blocked = (__ballot(occl) & gm) != 0ull;
+            const bool more = sp != 0 || hb != 0 || (__ballot(cur != NONE) & gm) != 0ull;
+            if (blocked || !more) {
+                live = false;
+                if (lane == gbase) s_vis[vis_slot] = blocked ? (uint8_t)0 : (uint8_t)1;
+            }
+#undef SPC_FAN_SPILL__
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // ---- wave-cooperative traversal: one closest-hit ray per lane + a pool of shadow rays -----------------------------------
 // Per iteration of the megakernel a wave has up to 64 closest-hit rays (the next path segments) and up to 192 shadow rays
 // (CONNECTION_N per eye vertex of the previous segment).  Neither depends on the other, so both are traced in ONE pass:
@@ -489,6 +654,8 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
         uint32_t* const q_spill = st.spill ? st.spill + ((long long)owner - (long long)lane) * (long long)st.spill_entries : nullptr;
         bool q_occluded = false, q_done = !has;
         while (__any(q_node != kTravDone)) {
+            // no closest-hit ray left: the shadow rays that remain need no order any more (fan_tail below)
+            if (SPC_FAN_TAIL && S.fan_tail && !__any(q_node != kTravDone && q_closest)) break;
             if (q_node != kTravDone) {
                 bool finished = false;
                 if (q_node >= 0) {
@@ -593,6 +760,9 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             }
         }
         (void)q_done;
+        if (SPC_FAN_TAIL && S.fan_tail && __any(q_node != kTravDone))
+            fan_tail<COUNT, BLOCK, STACK_LDS>(S, st, q_node != kTravDone, qo, qd, q_best, q_node == kTravDone ? 0xffffffffu : stack_word(q_node, q_leaf > 0 ? q_leaf : 0), q_sp, owner,
+                                              q_r, s_vis, list, cn);
     }
 }
 

@@ -111,7 +111,7 @@ struct DeviceScene {
     int32_t n_lights;        // QUAD lights, then the ENV light if the scene has an environment map
     int32_t n_mats;
     int32_t general;         // != 0: the scene has an environment map or a material with `brdf` set -> the timed kernels' ENV = true forms
-    int32_t pad_general;
+    int32_t fan_tail;        // != 0: the shadow rays of the quad tail fan out over the idle quads (device_lib.h: fan_tail)
     DEnv env;
 };
 

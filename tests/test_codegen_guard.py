@@ -29,10 +29,11 @@ PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 12809, "_ZN3
                          "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 14817, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 14006}   # profiles/r04c_*
 
 
-def _traversal_loops(lines, quad=False):
+def _traversal_loops(lines, quad=False, fan=False):
     """The traversal loop of a kernel -- the smallest loop around four global_load_dwordx4 in a row (SPC_NODE_STEP's node fetch) -- as
     [(instructions, scratch stores, scratch loads)]; with quad=True the quad tail's loop instead (the smallest loop that holds a
-    quad_perm DPP instruction and a global_load_dwordx4).  A loop = a backward branch; addresses come from the `// 0000000012AB:` column."""
+    quad_perm DPP instruction and a global_load_dwordx4, and no ds_bpermute); with fan=True the loop of fan_tail (the same WITH the
+    ds_bpermute of its regrouping).  A loop = a backward branch; addresses come from the `// 0000000012AB:` column."""
     addr = {}
     for i, l in enumerate(lines):
         m = re.search(r"//\s*([0-9A-Fa-f]{8,16}):", l)
@@ -50,8 +51,8 @@ def _traversal_loops(lines, quad=False):
     best = None   # the smallest loop around a four-quad fetch: the traversal iteration
     for a, b in loops:
         blk = lines[a:b + 1]
-        if quad:
-            ok = any("quad_perm" in x for x in blk) and any("global_load_dwordx4" in x for x in blk)
+        if quad or fan:
+            ok = any("quad_perm" in x for x in blk) and any("global_load_dwordx4" in x for x in blk) and any("ds_bpermute" in x for x in blk) == fan
         else:
             ok = any(all("global_load_dwordx4" in x for x in blk[j:j + 4]) for j in range(len(blk) - 3))
         if ok and (best is None or b - a < best[1] - best[0]):
@@ -94,7 +95,8 @@ def code_object(hip_lib, pkg, tmp_path_factory):
                 if "k_spcbpt" in cur:
                     body[cur].append(line)
         disasm.update({k: dict(instructions=n[k], packed=pk[k], traversal_loops=_traversal_loops(body[k]) if k in body else None,
-                              quad_tail_loop=_traversal_loops(body[k], quad=True) if k in body else None) for k in n})
+                              quad_tail_loop=_traversal_loops(body[k], quad=True) if k in body else None,
+                              fan_tail_loop=_traversal_loops(body[k], fan=True) if k in body else None) for k in n})
     assert meta, "no gfx950 code object with k_spcbpt found in the library"
     return meta, disasm
 
@@ -124,7 +126,11 @@ def test_timed_megakernel_resources(code_object, form):
     assert 600 <= size <= 800, report                                # 702-725 instructions per traversal iteration (node step + triangle step)
     # ... and the quad tail's loop (four lanes per ray: the loop around a DPP quad_perm and a single node-record fetch) spills nothing either
     tail = d["quad_tail_loop"]
-    assert tail and tail[0][1] == 0 and tail[0][2] == 0 and tail[0][0] <= 480, report   # 425-432 instructions (node + leaf step of up to 16 rays)
+    assert tail and tail[0][1] == 0 and tail[0][2] == 0 and tail[0][0] <= 500, report   # 441-457 instructions (node + leaf step of up to 16 rays)
+    # ... and fan_tail's (the tail's shadow rays on all the wave's quads): no store, and the two reloads are the HBM area's base in the rare
+    # paths that refill the bag from it or overflow into it
+    fan = d["fan_tail_loop"]
+    assert fan and fan[0][1] == 0 and fan[0][2] <= 2 and fan[0][0] <= 520, report        # 454-470 instructions, ~95 of them the regrouping
 
 
 def test_library_exports_only_the_c_abi(hip_lib, pkg):

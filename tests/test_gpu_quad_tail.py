@@ -12,13 +12,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _render(pkg, scene, W, H, lt, tup, no_tail, frames=3, batch=False, counters=False):
+def _render(pkg, scene, W, H, lt, tup, no_tail, frames=3, batch=False, counters=False, no_fan=False):
     if no_tail: os.environ["SPCBPT_NO_QUAD_TAIL"] = "1"
+    if no_fan: os.environ["SPCBPT_NO_FAN_TAIL"] = "1"
     if batch: os.environ["SPCBPT_EYE_BATCH"] = "4"
     try:
         r = pkg.Renderer(scene, 0)
     finally:
-        os.environ.pop("SPCBPT_NO_QUAD_TAIL", None); os.environ.pop("SPCBPT_EYE_BATCH", None)
+        os.environ.pop("SPCBPT_NO_QUAD_TAIL", None); os.environ.pop("SPCBPT_NO_FAN_TAIL", None); os.environ.pop("SPCBPT_EYE_BATCH", None)
     cam = scene.camera
     r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
     r.resize(W, H)
@@ -51,8 +52,10 @@ def test_quad_tail_leaves_every_film_bit_identical(gpu, pkg, name):
                        # slivers spanning the room: stacks run past their 16 LDS entries, so the tail pushes and pops the HBM part too
                        "needles": (pkg.scenes.needle_room(20000), 160, 120, (4000, 64, 1))}[name]
     _, off, tup = _render(pkg, scene, W, H, lt, None, True)
-    r_on, on, _ = _render(pkg, scene, W, H, lt, tup, False)
+    r_on, on, _ = _render(pkg, scene, W, H, lt, tup, False, no_fan=True)    # one quad per ray to the end
     assert np.isfinite(on).all() and np.array_equal(on, off), int((on != off).any(-1).sum())
+    _, fan, _ = _render(pkg, scene, W, H, lt, tup, False)                   # the default: shadow rays fan out over the idle quads
+    assert np.array_equal(fan, off), int((fan != off).any(-1).sum())
     _, b_on, _ = _render(pkg, scene, W, H, lt, tup, False, batch=True)
     assert np.array_equal(b_on, off)                                      # ... and in the batched kernel
 
@@ -63,7 +66,7 @@ def test_quad_tail_is_in_use_and_counts_the_same_events(gpu, pkg):
     scene = pkg.scenes.bedroom(target_tris=60000, tex_size=64)
     lt = (8000, 64, 1)
     r_off, off, tup = _render(pkg, scene, 256, 144, lt, None, True, frames=2, counters=True)
-    r_on, on, _ = _render(pkg, scene, 256, 144, lt, tup, False, frames=2, counters=True)
+    r_on, on, _ = _render(pkg, scene, 256, 144, lt, tup, False, frames=2, counters=True, no_fan=True)
     assert np.array_equal(on, off)
     c_off, c_on = r_off.counters(), r_on.counters()
     print({k: (c_on[k], c_off[k]) for k in c_on})
@@ -74,3 +77,23 @@ def test_quad_tail_is_in_use_and_counts_the_same_events(gpu, pkg):
     p_off, p_on = r_off.phase_clocks(), r_on.phase_clocks()
     assert p_on["node_lanes"] > 1.03 * p_off["node_lanes"]               # the tail's quads: four lanes per node visit
     assert p_on["node_slots"] <= p_off["node_slots"]
+
+
+def test_fan_tail_is_in_use_and_changes_only_the_order_of_visits(gpu, pkg):
+    """fan_tail (device_lib.h): a shadow ray's stack is a bag, so its nodes may be visited several at a time.  Rays, vertices and
+    connections are those of the ordered traversal exactly and so is the film; an unoccluded ray visits the same nodes, an occluded
+    one finds its occluder a few nodes earlier or later; the node-step iterations of the waves go DOWN (the point of it)."""
+    scene = pkg.scenes.bedroom(target_tris=60000, tex_size=64)
+    lt = (8000, 64, 1)
+    r_q, q, tup = _render(pkg, scene, 256, 144, lt, None, False, frames=2, counters=True, no_fan=True)
+    r_f, f, _ = _render(pkg, scene, 256, 144, lt, tup, False, frames=2, counters=True)
+    assert np.array_equal(f, q)
+    c_q, c_f = r_q.counters(), r_f.counters()
+    print({k: (c_f[k], c_q[k]) for k in c_f})
+    for k in ("closest_rays", "shadow_rays", "surface_vertices", "connections", "tree_nodes", "cmf_probes"):
+        assert c_f[k] == c_q[k], (k, c_f[k], c_q[k])
+    assert 0.97 * c_q["node_visits"] <= c_f["node_visits"] <= 1.05 * c_q["node_visits"], (c_f["node_visits"], c_q["node_visits"])
+    assert c_f["tri_tests"] <= 1.08 * c_q["tri_tests"], (c_f["tri_tests"], c_q["tri_tests"])
+    p_q, p_f = r_q.phase_clocks(), r_f.phase_clocks()
+    print("node-step iterations", p_f["node_slots"] // 64, p_q["node_slots"] // 64)
+    assert p_f["node_slots"] < 0.93 * p_q["node_slots"]

@@ -204,6 +204,7 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 // the wave processes leaves together, so the two code paths are not interleaved per iteration inside a divergent wave.
 static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_QUAD_TAIL
+#define SPC_ONE_FETCH 1
 #define SPC_QUAD_TAIL 1   // the last <= 16 rays of a pooled pass continue on four lanes each (trace_pool); 0 = the lane loop to the end
 #define SPC_FAN_TAIL 1    // ... and its shadow rays on as many quads as the wave has idle (fan_tail); 0 = one quad per ray to the end
 #endif
@@ -272,6 +273,10 @@ SPC_DEV uint32_t stack_word(int ref, int count) {
         const size_t nb__ = (size_t)node * NODE_QUADS;                                                                \
         const float4 Q0 = ldq(S.nodes, nb__ + 0), Q1 = ldq(S.nodes, nb__ + 1), Q2 = ldq(S.nodes, nb__ + 2),            \
                      Q3 = ldq(S.nodes, nb__ + 3);                                                                     \
+        SPC_NODE_STEP_Q(TMIN, TMAX, Q0, Q1, Q2, Q3);                                                                  \
+    } while (0)
+#define SPC_NODE_STEP_Q(TMIN, TMAX, Q0, Q1, Q2, Q3) /* ... on a node record that is already in registers */          \
+    do {                                                                                                              \
         cn.add(C_NODE); /* one 64-B visit */                                                                          \
         SPC_UTIL_COUNT(C_U_NODE_LANES, C_U_NODE_SLOTS)                                                                \
         const uint32_t ref__[4] = {__float_as_uint(Q2.z), __float_as_uint(Q2.w), __float_as_uint(Q3.x),               \
@@ -557,6 +562,23 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
     st.sp = 0;
     if (own) cn.add(C_CLOSEST);
     own_hit.t = 1e16f; own_hit.tri = -1; own_hit.u = own_hit.v = 0.0f;
+#if SPC_ONE_FETCH
+    // ONE gather per iteration, issued one step AHEAD: a lane on an internal node needs its 64-B node record, a lane on a leaf its
+    // 64-B triangle record -- the same four loads with another base.  The record of the NEXT step is requested as soon as the step
+    // that decides it is done, so the fetch is in flight while the finished lanes store their results and draw new rays (an LDS
+    // atomic and three dependent LDS reads) and the wave votes; an iteration waits for (what is left of) one round trip where the
+    // if-if schedule of rounds 1-3 waited for two in a row, node record then triangle.  A leaf that a node step reaches is tested in
+    // the next iteration: a lane advances one step per iteration.  Same steps, same order per ray: the films do not change.
+    static_assert(NODE_QUADS == 4, "node and triangle records are both four quads");
+    float4 R0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), R1 = R0, R2 = R0, R3 = R0;
+#define SPC_FETCH_STEP__()                                                                                            \
+    do {                                                                                                              \
+        const float* rp__ = node < 0 ? S.tris : S.nodes;                                                              \
+        const size_t rb__ = (size_t)(node < 0 ? ~node : node) * 4;                                                    \
+        R0 = ldq(rp__, rb__); R1 = ldq(rp__, rb__ + 1); R2 = ldq(rp__, rb__ + 2); R3 = ldq(rp__, rb__ + 3);           \
+    } while (0)
+    if (node != kTravDone) SPC_FETCH_STEP__();
+#endif
     while (true) {
         if (node == kTravDone && !done) {  // acquire the next shadow ray of the pool
             const uint32_t k = atomicAdd(s_next, 1u);
@@ -570,6 +592,9 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             best_t = rq.w - kEps;
             node = 0; st.sp = 0;
             cn.add(C_SHADOW);
+#if SPC_ONE_FETCH
+            SPC_FETCH_STEP__();   // the root
+#endif
             }
         }
         const unsigned long long live__ = __ballot(node != kTravDone);
@@ -584,6 +609,24 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                 cn.add(closest ? C_U_TAIL_CLOSEST : C_U_TAIL_SHADOW);
                 if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cn.add(C_U_TAIL_SLOTS, 64);
             }
+#if SPC_ONE_FETCH
+            // all sixteen dwords of the record fetched a step ago, here: without this the compiler narrows the four 16-B loads to what both
+            // kinds of step read and fetches the rest inside the branches, after the wait -- a second round trip
+            asm volatile("" : "+v"(R0.x), "+v"(R0.y), "+v"(R0.z), "+v"(R0.w), "+v"(R1.x), "+v"(R1.y), "+v"(R1.z), "+v"(R1.w));
+            asm volatile("" : "+v"(R2.x), "+v"(R2.y), "+v"(R2.z), "+v"(R2.w), "+v"(R3.x), "+v"(R3.y), "+v"(R3.z), "+v"(R3.w));
+            const bool at_leaf = node < 0;
+            if (!at_leaf) { SPC_NODE_STEP_Q(kEps, best_t, R0, R1, R2, R3); finished = node == kTravDone; }
+            else if (leaf_count <= 0) {
+                SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
+                finished = node == kTravDone;
+            } else {
+                const int tri = ~node;
+                const float4 a = R0, b = R1, c = R2;
+                cn.add(C_TRI);
+                SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)
+                const bool cull = closest && (__float_as_uint(R3.w) & 0x80000000u) != 0;  // single-sided emitters
+                float t, u, v;
+#else
             if (node >= 0) { SPC_NODE_STEP(kEps, best_t); finished = node == kTravDone; }
             if (node < 0 && leaf_count <= 0) {
                 SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
@@ -597,6 +640,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                 bool cull = false;
                 if (closest) cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;  // single-sided emitters
                 float t, u, v;
+#endif
                 const bool h = tri_test(a, b, c, o, d, kEps, best_t, cull, t, u, v);
                 if (h && !closest) {
                     occluded = true; finished = true; node = kTravDone;
@@ -607,6 +651,9 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                     if (leaf_count == 0) { SPC_TRAV_POP(); finished = node == kTravDone; }
                 }
             }
+#if SPC_ONE_FETCH
+            if (node != kTravDone) SPC_FETCH_STEP__();   // the next step's record
+#endif
             if (finished) {
                 if (closest) {
                     own_hit.t = best_t; own_hit.tri = best_tri; own_hit.u = best_u; own_hit.v = best_v;
@@ -618,6 +665,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             }
         }
     }
+#undef SPC_FETCH_STEP__
     if (SPC_QUAD_TAIL && quad_live != 0ull) {
         // ---- quad tail: the k-th ray still in flight continues on lanes 4 k .. 4 k + 3 -------------------------------------------
         // Lane r of a quad loads record r of the node (one coalesced 64-B line per ray), tests ITS child, and the four entry

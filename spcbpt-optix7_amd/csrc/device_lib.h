@@ -315,8 +315,10 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     int leaf_count = 0;  // triangles left in the current leaf
     while (node != kTravDone) {
         if (node >= 0) SPC_NODE_STEP(tmin, best_t);
-        // (a single 64-B fetch per iteration serving node OR triangle lanes was measured: 14.0 ms vs 11.1 ms per frame --
-        // a lane that reaches a leaf then waits a whole iteration for its first triangle)
+        // (A single 64-B fetch per iteration serving node OR triangle lanes loses HERE, where every lane follows one ray to its end:
+        // round 1 14.0 against 11.1 ms per frame; round 4, fetched a step ahead: pt frame 4.29 -> 4.43 ms, light pass 1.13 -> 1.16 ms --
+        // a lane that reaches a leaf waits a whole iteration for its first triangle.  It WINS in trace_pool, whose triangle step runs
+        // at a tenth of the lanes in 83 % of the iterations: see SPC_ONE_FETCH there.)
         if (node < 0 && leaf_count <= 0) {
             SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
         } else if (node < 0) {

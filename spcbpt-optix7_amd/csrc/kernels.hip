@@ -303,22 +303,62 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                         f_lvc = D.lvc; f_subspace = D.subspace; f_cmfs = D.cmfs; f_jump = D.jump; f_path_count = D.sampler_counts[1];
                         f_counts = D.sampler_counts;
                     }
+                    // Three stages, each over all CONNECTION_N connections, so that what does not depend on each other is in flight together:
+                    // (1) per connection, in order (the random numbers are one stream, and an empty subspace draws none for its second stage):
+                    //     the light subspace and its record; (2) the bisections of sampleSecondStage side by side -- one round trip per level
+                    //     for the three of them instead of three; (3) the sampled slots, the light vertices' position quads and the rays.
+                    float pmf1_[SPCBPT_CONNECTION_N], pmf2_[SPCBPT_CONNECTION_N], u2_[SPCBPT_CONNECTION_N];
+                    int lslot_[SPCBPT_CONNECTION_N], bias_[SPCBPT_CONNECTION_N], size_[SPCBPT_CONNECTION_N];
 #pragma unroll
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                        float pmf1 = 1.0f, pmf2;
-                        float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
-                        int lslot = -1;
+                        pmf1_[it] = 1.0f; pmf2_[it] = 0.0f; u2_[it] = 0.0f; lslot_[it] = -1; bias_[it] = 0; size_[it] = 0;
                         if (p.uniform_lvc) {   // the comparator of BASELINE config 5: uniformSample (cuProg.h:283-289), one random number
                             const int vc = f_counts[0];
-                            if (vc > 0) lslot = uniform_sample(f_jump, vc, w.seed, pmf2);
+                            if (vc > 0) lslot_[it] = uniform_sample(f_jump, vc, w.seed, pmf2_[it]);
                         } else {
-                            const int l = sample_first_stage<COUNT, CACHE>(p, cur.sub, w.seed, pmf1, cn);
+                            const int l = sample_first_stage<COUNT, CACHE>(p, cur.sub, w.seed, pmf1_[it], cn);
                             const DSubspace ss = f_subspace[l];
-                            if (ss.size != 0) {
-                                const int k = binary_sample(f_cmfs + ss.jump_bias, ss.size, w.seed, pmf2, cn);
-                                lslot = f_jump[ss.jump_bias + k];
+                            if (ss.size != 0) { bias_[it] = ss.jump_bias; size_[it] = ss.size; u2_[it] = rnd(w.seed); }
+                        }
+                    }
+                    {   // binary_sample (cuProg.h:245-264) of the three, level by level
+                        int lo_[SPCBPT_CONNECTION_N], hi_[SPCBPT_CONNECTION_N], mid_[SPCBPT_CONNECTION_N];
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lo_[it] = 0; hi_[it] = size_[it]; mid_[it] = size_[it] / 2 - 1; }
+                        bool any_open = false;
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) any_open = any_open || hi_[it] - lo_[it] > 1;
+                        while (any_open) {
+                            float v_[SPCBPT_CONNECTION_N];
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) v_[it] = hi_[it] - lo_[it] > 1 ? f_cmfs[bias_[it] + mid_[it]] : 0.0f;
+                            any_open = false;
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                                if (hi_[it] - lo_[it] > 1) {
+                                    cn.add(C_CMF);
+                                    if (u2_[it] < v_[it]) hi_[it] = mid_[it] + 1;
+                                    else lo_[it] = mid_[it] + 1;
+                                    mid_[it] = (lo_[it] + hi_[it]) / 2 - 1;
+                                }
+                                any_open = any_open || hi_[it] - lo_[it] > 1;
                             }
                         }
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                            if (size_[it] != 0) {
+                                const float* cmf = f_cmfs + bias_[it];
+                                const int k = lo_[it];
+                                pmf2_[it] = k == 0 ? cmf[k] : cmf[k] - cmf[k - 1];
+                                lslot_[it] = f_jump[bias_[it] + k];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                        const float pmf1 = pmf1_[it], pmf2 = pmf2_[it];
+                        const int lslot = lslot_[it];
+                        float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
                         if (lslot >= 0) {
                             w_slot[it * 64 + lane] = lslot;
                             cn.add(C_CONN);

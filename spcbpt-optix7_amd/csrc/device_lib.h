@@ -605,8 +605,8 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
         // pass is the tail that used to run these iterations at a fifth of the lanes.  Hand each ray to FOUR lanes (quad tail below).
         if (SPC_QUAD_TAIL && S.nodes_q && __popcll(live__) <= 16 && __any(done)) { quad_live = live__; break; }
         const bool tail = COUNT && __any(done);   // (counting build) some lane found the pool empty: what follows is the pass's tail
+        bool finished = false, occluded = false;
         if (node != kTravDone) {
-            bool finished = false, occluded = false;
             if (COUNT && tail && node >= 0) {
                 cn.add(closest ? C_U_TAIL_CLOSEST : C_U_TAIL_SHADOW);
                 if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cn.add(C_U_TAIL_SLOTS, 64);
@@ -653,17 +653,17 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                     if (leaf_count == 0) { SPC_TRAV_POP(); finished = node == kTravDone; }
                 }
             }
+        }
 #if SPC_ONE_FETCH
-            if (node != kTravDone) SPC_FETCH_STEP__();   // the next step's record
+        if (node != kTravDone) SPC_FETCH_STEP__();   // the next step's record: ONE request site after the step, outside its branches
 #endif
-            if (finished) {
-                if (closest) {
-                    own_hit.t = best_t; own_hit.tri = best_tri; own_hit.u = best_u; own_hit.v = best_v;
-                    closest = false;
-                    best_tri = -1;
-                } else {
-                    s_vis[r] = occluded ? (uint8_t)0 : (uint8_t)1;
-                }
+        if (finished) {
+            if (closest) {
+                own_hit.t = best_t; own_hit.tri = best_tri; own_hit.u = best_u; own_hit.v = best_v;
+                closest = false;
+                best_tri = -1;
+            } else {
+                s_vis[r] = occluded ? (uint8_t)0 : (uint8_t)1;
             }
         }
     }

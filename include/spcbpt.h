@@ -347,8 +347,8 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
  * resampling (part of [2], summed over the lanes that sample); [10..13] 100 MHz wall clock of the megakernel's waves: earliest
  * start, latest end, sum of ends, number of waves (how long the last waves run alone); [14..16] the tail of the pooled traversal
  * pass, i.e. its node steps after the wave's ray pool ran dry: slots (64 x iterations), lanes still on a closest-hit ray, lanes on
- * a shadow ray. */
-int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[17]);
+ * a shadow ray; [17..18] the connection evaluations of the connect phase: slots (64 x rounds of its job loop) and jobs. */
+int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[19]);
 /* Hash of the sources this library was built from (csrc/source_hash.py); the Python mirror refuses a stale library. */
 const char* spcbpt_build_source_hash(void);
 /* sizeof of the structs of this header as the library was COMPILED, in declaration order: material, texture, quad_light,

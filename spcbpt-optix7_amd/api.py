@@ -847,10 +847,10 @@ class Renderer:
         return c.as_dict()
 
     def phase_clocks(self):
-        out = (C.c_uint64 * 17)()
+        out = (C.c_uint64 * 19)()
         self._chk(self.lib.spcbpt_debug_phase_clocks(self.h, out), "debug_phase_clocks")
         return dict(zip(("regen", "closest", "shade", "shadow_pool", "connect", "node_slots", "node_lanes", "tri_slots", "tri_lanes", "sample_lane_clocks",
-                         "wave_start_min", "wave_end_max", "wave_end_sum", "waves", "tail_slots", "tail_closest_lanes", "tail_shadow_lanes"),
+                         "wave_start_min", "wave_end_max", "wave_end_sum", "waves", "tail_slots", "tail_closest_lanes", "tail_shadow_lanes", "job_slots", "job_lanes"),
                         [int(v) for v in out]))
 
     def set_connection_sampler(self, mode: int):

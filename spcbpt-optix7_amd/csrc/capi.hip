@@ -1518,7 +1518,7 @@ int spcbpt_get_counters(spcbpt_ctx* c, spcbpt_counters* o) {
     o->eye_paths = h[C_EYE]; o->light_paths = h[C_LIGHT];
     return SPCBPT_OK;
 }
-int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[17]) {
+int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[19]) {
     CTX_CHECK(c);
     if (!out) return SPCBPT_ERR_INVALID_ARG;
     unsigned long long h[C_COUNT];
@@ -1527,7 +1527,7 @@ int spcbpt_debug_phase_clocks(spcbpt_ctx* c, uint64_t out[17]) {
     for (int i = 0; i < 5; i++) out[i] = h[C_PUBLIC + i] << 4;
     for (int i = 5; i < 9; i++) out[i] = h[C_PUBLIC + i];
     out[9] = h[C_T_SAMPLE] << 4;
-    out[10] = h[C_W_START_MIN]; out[11] = h[C_W_END_MAX]; out[12] = h[C_W_END_SUM]; out[13] = h[C_W_WAVES]; out[14] = h[C_U_TAIL_SLOTS]; out[15] = h[C_U_TAIL_CLOSEST]; out[16] = h[C_U_TAIL_SHADOW];  // summed over lanes (every lane that samples adds its own clock delta)
+    out[10] = h[C_W_START_MIN]; out[11] = h[C_W_END_MAX]; out[12] = h[C_W_END_SUM]; out[13] = h[C_W_WAVES]; out[14] = h[C_U_TAIL_SLOTS]; out[15] = h[C_U_TAIL_CLOSEST]; out[16] = h[C_U_TAIL_SHADOW]; out[17] = h[C_U_JOB_SLOTS]; out[18] = h[C_U_JOB_LANES];  // summed over lanes (every lane that samples adds its own clock delta)
     return SPCBPT_OK;
 }
 int spcbpt_reset_counters(spcbpt_ctx* c) {

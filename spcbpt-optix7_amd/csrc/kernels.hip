@@ -218,6 +218,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     const bool job = j < n_jobs;
                     const uint32_t slot = job ? w_job[j] : 0u, owner = slot & 63u;
                     const f3 ownerR3 = mk3(__shfl(cur.R3.x, (int)owner, 64), __shfl(cur.R3.y, (int)owner, 64), __shfl(cur.R3.z, (int)owner, 64));
+                    if (COUNT) { if (job) cn.add(C_U_JOB_LANES); if (lane == 0) cn.add(C_U_JOB_SLOTS, 64); }
                     if (!job) continue;
                     const uint32_t* col = w_stack + owner;
                     const float4 po = w_org[owner];

@@ -97,6 +97,7 @@ enum CounterSlot {
     C_T_SAMPLE,  // part of C_T_SHADE spent in the two-stage resampling
     C_W_START_MIN, C_W_END_MAX, C_W_END_SUM, C_W_WAVES,  // wall-clock (100 MHz) start/end of the megakernel's waves: tail analysis
     C_U_TAIL_SLOTS, C_U_TAIL_CLOSEST, C_U_TAIL_SHADOW,  // node steps of the pooled pass after the wave's pool ran dry: 64 x iterations, lanes by kind of ray
+    C_U_JOB_SLOTS, C_U_JOB_LANES,  // connection evaluations (the job loop of the connect phase): 64 x rounds, jobs
     C_COUNT
 };
 

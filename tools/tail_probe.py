@@ -23,3 +23,4 @@ print("node util", ph["node_lanes"] / ph["node_slots"], "tri util", ph["tri_lane
 print("tail share of node slots", ph["tail_slots"] / ph["node_slots"], "tail util", (ph["tail_closest_lanes"] + ph["tail_shadow_lanes"]) / max(ph["tail_slots"], 1),
       "closest share of tail lanes", ph["tail_closest_lanes"] / max(ph["tail_closest_lanes"] + ph["tail_shadow_lanes"], 1))
 print("node iterations per frame", ph["node_slots"] / 64, "tri iterations", ph["tri_slots"] / 64)
+print("connect phase: jobs per round of 64", ph["job_lanes"] / max(ph["job_slots"] / 64, 1), "rounds per frame", ph["job_slots"] / 64, "jobs per eye path", ph["job_lanes"] / (W * H))

@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--light-batch", type=int, default=-1,
                     help="1: the light passes of a batch of frames as ONE persistent launch too (spcbpt_launch_light_batch), a batch ahead; "
                          "0: one launch per pass (a pass is a ~1.2 ms dependent chain however few paths a rank traces; a batch of them in one thin, long-lived grid costs the eye kernels beside it less)")
+    ap.add_argument("--build-batch", type=int, default=1, help="1 (default): the sampler builds of a batch of frames as one set of four launches (spcbpt_build_sampler_batch); 0: one build per step")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
     ap.add_argument("--exchange-batch", type=int, default=1, help="1 (default): ONE all-gather per light batch (spcbpt_comm_exchange_lvc_batch); 0: one exchange per frame")
@@ -356,20 +357,29 @@ def main():
                 r.sync_light()
             if not (lbatch and xbatch):
                 comm.exchange_lvc()            # queues the all-gather + compaction on the communicator's stream; no host wait
-        r.build_sampler()
-        if isolate and (batch == 1 or len(queued) == batch - 1):
+        if not bbatch:
+            r.build_sampler()
+        if isolate and not bbatch and (batch == 1 or len(queued) == batch - 1):
             r.sync()                           # roofline pass: the light pass launched above must not share the GPU with the eye kernel
         if batch == 1:
             r.launch("SPCBPT_eye", f, rows)
         else:                                  # one persistent eye kernel per `batch` frames (tile queue spans the frames)
             queued.append(f)
             if len(queued) == batch:
-                flush()
+                flush(isolate)
 
     queued = []
+    # the sampler builds of a batch of frames as ONE set of four launches (spcbpt_build_sampler_batch), issued with the eye launch that
+    # needs them: every step still has its build, but 20 builds in a row are 80 small dependent launches in front of a kernel that
+    # cannot start before the last (2.4 ms of the 86 a 20-step run takes)
+    bbatch = lbatch and args.build_batch != 0 and (comm is None or xbatch)   # (a per-frame exchange addresses the oldest UNBUILT pass: its build cannot wait)
 
-    def flush():
+    def flush(isolate=False):
         if queued:
+            if bbatch:
+                r.build_sampler_batch(len(queued))
+                if isolate:
+                    r.sync()
             r.launch_eye_batch(queued, rows)
             queued.clear()
 

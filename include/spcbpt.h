@@ -448,6 +448,13 @@ int spcbpt_launch_eye_batch(spcbpt_ctx* ctx, int n_frames, const uint32_t* subfr
  * pass still takes the ~1.2 ms of its longest path, and beside the eye grid they run one after the other; in one queue they cost
  * about one full-size pass.  n_frames <= 32 (SPCBPT_ERR_INVALID_ARG), SPCBPT_ERR_STATE without light-ahead mode. */
 int spcbpt_launch_light_batch(spcbpt_ctx* ctx, uint32_t first_frame, int n_frames);
+/* Batched sampler build (no reference counterpart): n_builds spcbpt_build_sampler calls -- the n_builds OLDEST queued light
+ * passes -- with the kernels of ONE build (the frame in the grid's second dimension).  Same tables, same state afterwards; what
+ * goes is the chain of 4 x n_builds small dependent launches in front of a batched eye launch that cannot start before the last
+ * of them (0.12 ms per build on the bench scene).  Sets that need more than the plain build (a gathered import with its totals
+ * on the device, SPCBPT_SAMPLER_BUILD=hipcub) are built one by one, as if spcbpt_build_sampler had been called n_builds times.
+ * 1 <= n_builds <= 32 (SPCBPT_ERR_INVALID_ARG). */
+int spcbpt_build_sampler_batch(spcbpt_ctx* ctx, int n_builds);
 
 /* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain
  * however few paths a rank traces, and the LVC exchange makes the host wait for it; with on != 0 the host may launch frame

@@ -487,6 +487,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_set_light_trace": [vp, C.POINTER(LightTraceParams)],
         "spcbpt_launch": [vp, C.c_char_p, u32, i32, i32, i32],
         "spcbpt_build_sampler": [vp],
+        "spcbpt_build_sampler_batch": [vp, C.c_int],
         "spcbpt_launch_eye_batch": [vp, i32, C.POINTER(u32), i32, i32, i32],
         "spcbpt_launch_light_batch": [vp, u32, i32],
         "spcbpt_lvc_export": [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32)],
@@ -575,7 +576,7 @@ def load_library(path: str = LIB_PATH):
 
 EXPORTED_SYMBOLS = [
     "spcbpt_create", "spcbpt_destroy", "spcbpt_last_error", "spcbpt_set_camera", "spcbpt_set_camera_lookat",
-    "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_launch_light_batch", "spcbpt_build_sampler",
+    "spcbpt_resize", "spcbpt_set_subspace", "spcbpt_set_light_trace", "spcbpt_launch", "spcbpt_launch_eye_batch", "spcbpt_launch_light_batch", "spcbpt_build_sampler", "spcbpt_build_sampler_batch",
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_debug_trace_bench",
@@ -687,6 +688,10 @@ class Renderer:
 
     def build_sampler(self):
         self._chk(self.lib.spcbpt_build_sampler(self.h), "build_sampler")
+
+    def build_sampler_batch(self, n: int):
+        """n build_sampler calls (the n oldest queued light passes) as one set of four launches (spcbpt_build_sampler_batch)."""
+        self._chk(self.lib.spcbpt_build_sampler_batch(self.h, int(n)), "build_sampler_batch")
 
     def sync(self):
         self._chk(self.lib.spcbpt_sync(self.h), "sync")

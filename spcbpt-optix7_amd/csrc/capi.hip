@@ -677,6 +677,71 @@ int Context::build_sampler() {
     return 0;
 }
 
+// LVC_Process for the n OLDEST light passes that have no sampler yet, as ONE set of four launches (kernels.hip: SamplerBuildBatch).
+// The tables are those of n build_sampler calls -- the same kernels with the frame in blockIdx.y -- and the sets end up in the same
+// state; what goes is n - 1 times the four dependent launches (0.12 ms per build: 2.4 ms in front of a 20-frame eye launch that
+// cannot start before the last of them).  Falls back to n single builds where a set needs what only that path does: a gathered
+// import whose totals live on the device, the radix-sort build, a cache whose counts the host has to read back.
+int Context::build_sampler_batch(int n) {
+    if (n < 1 || n > kMaxBatchFrames) { error = "build_sampler_batch: 1 .. 32 builds per call"; return SPCBPT_ERR_INVALID_ARG; }
+    bool plain = counting_build && n > 1 && d_lvc && (int)pending.size() >= n;
+    for (int k = 0; plain && k < n; k++) {
+        const int b = pending[(size_t)k];
+        if (set_bound[b] >= 0 || !(set_count_host[b] >= 0 || light_counts_valid[b])) plain = false;
+    }
+    if (!plain) {
+        for (int k = 0; k < n; k++) { const int rc = build_sampler(); if (rc) return rc; }
+        return 0;
+    }
+    if (!sbb_keys || sbb_frames < n || sbb_capacity < lvc_capacity) {   // scratch of the batch: per frame what d_keys / d_weights / d_wsorted / d_hist are to one build
+        if (sync_all()) return SPCBPT_ERR_HIP;
+        dev_free(sbb_keys); dev_free(sbb_weights); dev_free(sbb_wsorted); dev_free(sbb_hist);
+        sbb_keys = nullptr; sbb_weights = nullptr; sbb_wsorted = nullptr; sbb_hist = nullptr;
+        const int frames = std::max(n, std::min((int)kMaxBatchFrames, std::max(eye_batch, n)));
+        HIP_TRY(this, dev_alloc(&sbb_keys, (size_t)frames * lvc_capacity)); HIP_TRY(this, dev_alloc(&sbb_weights, (size_t)frames * lvc_capacity));
+        HIP_TRY(this, dev_alloc(&sbb_wsorted, (size_t)frames * lvc_capacity)); HIP_TRY(this, dev_alloc(&sbb_hist, (size_t)frames * sampler_build_hist_ints()));
+        sbb_frames = frames; sbb_capacity = lvc_capacity;
+    }
+    SamplerBuildBatch B = {};
+    B.keys = sbb_keys; B.weights = sbb_weights; B.wsorted = sbb_wsorted; B.hist = sbb_hist; B.item_stride = lvc_capacity;
+    int sets[kMaxBatchFrames];
+    for (int k = 0; k < n; k++) {
+        const int b = pending[(size_t)k];
+        sets[k] = b;
+        if (light_lane_of_set[b] != 0 && light_counts_valid[b]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_light[b], 0));   // traced on the second lane
+        int count = set_count_host[b];
+        if (count < 0) {   // the light pass left (vertex_count, path_count) in pinned memory
+            HIP_TRY(this, hipEventSynchronize(ev_light[b]));
+            count = h_light_counts[2 * b];
+        }
+        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = nullptr; B.path_count[k] = set_counts[b] + 1;
+        B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b];
+        HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));   // the build counts the paths on its way (as build_sampler does)
+    }
+    time_begin("sampler_build");
+    launch_sampler_build_batch(B, n, stream);
+    time_end();
+    HIP_TRY(this, hipGetLastError());
+    keys_ready = false;
+    for (int k = 0; k < n; k++) {
+        const int b = sets[k];
+        eset = b;
+        HIP_TRY(this, hipEventRecord(ev_sampler[b], stream));
+        ev_sampler_set[b] = true;
+        HIP_TRY(this, hipEventRecord(ev_set_stream[b], stream));
+        ev_set_touched[b] = true;
+        for (auto it = built_sets.begin(); it != built_sets.end();) it = (*it == b) ? built_sets.erase(it) : it + 1;
+        built_sets.push_back(b);
+        while ((int)built_sets.size() > kMaxBatchFrames) built_sets.pop_front();
+        if (!pending.empty() && pending.front() == b) pending.pop_front();
+    }
+    have_sampler = true;
+    lvc_count = B.n_host[n - 1];   // the members describe the set built last, as after build_sampler
+    if (light_counts_valid[sets[n - 1]] && set_count_host[sets[n - 1]] < 0) path_count = h_light_counts[2 * sets[n - 1] + 1];
+    select_set(lset);
+    return 0;
+}
+
 // The oldest pending light pass's shard for an exchange that runs on the caller's stream `xs`: instead of the host waiting for
 // the pass (spcbpt_sync_light), `xs` waits for it on the device.
 int Context::export_on(hipStream_t xs, void** dv, void** dc, int* cap) {
@@ -903,10 +968,12 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     eset = sets[n - 1];
     // the frames' merges, in frame order, after the previous launch's merge
     if (last_merge_k >= 0 && last_merge_k != rk && rstreams[last_merge_k] != rstream) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_merge[last_merge_k], 0));
-    for (int k = 0; k < n; k++) {
-        kp.subframe = subframes[k];
-        kp.result = d_result_b[rk][k];
-        launch_film_merge(kp, rstream);
+    {   // ... as one pass over the pixels (kernels.hip: k_film_merge_batch -- the operations of n merges, per pixel in frame order)
+        MergeBatch mb = {};
+        for (int k = 0; k < n; k++) { mb.result[k] = d_result_b[rk][k]; mb.subframe[k] = subframes[k]; }
+        kp.subframe = subframes[n - 1];
+        kp.result = d_result_b[rk][0];
+        launch_film_merge_batch(kp, mb, n, rstream);
         HIP_TRY(this, hipGetLastError());
     }
     kp.frames = nullptr; kp.n_frames = 0;
@@ -983,6 +1050,7 @@ Context::~Context() {
     for (int s2 = 0; s2 < kMaxRender; s2++) for (int g2 = 0; g2 < kDescRing; g2++) if (ev_desc[s2][g2]) (void)hipEventDestroy(ev_desc[s2][g2]);
     dev_free(b_scratch); dev_free(b_core_counts); dev_free(b_core_offsets); dev_free(b_keys); dev_free(b_vals); dev_free(b_weights); dev_free(b_temp); dev_free(b_spill);
     if (lstream_b) (void)hipStreamDestroy(lstream_b); dev_free(d_spill); dev_free(d_temp); dev_free(d_hist);
+    dev_free(sbb_keys); dev_free(sbb_weights); dev_free(sbb_wsorted); dev_free(sbb_hist);
     for (int s = 0; s < kMaxRender; s++) {
         if (rstreams[s] && rstreams[s] != stream) (void)hipStreamDestroy(rstreams[s]);
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
@@ -1337,6 +1405,10 @@ int spcbpt_launch_eye_batch(spcbpt_ctx* c, int n_frames, const uint32_t* subfram
     return c->launch_eye_batch(n_frames, subframes, r0, r1, rs);
 }
 
+int spcbpt_build_sampler_batch(spcbpt_ctx* c, int n_builds) {
+    CTX_CHECK(c);
+    return c->build_sampler_batch(n_builds);
+}
 int spcbpt_launch_light_batch(spcbpt_ctx* c, uint32_t first_frame, int n_frames) {
     CTX_CHECK(c);
     return c->launch_light_batch(first_frame, n_frames);

@@ -207,6 +207,9 @@ struct Context {
     int fetch_counts();           // counts of the latest light pass's set (lset) -> lvc_count, path_count
     int fetch_counts_of(int set);
     int build_sampler();
+    int build_sampler_batch(int n);   // the n oldest pending passes in one set of four launches (capi.hip)
+    uint32_t* sbb_keys = nullptr; float* sbb_weights = nullptr; double* sbb_wsorted = nullptr; int* sbb_hist = nullptr;   // its scratch: per frame what d_keys .. d_hist are
+    int sbb_frames = 0; size_t sbb_capacity = 0;
     int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis = false, bool defer_merge = false);
     // spcbpt_launch_deferred: a render launch whose film merge (running mean + tone map from its `result` buffer) has not been queued:
     // the frame is either merged later (merge_deferred(true)) or never (false) -- the interactive loop's speculative next frame

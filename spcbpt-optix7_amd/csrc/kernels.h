@@ -26,9 +26,21 @@ void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys
 void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, const CompactBatch& dst, int nf,
                            int* overflow, hipStream_t s);
 void launch_pack_shards(const CompactBatch& src, int nf, int cap, LightVertex* send, int* send_counts, hipStream_t s);
+// the film merges of the frames of a batched eye launch, in frame order, as one pass over the pixels
+struct MergeBatch { const float* result[kMaxBatchFrames]; uint32_t subframe[kMaxBatchFrames]; };
+void launch_film_merge_batch(const KParams& p, const MergeBatch& m, int frames, hipStream_t s);
 void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s);
 // the sampler build as one stable counting sort (four launches): kernels.hip "sampler build in four launches"
 size_t sampler_build_hist_ints();
+// ... of up to kMaxBatchFrames caches at once (blockIdx.y = frame): what differs per frame, and the scratch the frames share --
+// frame f uses keys / weights / wsorted + f * item_stride and hist + f * sampler_build_hist_ints()
+struct SamplerBuildBatch {
+    const LightVertex* lvc[kMaxBatchFrames]; const int* n_dev[kMaxBatchFrames]; int* path_count[kMaxBatchFrames];
+    DSubspace* sub[kMaxBatchFrames]; uint32_t* jump[kMaxBatchFrames]; float* cmfs[kMaxBatchFrames];
+    int n_host[kMaxBatchFrames];
+    uint32_t* keys; float* weights; int* hist; double* wsorted; size_t item_stride;
+};
+void launch_sampler_build_batch(const SamplerBuildBatch& b, int frames, hipStream_t s);
 void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
                           uint32_t* jump, double* wsorted, float* cmfs, hipStream_t s);
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s);

@@ -995,8 +995,16 @@ __global__ void k_cmf(const double* __restrict__ prefix, const uint32_t* __restr
 // Same tables as the sort: the order inside a subspace is the cache order (stable), empty subspaces carry the running offset.
 // The CMF sums a subspace's weights by themselves (the scan above takes differences of a global prefix): equal to 1e-16 relative.
 static constexpr int SB_BLOCKS = 512;
-__global__ __launch_bounds__(64) void k_sb_hist(const LightVertex* __restrict__ lvc, int n_host, const int* __restrict__ n_dev, uint32_t* __restrict__ keys,
-                                                float* __restrict__ weights, int* __restrict__ hist, int* __restrict__ path_count) {
+// (blockIdx.y = frame of a batched build: SamplerBuildBatch, kernels.h; a single build is a batch of one)
+__global__ __launch_bounds__(64) void k_sb_hist(const SamplerBuildBatch B) {
+    const int f = blockIdx.y;
+    const LightVertex* __restrict__ lvc = B.lvc[f];
+    const int n_host = B.n_host[f];
+    const int* __restrict__ n_dev = B.n_dev[f];
+    uint32_t* __restrict__ keys = B.keys + (size_t)f * B.item_stride;
+    float* __restrict__ weights = B.weights + (size_t)f * B.item_stride;
+    int* __restrict__ hist = B.hist + (size_t)f * (SB_BLOCKS + 1) * 1024;
+    int* __restrict__ path_count = B.path_count[f];
     __shared__ uint32_t h[1024];
     const int lane = threadIdx.x, b = blockIdx.x;
 #pragma unroll
@@ -1023,7 +1031,9 @@ __global__ __launch_bounds__(64) void k_sb_hist(const LightVertex* __restrict__ 
         if (lane == 0 && starts) atomicAdd(path_count, starts);
     }
 }
-__global__ __launch_bounds__(1024) void k_sb_scan(int* __restrict__ hist, DSubspace* __restrict__ sub) {
+__global__ __launch_bounds__(1024) void k_sb_scan(const SamplerBuildBatch B) {
+    int* __restrict__ hist = B.hist + (size_t)blockIdx.y * (SB_BLOCKS + 1) * 1024;
+    DSubspace* __restrict__ sub = B.sub[blockIdx.y];
     // thread = subspace id.  hist[b][id] becomes the number of items with that id in the blocks before b; row SB_BLOCKS receives the
     // position of the id's first item = items with smaller ids: for an empty subspace the end of the last non-empty one before it,
     // the running offset of the reference's host loop (device_thrust.cu:301-309)
@@ -1048,8 +1058,15 @@ __global__ __launch_bounds__(1024) void k_sb_scan(int* __restrict__ hist, DSubsp
     hist[(size_t)SB_BLOCKS * 1024 + k] = base;
     if (k < SPCBPT_NUM_SUBSPACE) { sub[k].jump_bias = base; sub[k].size = run; sub[k].sum_pmf = 0.0f; sub[k].pad = 0; }
 }
-__global__ __launch_bounds__(64) void k_sb_scatter(const uint32_t* __restrict__ keys, const float* __restrict__ weights, int n_host, const int* __restrict__ n_dev,
-                                                   const int* __restrict__ hist, uint32_t* __restrict__ jump, double* __restrict__ wsorted) {
+__global__ __launch_bounds__(64) void k_sb_scatter(const SamplerBuildBatch B) {
+    const int f = blockIdx.y;
+    const uint32_t* __restrict__ keys = B.keys + (size_t)f * B.item_stride;
+    const float* __restrict__ weights = B.weights + (size_t)f * B.item_stride;
+    const int n_host = B.n_host[f];
+    const int* __restrict__ n_dev = B.n_dev[f];
+    const int* __restrict__ hist = B.hist + (size_t)f * (SB_BLOCKS + 1) * 1024;
+    uint32_t* __restrict__ jump = B.jump[f];
+    double* __restrict__ wsorted = B.wsorted + (size_t)f * B.item_stride;
     __shared__ uint32_t next[1024];   // where this block's next item of each id goes
     const int lane = threadIdx.x, b = blockIdx.x;
 #pragma unroll
@@ -1082,7 +1099,10 @@ __global__ __launch_bounds__(64) void k_sb_scatter(const uint32_t* __restrict__ 
         }
     }
 }
-__global__ __launch_bounds__(256) void k_sb_cmf(DSubspace* __restrict__ sub, const double* __restrict__ wsorted, float* __restrict__ cmfs) {
+__global__ __launch_bounds__(256) void k_sb_cmf(const SamplerBuildBatch B) {
+    DSubspace* __restrict__ sub = B.sub[blockIdx.y];
+    const double* __restrict__ wsorted = B.wsorted + (size_t)blockIdx.y * B.item_stride;
+    float* __restrict__ cmfs = B.cmfs[blockIdx.y];
     __shared__ double sh[256];
     const int k = blockIdx.x, t = threadIdx.x;
     const int b = sub[k].jump_bias, sz = sub[k].size;
@@ -1118,12 +1138,19 @@ __global__ __launch_bounds__(256) void k_sb_cmf(DSubspace* __restrict__ sub, con
     if (t == 0) sub[k].sum_pmf = (float)total;
 }
 size_t sampler_build_hist_ints() { return (size_t)(SB_BLOCKS + 1) * 1024; }
+void launch_sampler_build_batch(const SamplerBuildBatch& b, int frames, hipStream_t s) {
+    if (frames <= 0) return;
+    hipLaunchKernelGGL(k_sb_hist, dim3(SB_BLOCKS, frames), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_sb_scan, dim3(1, frames), dim3(1024), 0, s, b);
+    hipLaunchKernelGGL(k_sb_scatter, dim3(SB_BLOCKS, frames), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_sb_cmf, dim3(SPCBPT_NUM_SUBSPACE, frames), dim3(256), 0, s, b);
+}
 void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
                           uint32_t* jump, double* wsorted, float* cmfs, hipStream_t s) {
-    hipLaunchKernelGGL(k_sb_hist, dim3(SB_BLOCKS), dim3(64), 0, s, lvc, n_host, n_dev, keys, weights, hist, path_count);
-    hipLaunchKernelGGL(k_sb_scan, dim3(1), dim3(1024), 0, s, hist, sub);
-    hipLaunchKernelGGL(k_sb_scatter, dim3(SB_BLOCKS), dim3(64), 0, s, keys, weights, n_host, n_dev, hist, jump, wsorted);
-    hipLaunchKernelGGL(k_sb_cmf, dim3(SPCBPT_NUM_SUBSPACE), dim3(256), 0, s, sub, wsorted, cmfs);
+    SamplerBuildBatch b = {};
+    b.lvc[0] = lvc; b.n_host[0] = n_host; b.n_dev[0] = n_dev; b.path_count[0] = path_count; b.sub[0] = sub; b.jump[0] = jump; b.cmfs[0] = cmfs;
+    b.keys = keys; b.weights = weights; b.hist = hist; b.wsorted = wsorted; b.item_stride = 0;
+    launch_sampler_build_batch(b, 1, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1409,6 +1436,41 @@ __global__ __launch_bounds__(BLOCK) void k_film_merge(const KParams p, const flo
     if (!lane_pixel(p, x, y)) return;
     const float4 r = reinterpret_cast<const float4*>(result)[(size_t)y * p.width + x];
     film_write(p, x, y, mk3(r.x, r.y, r.z));  // p.result is null here: the direct path
+}
+// ... of the frames of a batched launch in one pass: per pixel the running mean takes the frames in order (the same operations as
+// `frames` launches of k_film_merge), the tone map is that of the last one
+__global__ __launch_bounds__(BLOCK) void k_film_merge_batch(const KParams p, const MergeBatch m, int frames) {
+    uint32_t x, y;
+    if (!lane_pixel(p, x, y)) return;
+    const size_t idx = (size_t)y * p.width + x;
+    float4* acc = reinterpret_cast<float4*>(p.accum);
+    f3 c = mk3(0.0f);
+    bool have = false;
+    for (int k = 0; k < frames; k++) {
+        const float4 r = reinterpret_cast<const float4*>(m.result[k])[idx];
+        f3 v = mk3(r.x, r.y, r.z);
+        if (m.subframe[k] > 0) {
+            if (!have) { const float4 prev = acc[idx]; c = mk3(prev.x, prev.y, prev.z); }
+            const float a = 1.0f / (float)(m.subframe[k] + 1);
+            v = lerp3(c, v, a);
+        }
+        c = v; have = true;
+    }
+    acc[idx] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (p.frame) {
+        const float lum = 0.3f * c.x + 0.6f * c.y + 0.1f * c.z;
+        const float s = 1.0f / (1.0f + lum / 1.5f);
+        const f3 t = c * s;
+        p.frame[idx] = quant8(to_srgb(clampf(t.x, 0.f, 1.f))) | (quant8(to_srgb(clampf(t.y, 0.f, 1.f))) << 8) |
+                       (quant8(to_srgb(clampf(t.z, 0.f, 1.f))) << 16) | (255u << 24);
+    }
+}
+void launch_film_merge_batch(const KParams& p, const MergeBatch& m, int frames, hipStream_t s) {
+    const int blocks = render_blocks(p);
+    if (blocks <= 0 || frames <= 0) return;
+    KParams q = p;
+    q.result = nullptr;
+    hipLaunchKernelGGL(k_film_merge_batch, dim3(blocks), dim3(BLOCK), 0, s, q, m, frames);
 }
 void launch_film_merge(const KParams& p, hipStream_t s) {
     const int blocks = render_blocks(p);

@@ -577,3 +577,57 @@ def test_a_batch_of_twenty_frames_equals_twenty_launches(gpu, pkg, monkeypatch):
     assert np.array_equal(b.read_accum(), want)
     with pytest.raises(pkg.SpcbptError):
         b.launch_eye_batch(list(range(33)))
+
+
+def test_batched_sampler_build_and_merge_equal_single_ones(gpu, pkg, monkeypatch):
+    """spcbpt_build_sampler_batch builds the samplers of n queued light passes with the kernels of one build (frame = the grid's second
+    dimension), and a batched eye launch merges its frames into the film in one pass: tables and film must be those of n single
+    builds and n single merges, bit for bit -- on a many-subspace tuple, with subframe indices that restart in mid-batch (a merge
+    that must NOT read the film) and with a second batch that wraps around the ring of buffer sets."""
+    scene = pkg.scenes.bedroom(target_tris=40000)
+    cam = scene.camera
+    W, H, NF = 128, 72, 5
+    monkeypatch.setenv("SPCBPT_EYE_BATCH", str(NF))
+    monkeypatch.setenv("SPCBPT_SETS", "7")
+    r = pkg.Renderer(scene, 0)
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], W / H)
+    r.resize(W, H)
+    r.set_light_trace(6000, 52, 1)
+    r.preprocess(200_000, 200_000, False)      # many-leaf trees, initial Gamma
+    r.set_light_ahead(True)
+    subframes = [[0, 1, 2, 3, 4], [5, 0, 1, 2, 3]]     # the second batch restarts the running mean at its second frame
+
+    def run(batched):
+        r.clear_accum()
+        tabs = []
+        for rnd in range(2):
+            r.launch_light_batch(10 * rnd + 1, NF)
+            if batched:
+                r.build_sampler_batch(NF)
+            else:
+                for f in range(NF):
+                    r.build_sampler()
+            tabs.append(r.sampler_read())          # the set built last
+            r.launch_eye_batch(subframes[rnd])
+        r.sync()
+        return tabs, r.read_accum().copy(), r.read_frame().copy()
+
+    t1, a1, f1 = run(False)
+    t2, a2, f2 = run(True)
+    for x, y in zip(t1, t2):
+        assert (x[3], x[4]) == (y[3], y[4]) and x[3] > 1000
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2])
+    assert np.isfinite(a1).all() and np.array_equal(a1, a2) and np.array_equal(f1, f2)
+    # frame by frame: the same film as single launches with single merges
+    r.clear_accum()
+    for rnd in range(2):
+        r.launch_light_batch(10 * rnd + 1, NF)
+        for f in range(NF):
+            r.build_sampler()
+            r.launch("SPCBPT_eye", subframes[rnd][f])
+    r.sync()
+    assert np.array_equal(r.read_accum(), a2) and np.array_equal(r.read_frame(), f2)
+    with pytest.raises(pkg.SpcbptError):
+        r.build_sampler_batch(33)
+    with pytest.raises(pkg.SpcbptError):
+        r.build_sampler_batch(0)

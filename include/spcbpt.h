@@ -451,8 +451,8 @@ int spcbpt_launch_light_batch(spcbpt_ctx* ctx, uint32_t first_frame, int n_frame
 /* Batched sampler build (no reference counterpart): n_builds spcbpt_build_sampler calls -- the n_builds OLDEST queued light
  * passes -- with the kernels of ONE build (the frame in the grid's second dimension).  Same tables, same state afterwards; what
  * goes is the chain of 4 x n_builds small dependent launches in front of a batched eye launch that cannot start before the last
- * of them (0.12 ms per build on the bench scene).  Sets that need more than the plain build (a gathered import with its totals
- * on the device, SPCBPT_SAMPLER_BUILD=hipcub) are built one by one, as if spcbpt_build_sampler had been called n_builds times.
+ * of them (0.12 ms per build on the bench scene).  With SPCBPT_SAMPLER_BUILD=hipcub, or for a cache whose counts the host has to
+ * read back first, the call is n_builds times spcbpt_build_sampler.
  * 1 <= n_builds <= 32 (SPCBPT_ERR_INVALID_ARG). */
 int spcbpt_build_sampler_batch(spcbpt_ctx* ctx, int n_builds);
 

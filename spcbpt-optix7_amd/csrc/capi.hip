@@ -680,14 +680,14 @@ int Context::build_sampler() {
 // LVC_Process for the n OLDEST light passes that have no sampler yet, as ONE set of four launches (kernels.hip: SamplerBuildBatch).
 // The tables are those of n build_sampler calls -- the same kernels with the frame in blockIdx.y -- and the sets end up in the same
 // state; what goes is n - 1 times the four dependent launches (0.12 ms per build: 2.4 ms in front of a 20-frame eye launch that
-// cannot start before the last of them).  Falls back to n single builds where a set needs what only that path does: a gathered
-// import whose totals live on the device, the radix-sort build, a cache whose counts the host has to read back.
+// cannot start before the last of them).  Gathered imports (totals on the device) are built over their upper bound, as build_sampler
+// does.  Falls back to n single builds for the radix-sort form and for a cache whose counts the host would have to read back.
 int Context::build_sampler_batch(int n) {
     if (n < 1 || n > kMaxBatchFrames) { error = "build_sampler_batch: 1 .. 32 builds per call"; return SPCBPT_ERR_INVALID_ARG; }
     bool plain = counting_build && n > 1 && d_lvc && (int)pending.size() >= n;
     for (int k = 0; plain && k < n; k++) {
         const int b = pending[(size_t)k];
-        if (set_bound[b] >= 0 || !(set_count_host[b] >= 0 || light_counts_valid[b])) plain = false;
+        if (set_bound[b] < 0 && !(set_count_host[b] >= 0 || light_counts_valid[b])) plain = false;   // counts the host would have to read back
     }
     if (!plain) {
         for (int k = 0; k < n; k++) { const int rc = build_sampler(); if (rc) return rc; }
@@ -709,14 +709,16 @@ int Context::build_sampler_batch(int n) {
         const int b = pending[(size_t)k];
         sets[k] = b;
         if (light_lane_of_set[b] != 0 && light_counts_valid[b]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_light[b], 0));   // traced on the second lane
-        int count = set_count_host[b];
+        const bool dev_count = set_bound[b] >= 0;   // gathered import: totals (and the path count) on the device, build over the upper bound
+        if (dev_count && ev_exch_set[b]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_exch[b], 0));
+        int count = dev_count ? set_bound[b] : set_count_host[b];
         if (count < 0) {   // the light pass left (vertex_count, path_count) in pinned memory
             HIP_TRY(this, hipEventSynchronize(ev_light[b]));
             count = h_light_counts[2 * b];
         }
-        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = nullptr; B.path_count[k] = set_counts[b] + 1;
+        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = dev_count ? set_counts[b] : nullptr; B.path_count[k] = dev_count ? nullptr : set_counts[b] + 1;
         B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b];
-        HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));   // the build counts the paths on its way (as build_sampler does)
+        if (!dev_count) HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));   // the build counts the paths on its way (as build_sampler does)
     }
     time_begin("sampler_build");
     launch_sampler_build_batch(B, n, stream);
@@ -736,8 +738,8 @@ int Context::build_sampler_batch(int n) {
         if (!pending.empty() && pending.front() == b) pending.pop_front();
     }
     have_sampler = true;
-    lvc_count = B.n_host[n - 1];   // the members describe the set built last, as after build_sampler
-    if (light_counts_valid[sets[n - 1]] && set_count_host[sets[n - 1]] < 0) path_count = h_light_counts[2 * sets[n - 1] + 1];
+    lvc_count = B.n_dev[n - 1] ? -1 : B.n_host[n - 1];   // the members describe the set built last, as after build_sampler (-1: only the device knows)
+    if (!B.n_dev[n - 1] && light_counts_valid[sets[n - 1]] && set_count_host[sets[n - 1]] < 0) path_count = h_light_counts[2 * sets[n - 1] + 1];
     select_set(lset);
     return 0;
 }

@@ -193,6 +193,32 @@ def test_rccl_batched_exchange_at_world_size_one(gpu, pkg):
 
 
 @pytest.mark.gpu
+def test_batched_builds_after_a_batched_exchange(gpu, pkg):
+    """spcbpt_build_sampler_batch on gathered imports (the sets' totals live on the device: the builds run over the agreed upper
+    bound): the loop of bench.py -- light batch, ONE exchange per batch, ONE set of build launches per batch, one eye launch -- over the
+    RCCL transport at world size 1, against the single-GPU film."""
+    scene = pkg.scenes.cornell_box()
+    NF, B = 6, 3
+    single, want = _single(pkg, scene, NF)
+    r = _make(pkg, scene, B)
+    c = pkg.dist.Comm(r, 0, 1, pkg.dist.unique_id())
+    r.set_subspace(*single.get_subspace())
+    c.broadcast_subspace(0)
+    c.calibrate(passes=1)
+    r.set_light_ahead(True)
+    r.launch_light_batch(1, B)
+    for f0 in range(0, NF, B):
+        r.launch_light_batch(f0 + 1 + B, B)
+        c.exchange_lvc_batch(B)
+        r.build_sampler_batch(B)
+        r.launch_eye_batch(list(range(f0, f0 + B)))
+    c.barrier()
+    c.gather_film()
+    assert np.array_equal(r.read_accum(), want)
+    c.close()
+
+
+@pytest.mark.gpu
 def test_an_uncalibrated_shard_capacity_beyond_the_cache_is_staged_not_refused(gpu, pkg):
     """The caches are sized per rank from each rank's own probe pass (spcbpt_lvc_set_capacity) while the default shard capacity is
     the largest padded scratch of any rank: without spcbpt_comm_calibrate a shard of shard_cap slots is more than a cache holds.

@@ -5,6 +5,7 @@ step time of a rank scales with N and with the number of frames in flight (SPCBP
 --native: the C++ host (libspcbpt_mgpu) at world size 1 -- every call of the real frame loop is there (pack, RCCL all-gather, compaction,
 device-count sampler build), but the gather carries only this rank's own shard: what N - 1 peers add is the driver's to measure.
 --xbatch (with --native --lbatch): ONE exchange per light batch (spcbpt_comm_exchange_lvc_batch) instead of one per frame.
+--bbatch (with --lbatch, and --xbatch if --native): the sampler builds of a batch as one set of launches (spcbpt_build_sampler_batch).
 --exchange runs the per-frame host sequence of the real job too (dist.FrameExchanger on a world-size-1 RCCL group: the
 all-gathers degenerate to copies, but every host wait of the exchange path is there), which is what bounds a rank's frame
 rate when its share of the image is small."""
@@ -45,6 +46,7 @@ if native:
     print("shard capacity after calibration:", comm.calibrate(passes=2, slack=1.5))
 lbatch = "--lbatch" in sys.argv and batch > 1
 xbatch = "--xbatch" in sys.argv and lbatch and comm is not None
+bbatch = "--bbatch" in sys.argv and lbatch and (comm is None or xbatch) and ex is None
 rows = (0, H, N)
 if lbatch:
     r.set_light_ahead(True)
@@ -58,6 +60,7 @@ def eye(f):
     if batch == 1: r.launch("SPCBPT_eye", f, rows); return
     queued.append(f)
     if len(queued) == batch:
+        if bbatch: r.build_sampler_batch(batch)
         r.launch_eye_batch(queued, rows); queued.clear()
 def step(f):
     if lbatch:
@@ -68,7 +71,8 @@ def step(f):
     if ex is not None: ex.allgather_lvc()
     if throttle: r.sync_light()
     if comm is not None and not xbatch: comm.exchange_lvc()
-    r.build_sampler(); eye(f)
+    if not bbatch: r.build_sampler()
+    eye(f)
 for f in range(batch * max(1, 8 // batch)): step(f)   # a multiple of the batch: nothing is left queued when the clock starts
 r.sync()
 t0 = time.perf_counter()
@@ -84,18 +88,20 @@ def timed_step(f):
     if xbatch:
         if f % batch == 0: comm.exchange_lvc_batch(batch)
     elif comm is not None: comm.exchange_lvc()
-    c2 = time.perf_counter(); r.build_sampler()
+    c2 = time.perf_counter()
+    if not bbatch: r.build_sampler()
     d = time.perf_counter(); eye(f)
     e = time.perf_counter()
     host["light"] += b - a; host["exchange"] += c2 - b; host["build"] += d - c2; host["eye"] += e - d
 for f in range(steps): timed_step(f)
 if queued:                       # a last, shorter eye launch: every frame counted is rendered
+    if bbatch: r.build_sampler_batch(len(queued))
     r.launch_eye_batch(queued, rows); queued.clear()
 t_host = time.perf_counter() - t0
 r.sync()
 dt = (time.perf_counter() - t0) / steps
 print("host time per frame (ms): " + ", ".join(f"{k} {v / steps * 1e3:.3f}" for k, v in host.items()) + f"; host busy {t_host / steps * 1e3:.3f} of {dt * 1e3:.3f} ms")
-print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' + (' (one per light batch)' if xbatch else '') if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' lbatch' if lbatch else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
+print(f"N={N} streams={streams}{' exchange' if exchange else ''}{' native-exchange' + (' (one per light batch)' if xbatch else '') if native else ''}{' ahead=' + str(depth) if ahead else ''}{' batch=' + str(batch) if batch > 1 else ''}{' lbatch' if lbatch else ''}{' bbatch' if bbatch else ''}{' trained' if trained else ''}: {dt * 1e3:.3f} ms per rank-frame  -> {N}-GPU job at {(W * H + M) / dt / 1e6:.1f} Mpaths/s if the exchange were free")
 if ex is not None:
     import torch.distributed as dist
     dist.destroy_process_group()

@@ -716,9 +716,12 @@ int Context::build_sampler_batch(int n) {
             HIP_TRY(this, hipEventSynchronize(ev_light[b]));
             count = h_light_counts[2 * b];
         }
-        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = dev_count ? set_counts[b] : nullptr; B.path_count[k] = dev_count ? nullptr : set_counts[b] + 1;
+        // the path count: a light pass's compaction (and a gathered import) has left it in the set; only a cache that came some other way
+        // (spcbpt_lvc_import) has it counted by the build, as build_sampler does
+        const bool count_paths = !dev_count && !light_counts_valid[b];
+        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = dev_count ? set_counts[b] : nullptr; B.path_count[k] = count_paths ? set_counts[b] + 1 : nullptr;
         B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b];
-        if (!dev_count) HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));   // the build counts the paths on its way (as build_sampler does)
+        if (count_paths) HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));
     }
     time_begin("sampler_build");
     launch_sampler_build_batch(B, n, stream);

@@ -516,14 +516,17 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     int grid_cap = light_batch_blocks;
     if (grid_cap == 0) {
         // ... in proportion to the light paths per pixel of this context's share of the frame (kp.row_step: the band step of the last
-        // eye launch), so that the batch stays shorter than the eye launch it runs beside: 400 blocks per (path / pixel), i.e. 20 for
+        // eye launch), so that the batch stays shorter than the eye launch it runs beside: 480 blocks per (path / pixel), i.e. 24 for
         // 100 000 paths against 1920 x 1080 pixels -- or against an eighth of both
         const double px = std::max(1.0, (double)kp.width * kp.height / std::max(1, (int)kp.row_step));
         const double ratio = (double)lt.core_count * std::max(1, lt.m_per_core) / px;
         // (a rank's share of a sharded frame wants more lanes for the same ratio: its eye launches are short, and the chain of a
         // batch -- passes, then one exchange and build per frame -- has to fit under them: N = 8 simulation 0.80-0.81 ms per
         // rank-frame with 48 blocks, 0.83-0.87 with 20)
-        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, std::ceil(400.0 * ratio)));
+        // (round 4: 400 -> 480 blocks per (path / pixel).  With the eye kernel 13 % faster the 20 blocks of 400 finished a 20-frame batch in
+        // 75 ms beside an eye launch of 83 -- and 16 blocks, too few, cost 10 %: the batch became the critical path.  24 keep a fifth in hand
+        // at no measurable cost: 20 / 24 / 28 / 32 blocks 4.176 / 4.204 / 4.181 / 4.231 ms per step)
+        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, std::ceil(480.0 * ratio)));
     }
     // (cores that trace many paths one after the other -- the reference's geometry -- are long jobs: never two of them per lane)
     if (lt.m_per_core >= 8) grid_cap = std::max(grid_cap, (int)(((long long)n * lt.core_count + 255) / 256));

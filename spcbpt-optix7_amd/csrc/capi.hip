@@ -619,8 +619,12 @@ int Context::build_sampler() {
     const bool dev_count = set_bound[bset] >= 0;   // gathered import: totals on the device, build over the upper bound
     if (dev_count && ev_exch_set[bset]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_exch[bset], 0));
     bool count_known = set_count_host[bset] >= 0 || dev_count;
+    // the counting build takes its item count on the device: a light pass's (vertex_count, path_count) need not reach the host first --
+    // the reference-shaped loop (light pass -> build -> eye launch, one sync per frame) then runs without a host wait in the middle
+    const bool lazy = counting_build && !count_known && light_counts_valid[bset];
     if (dev_count) { lvc_count = set_bound[bset]; path_count = -1; }
     else if (count_known) lvc_count = set_count_host[bset];
+    else if (lazy) { lvc_count = (int)std::min<size_t>(lvc_capacity, 0x7fffffff); path_count = -1; count_known = true; }
     else if (light_counts_valid[bset]) {
         HIP_TRY(this, hipEventSynchronize(ev_light[bset]));
         lvc_count = h_light_counts[2 * bset]; path_count = h_light_counts[2 * bset + 1];
@@ -633,9 +637,9 @@ int Context::build_sampler() {
         // one stable counting sort over the 10-bit subspace ids: four launches (kernels.hip).  The path count is taken on the way
         // unless the light pass (or the gathered import) has left it in the set already.
         if (!d_hist) HIP_TRY(this, dev_alloc(&d_hist, sampler_build_hist_ints()));
-        const bool count_paths = !dev_count && !(keys_ready && keys_set == bset);
+        const bool count_paths = !dev_count && !lazy && !(keys_ready && keys_set == bset);   // (a light pass has left the path count in its set)
         if (count_paths) HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
-        launch_sampler_build(d_lvc, n, dev_count ? d_sampler_counts : nullptr, d_keys, d_weights, d_hist, count_paths ? d_sampler_counts + 1 : nullptr,
+        launch_sampler_build(d_lvc, n, (dev_count || lazy) ? d_sampler_counts : nullptr, d_keys, d_weights, d_hist, count_paths ? d_sampler_counts + 1 : nullptr,
                              d_subspace, d_vals2, d_wsorted, d_cmfs, stream);
         keys_ready = false;
     } else {
@@ -675,7 +679,7 @@ int Context::build_sampler() {
     built_sets.push_back(bset);
     while ((int)built_sets.size() > kMaxBatchFrames) built_sets.pop_front();
     if (!pending.empty() && pending.front() == bset) pending.pop_front();
-    if (dev_count) lvc_count = -1;   // the host does not know it
+    if (dev_count || lazy) lvc_count = -1;   // the host does not know it (fetch_counts brings it when somebody asks)
     select_set(lset);   // the members name the latest light pass's set again
     return 0;
 }
@@ -715,14 +719,12 @@ int Context::build_sampler_batch(int n) {
         const bool dev_count = set_bound[b] >= 0;   // gathered import: totals (and the path count) on the device, build over the upper bound
         if (dev_count && ev_exch_set[b]) HIP_TRY(this, hipStreamWaitEvent(stream, ev_exch[b], 0));
         int count = dev_count ? set_bound[b] : set_count_host[b];
-        if (count < 0) {   // the light pass left (vertex_count, path_count) in pinned memory
-            HIP_TRY(this, hipEventSynchronize(ev_light[b]));
-            count = h_light_counts[2 * b];
-        }
+        const bool lazy = count < 0;   // a light pass's count: read on the device (no host wait for the pass)
+        if (lazy) count = (int)std::min<size_t>(lvc_capacity, 0x7fffffff);
         // the path count: a light pass's compaction (and a gathered import) has left it in the set; only a cache that came some other way
         // (spcbpt_lvc_import) has it counted by the build, as build_sampler does
         const bool count_paths = !dev_count && !light_counts_valid[b];
-        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = dev_count ? set_counts[b] : nullptr; B.path_count[k] = count_paths ? set_counts[b] + 1 : nullptr;
+        B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = (dev_count || lazy) ? set_counts[b] : nullptr; B.path_count[k] = count_paths ? set_counts[b] + 1 : nullptr;
         B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b];
         if (count_paths) HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));
     }
@@ -745,7 +747,6 @@ int Context::build_sampler_batch(int n) {
     }
     have_sampler = true;
     lvc_count = B.n_dev[n - 1] ? -1 : B.n_host[n - 1];   // the members describe the set built last, as after build_sampler (-1: only the device knows)
-    if (!B.n_dev[n - 1] && light_counts_valid[sets[n - 1]] && set_count_host[sets[n - 1]] < 0) path_count = h_light_counts[2 * sets[n - 1] + 1];
     select_set(lset);
     return 0;
 }

@@ -146,6 +146,18 @@ struct TravStack {
         if (sp < STACK_LDS) return column()[sp * BLOCK];
         return stack_pop_slow(spill, spill_entries, sp - STACK_LDS);
     }
+    // ... of a step whose caller has established that no lane of the wave is within three entries of the LDS part's end (trace_pool
+    // votes once per iteration): no bounds logic, no call sites of the HBM part -- ~30 instructions of every iteration
+    SPC_DEV void push_far_lds(uint32_t r1, bool c1, uint32_t r2, bool c2, uint32_t r3, bool c3) {
+        lds_u32* lds = column();
+        if (c3) lds[sp * BLOCK] = r3;
+        const int p2 = sp + (c3 ? 1 : 0);
+        if (c2) lds[p2 * BLOCK] = r2;
+        const int p1 = p2 + (c2 ? 1 : 0);
+        if (c1) lds[p1 * BLOCK] = r1;
+        sp = p1 + (c1 ? 1 : 0);
+    }
+    SPC_DEV uint32_t pop_lds() { sp--; return column()[sp * BLOCK]; }
 };
 
 struct HitRec { float t; int tri; float u, v; };
@@ -210,11 +222,12 @@ static constexpr int kTravDone = 0x7fffffff;
 #endif
 // pop the next stack entry into (node, leaf_count); leaf refs carry their count: 1<<31 | first<<3 | count (count <= 4).
 // A macro, not a lambda: a by-reference capture keeps node / leaf_count in scratch memory inside the loop.
-#define SPC_TRAV_POP()                                                                              \
+#define SPC_TRAV_POP() SPC_TRAV_POP_(pop)
+#define SPC_TRAV_POP_(POP)                                                                          \
     do {                                                                                            \
         if (st.sp == 0) { node = kTravDone; }                                                       \
         else {                                                                                      \
-            const uint32_t w__ = st.pop();                                                          \
+            const uint32_t w__ = st.POP();                                                          \
             if (w__ & 0x80000000u) { node = ~(int)((w__ & 0x7fffffffu) >> 3); leaf_count = (int)(w__ & 7u); } \
             else node = (int)w__;                                                                   \
         }                                                                                           \
@@ -273,9 +286,10 @@ SPC_DEV uint32_t stack_word(int ref, int count) {
         const size_t nb__ = (size_t)node * NODE_QUADS;                                                                \
         const float4 Q0 = ldq(S.nodes, nb__ + 0), Q1 = ldq(S.nodes, nb__ + 1), Q2 = ldq(S.nodes, nb__ + 2),            \
                      Q3 = ldq(S.nodes, nb__ + 3);                                                                     \
-        SPC_NODE_STEP_Q(TMIN, TMAX, Q0, Q1, Q2, Q3);                                                                  \
+        SPC_NODE_STEP_Q(TMIN, TMAX, Q0, Q1, Q2, Q3, push_far, pop);                                                   \
     } while (0)
-#define SPC_NODE_STEP_Q(TMIN, TMAX, Q0, Q1, Q2, Q3) /* ... on a node record that is already in registers */          \
+/* ... on a node record that is already in registers; PUSH / POP name the stack operations (the plain ones, or the LDS-only ones) */ \
+#define SPC_NODE_STEP_Q(TMIN, TMAX, Q0, Q1, Q2, Q3, PUSH, POP)                                                        \
     do {                                                                                                              \
         cn.add(C_NODE); /* one 64-B visit */                                                                          \
         SPC_UTIL_COUNT(C_U_NODE_LANES, C_U_NODE_SLOTS)                                                                \
@@ -288,9 +302,9 @@ SPC_DEV uint32_t stack_word(int ref, int count) {
         const uint32_t r0__ = sel4u(ref__, k__[0] & 3u), r1__ = sel4u(ref__, k__[1] & 3u),                            \
                        r2__ = sel4u(ref__, k__[2] & 3u), r3__ = sel4u(ref__, k__[3] & 3u);                            \
         if (k__[0] == 0xffffffffu) {                                                                                  \
-            SPC_TRAV_POP();                                                                                           \
+            SPC_TRAV_POP_(POP);                                                                                       \
         } else {                                                                                                      \
-            st.push_far(r1__, k__[1] != 0xffffffffu, r2__, k__[2] != 0xffffffffu, r3__, k__[3] != 0xffffffffu);       \
+            st.PUSH(r1__, k__[1] != 0xffffffffu, r2__, k__[2] != 0xffffffffu, r3__, k__[3] != 0xffffffffu);           \
             if (r0__ & 0x80000000u) { node = ~(int)((r0__ & 0x7fffffffu) >> 3); leaf_count = (int)(r0__ & 7u); }      \
             else node = (int)r0__;                                                                                    \
         }                                                                                                             \
@@ -606,53 +620,46 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
         if (SPC_QUAD_TAIL && S.nodes_q && __popcll(live__) <= 16 && __any(done)) { quad_live = live__; break; }
         const bool tail = COUNT && __any(done);   // (counting build) some lane found the pool empty: what follows is the pass's tail
         bool finished = false, occluded = false;
+        const bool shallow__ = !__any(node != kTravDone && st.sp + 3 > STACK_LDS);   // no lane near the end of its LDS entries (wave-uniform)
         if (node != kTravDone) {
             if (COUNT && tail && node >= 0) {
                 cn.add(closest ? C_U_TAIL_CLOSEST : C_U_TAIL_SHADOW);
                 if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) cn.add(C_U_TAIL_SLOTS, 64);
             }
-#if SPC_ONE_FETCH
             // all sixteen dwords of the record fetched a step ago, here: without this the compiler narrows the four 16-B loads to what both
             // kinds of step read and fetches the rest inside the branches, after the wait -- a second round trip
             asm volatile("" : "+v"(R0.x), "+v"(R0.y), "+v"(R0.z), "+v"(R0.w), "+v"(R1.x), "+v"(R1.y), "+v"(R1.z), "+v"(R1.w));
             asm volatile("" : "+v"(R2.x), "+v"(R2.y), "+v"(R2.z), "+v"(R2.w), "+v"(R3.x), "+v"(R3.y), "+v"(R3.z), "+v"(R3.w));
-            const bool at_leaf = node < 0;
-            if (!at_leaf) { SPC_NODE_STEP_Q(kEps, best_t, R0, R1, R2, R3); finished = node == kTravDone; }
-            else if (leaf_count <= 0) {
-                SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
-                finished = node == kTravDone;
-            } else {
-                const int tri = ~node;
-                const float4 a = R0, b = R1, c = R2;
-                cn.add(C_TRI);
-                SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)
-                const bool cull = closest && (__float_as_uint(R3.w) & 0x80000000u) != 0;  // single-sided emitters
-                float t, u, v;
-#else
-            if (node >= 0) { SPC_NODE_STEP(kEps, best_t); finished = node == kTravDone; }
-            if (node < 0 && leaf_count <= 0) {
-                SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
-                finished = node == kTravDone;
-            } else if (node < 0) {
-                const int tri = ~node;
-                const size_t base = (size_t)tri * 4;
-                const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
-                cn.add(C_TRI);
-                SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)
-                bool cull = false;
-                if (closest) cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;  // single-sided emitters
-                float t, u, v;
-#endif
-                const bool h = tri_test(a, b, c, o, d, kEps, best_t, cull, t, u, v);
-                if (h && !closest) {
-                    occluded = true; finished = true; node = kTravDone;
-                } else {
-                    if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }
-                    node -= 1;  // ~(tri + 1)
-                    leaf_count -= 1;
-                    if (leaf_count == 0) { SPC_TRAV_POP(); finished = node == kTravDone; }
-                }
-            }
+            // The step, in two instantiations: with the plain stack operations (bounds logic and call sites of the HBM part at every push and
+            // pop: ~30 instructions that a step pays whether or not any lane is near the end of its 16 LDS entries), and with the LDS-only
+            // ones for the iterations in which no lane of the wave is (a vote per iteration; probe: 1.8 % of the kernel).
+#define SPC_POOL_STEP__(PUSH, POP)                                                                                    \
+            do {                                                                                                      \
+                const bool at_leaf = node < 0;                                                                        \
+                if (!at_leaf) { SPC_NODE_STEP_Q(kEps, best_t, R0, R1, R2, R3, PUSH, POP); finished = node == kTravDone; } \
+                else if (leaf_count <= 0) {                                                                           \
+                    SPC_TRAV_POP_(POP);  /* an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test */ \
+                    finished = node == kTravDone;                                                                     \
+                } else {                                                                                              \
+                    const int tri = ~node;                                                                            \
+                    cn.add(C_TRI);                                                                                    \
+                    SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)                                                      \
+                    const bool cull = closest && (__float_as_uint(R3.w) & 0x80000000u) != 0;  /* single-sided emitters */ \
+                    float t, u, v;                                                                                    \
+                    const bool h = tri_test(R0, R1, R2, o, d, kEps, best_t, cull, t, u, v);                           \
+                    if (h && !closest) {                                                                              \
+                        occluded = true; finished = true; node = kTravDone;                                           \
+                    } else {                                                                                          \
+                        if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                \
+                        node -= 1;  /* ~(tri + 1) */                                                                  \
+                        leaf_count -= 1;                                                                              \
+                        if (leaf_count == 0) { SPC_TRAV_POP_(POP); finished = node == kTravDone; }                    \
+                    }                                                                                                 \
+                }                                                                                                     \
+            } while (0)
+            if (shallow__) SPC_POOL_STEP__(push_far_lds, pop_lds);
+            else SPC_POOL_STEP__(push_far, pop);
+#undef SPC_POOL_STEP__
         }
 #if SPC_ONE_FETCH
         if (node != kTravDone) SPC_FETCH_STEP__();   // the next step's record: ONE request site after the step, outside its branches

@@ -8,7 +8,8 @@ timed instantiations of k_spcbpt, the resources that decide occupancy and the tw
   * 128 VGPRs (4 waves per SIMD) and <= 40 960 B of LDS (4 blocks per CU) -- the occupancy the launch sizes its persistent grid for;
   * private segment (scratch) <= 160 B per lane -- spills are the kernel's writes to HBM (profiles/r03_experiments.md); SLP
     vectorisation or loop-invariant hoisting in the traversal loop pushed it to 264-384 B;
-  * packed-float instructions: only the 12 hand-written v_pk_fma_f32 of the slab test -- the SLP vectoriser made 6 900 of them;
+  * packed-float instructions: only the hand-written v_pk_fma_f32 of the slab test (12, in two instantiations of the step) -- the SLP
+    vectoriser made 6 900 of them;
   * instruction count of the kernel within 10 % of what was profiled;
   * no spill inside the traversal loop nor inside the quad tail's loop; the loops' sizes are pinned too.
 Needs no GPU (hipcc cross-compiles; the tools ship with ROCm)."""
@@ -25,8 +26,8 @@ ARGS = "EEEvNS_7KParamsE"
 # <COUNT, BATCH, CACHE, ENV>: the timed forms (COUNT = false, CACHE = true)
 TIMED = {"single frame, plain scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS, "batched, plain scene (bench.py)": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS,
          "single frame, general scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS, "batched, general scene": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS}
-PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 13558, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 12770,
-                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 15562, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 14711}   # profiles/r04e_*
+PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 13998, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13181,
+                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 15998, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 15154}   # profiles/r04i_*
 
 
 def _traversal_loops(lines, quad=False, fan=False):
@@ -112,7 +113,7 @@ def test_timed_megakernel_resources(code_object, form):
     assert m["vgpr_count"] <= 128, report                          # 4 waves per SIMD (SPC_EYE_WAVES)
     assert m["group_segment_fixed_size"] <= 40960, report           # 4 blocks per CU in 160 KB of LDS
     assert m["private_segment_fixed_size"] <= (176 if "general" in form else 160), report   # scratch per lane: the kernel's HBM writes
-    assert d["packed"] <= 16, report                                # the slab test's 12 v_pk_fma_f32; SLP vectorisation made thousands
+    assert d["packed"] <= 28, report                                # the slab test's 12 v_pk_fma_f32, in the two instantiations of the pooled step; SLP vectorisation made thousands
     want = PROFILED_INSTRUCTIONS[name]
     assert abs(d["instructions"] - want) <= 0.10 * want, report     # the code the profiles/ numbers were measured on
     # The spills of this kernel (its 144-160 B of scratch) are path state parked ACROSS the traversal pass: the traversal loop itself
@@ -124,7 +125,7 @@ def test_timed_megakernel_resources(code_object, form):
     size, stores, loads = loops[0]
     assert stores == 0, report                                       # nothing is spilled inside the loop ...
     assert loads <= 6, report                                        # ... and the only reloads are the HBM stack area's base in the (rare) sp >= 16 path
-    assert 600 <= size <= 800, report                                # 690-725 instructions per traversal iteration (record fetch a step ahead, node step or triangle step)
+    assert 1000 <= size <= 1250, report                              # 1 110-1 130 instructions: the step twice (LDS-only stack operations / with the HBM part), ~560 executed per iteration
     # ... and the quad tail's loop (four lanes per ray: the loop around a DPP quad_perm and a single node-record fetch) spills nothing either
     tail = d["quad_tail_loop"]
     assert tail and tail[0][1] == 0 and tail[0][2] == 0 and tail[0][0] <= 500, report   # 441-457 instructions (node + leaf step of up to 16 rays)

@@ -327,37 +327,50 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
     st.sp = 0;
     int node = 0;        // >= 0 internal node, < 0 leaf (~next triangle to test), kTravDone = finished
     int leaf_count = 0;  // triangles left in the current leaf
+    // (A single 64-B fetch per iteration serving node OR triangle lanes loses HERE, where every lane follows one ray to its end:
+    // round 1 14.0 against 11.1 ms per frame; round 4, fetched a step ahead: pt frame 4.29 -> 4.43 ms, light pass 1.13 -> 1.16 ms --
+    // a lane that reaches a leaf waits a whole iteration for its first triangle.  It WINS in trace_pool, whose triangle step runs
+    // at a tenth of the lanes in 83 % of the iterations: see SPC_ONE_FETCH there.)
+    // The iteration in two instantiations, as in trace_pool: LDS-only stack operations while no lane still in the loop is within three
+    // entries of the end of its LDS part (a vote per iteration), the plain ones otherwise.
+#define SPC_TRAVERSE_ITER__(PUSH, POP)                                                                                \
+    do {                                                                                                              \
+        if (node >= 0) {                                                                                              \
+            const size_t nb__ = (size_t)node * NODE_QUADS;                                                            \
+            const float4 Q0 = ldq(S.nodes, nb__ + 0), Q1 = ldq(S.nodes, nb__ + 1), Q2 = ldq(S.nodes, nb__ + 2),        \
+                         Q3 = ldq(S.nodes, nb__ + 3);                                                                 \
+            SPC_NODE_STEP_Q(tmin, best_t, Q0, Q1, Q2, Q3, PUSH, POP);                                                 \
+        }                                                                                                             \
+        if (node < 0 && leaf_count <= 0) {                                                                            \
+            SPC_TRAV_POP_(POP);  /* an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test */ \
+        } else if (node < 0) {                                                                                        \
+            const int tri = ~node;                                                                                    \
+            const size_t base = (size_t)tri * 4;                                                                      \
+            const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);                 \
+            cn.add(C_TRI);                                                                                            \
+            SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)                                                              \
+            bool cull = false;                                                                                        \
+            if (!ANY) {                                                                                               \
+                /* emitter flag lives in quad 3; only fetched for closest-hit rays (single-sided emitters, q16) */     \
+                cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;                                 \
+            }                                                                                                         \
+            float t, u, v;                                                                                            \
+            const bool h = tri_test(a, b, c, o, d, tmin, best_t, cull, t, u, v);                                      \
+            if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                            \
+            if (ANY && h) {                                                                                           \
+                node = kTravDone;                                                                                     \
+            } else {                                                                                                  \
+                node -= 1;  /* ~(tri + 1) */                                                                          \
+                leaf_count -= 1;                                                                                      \
+                if (leaf_count == 0) SPC_TRAV_POP_(POP);                                                              \
+            }                                                                                                         \
+        }                                                                                                             \
+    } while (0)
     while (node != kTravDone) {
-        if (node >= 0) SPC_NODE_STEP(tmin, best_t);
-        // (A single 64-B fetch per iteration serving node OR triangle lanes loses HERE, where every lane follows one ray to its end:
-        // round 1 14.0 against 11.1 ms per frame; round 4, fetched a step ahead: pt frame 4.29 -> 4.43 ms, light pass 1.13 -> 1.16 ms --
-        // a lane that reaches a leaf waits a whole iteration for its first triangle.  It WINS in trace_pool, whose triangle step runs
-        // at a tenth of the lanes in 83 % of the iterations: see SPC_ONE_FETCH there.)
-        if (node < 0 && leaf_count <= 0) {
-            SPC_TRAV_POP();  // an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test
-        } else if (node < 0) {
-            const int tri = ~node;
-            const size_t base = (size_t)tri * 4;
-            const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);
-            cn.add(C_TRI);
-            SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)
-            bool cull = false;
-            if (!ANY) {
-                // emitter flag lives in quad 3; only fetched for closest-hit rays (single-sided emitters, q16)
-                cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;
-            }
-            float t, u, v;
-            const bool h = tri_test(a, b, c, o, d, tmin, best_t, cull, t, u, v);
-            if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }
-            if (ANY && h) {
-                node = kTravDone;
-            } else {
-                node -= 1;  // ~(tri + 1)
-                leaf_count -= 1;
-                if (leaf_count == 0) SPC_TRAV_POP();
-            }
-        }
+        if (!__any(st.sp + 3 > STACK_LDS)) SPC_TRAVERSE_ITER__(push_far_lds, pop_lds);
+        else SPC_TRAVERSE_ITER__(push_far, pop);
     }
+#undef SPC_TRAVERSE_ITER__
     hit.t = best_t; hit.tri = best_tri; hit.u = best_u; hit.v = best_v;
     return best_tri >= 0;
 }

@@ -1045,7 +1045,7 @@ int Context::install_minimal_tuple() {
 Context::~Context() {
     resolve_spans();
     free_preprocess();
-    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_nodes_q2); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
+    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_nodes_q2); /* d_tris lives in d_nodes' allocation */ dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
     dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
@@ -1216,8 +1216,10 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 16); c->bvh_depth = bvh.depth;
     c->n_lights = (int)lights.size(); c->n_mats = (int)mats.size();
 
-    CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size()));
-    CREATE_TRY(dev_alloc(&c->d_tris, bvh.tris.size()));
+    // nodes and triangles in ONE allocation, the triangle records right behind the node records (both 64 B): the pooled traversal
+    // step fetches "the record of its next step" through one base pointer (device_lib.h: SPC_FETCH_STEP__)
+    CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size() + bvh.tris.size()));
+    c->d_tris = c->d_nodes + bvh.nodes.size();
     CREATE_TRY(dev_alloc(&c->d_tri_orig, bvh.tri_orig.size()));
     CREATE_TRY(dev_alloc(&c->d_mats, mats.size()));
     CREATE_TRY(dev_alloc(&c->d_lights, lights.size()));
@@ -1261,7 +1263,7 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     CREATE_TRY(dev_alloc(&c->d_counters, (size_t)C_COUNT));
     CREATE_TRY(hipMemset(c->d_counters, 0, C_COUNT * sizeof(unsigned long long)));
     memset(&c->kp, 0, sizeof(c->kp));
-    c->kp.scene.nodes = c->d_nodes; c->kp.scene.tris = c->d_tris; c->kp.scene.tri_orig = c->d_tri_orig; c->kp.scene.mats = c->d_mats;
+    c->kp.scene.nodes = c->d_nodes; c->kp.scene.tris = c->d_tris; c->kp.scene.tri_base = c->n_nodes; c->kp.scene.tri_orig = c->d_tri_orig; c->kp.scene.mats = c->d_mats;
     c->kp.scene.lights = c->d_lights; c->kp.scene.tex = c->d_tex; c->kp.scene.n_lights = c->n_lights; c->kp.scene.n_mats = c->n_mats;
     // the same nodes, one record per child: the quad tail of the pooled traversal pass (device_lib.h) and the traversal A/B harness
     CREATE_TRY(dev_alloc(&c->d_nodes_q, (size_t)c->n_nodes * 16));

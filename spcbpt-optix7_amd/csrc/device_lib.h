@@ -602,9 +602,9 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
     float4 R0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), R1 = R0, R2 = R0, R3 = R0;
 #define SPC_FETCH_STEP__()                                                                                            \
     do {                                                                                                              \
-        const float* rp__ = node < 0 ? S.tris : S.nodes;                                                              \
-        const size_t rb__ = (size_t)(node < 0 ? ~node : node) * 4;                                                    \
-        R0 = ldq(rp__, rb__); R1 = ldq(rp__, rb__ + 1); R2 = ldq(rp__, rb__ + 2); R3 = ldq(rp__, rb__ + 3);           \
+        /* one base: the triangle records follow the node records (DeviceScene::tri_base = n_nodes) */                \
+        const size_t rb__ = (size_t)(uint32_t)(node < 0 ? S.tri_base + ~node : node) * 4;                             \
+        R0 = ldq(S.nodes, rb__); R1 = ldq(S.nodes, rb__ + 1); R2 = ldq(S.nodes, rb__ + 2); R3 = ldq(S.nodes, rb__ + 3); \
     } while (0)
     if (node != kTravDone) SPC_FETCH_STEP__();
 #endif

@@ -113,6 +113,8 @@ struct DeviceScene {
     int32_t n_mats;
     int32_t general;         // != 0: the scene has an environment map or a material with `brdf` set -> the timed kernels' ENV = true forms
     int32_t fan_tail;        // != 0: the shadow rays of the quad tail fan out over the idle quads (device_lib.h: fan_tail)
+    int32_t tri_base;        // the triangle records follow the node records in one allocation: record n_nodes + t of `nodes` is triangle t
+    int32_t pad_tri_base;
     DEnv env;
 };
 

@@ -485,6 +485,7 @@ def main():
     ms_sync_each = None
     ms_sync_each_ahead = None
     ms_viewer = None
+    ms_viewer_moving = None
     if args.sync_each_frames > 0 and ex is None:
         # optixPathTracer.cpp:791-822: launchLVCTrace (light pass + LVC_Process) then launchSubframe, a device sync after each
         # (513, 634) -- one frame in flight, nothing batched, nothing ahead
@@ -540,9 +541,18 @@ def main():
                     t1 = time.perf_counter()
                 v.frame()
             ms_viewer = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
-            v.set_pipeline(0)   # drops what was traced ahead
-            rv.sync()
-            v.close()
+            # ... and while the camera is dragged: one cursor event per displayed frame, so every call restarts the accumulation;
+            # the loop then does not speculate (a frame queued in such a call would be dropped by the next event after running to
+            # completion beside the real one) and costs what its light-pass-ahead mode costs
+            v.mouse_button("left", 1, 400, 300)
+            for f in range(args.sync_each_frames + 3):
+                if f == 3:
+                    t1 = time.perf_counter()
+                v.cursor_pos(401 + (f % 16), 300 + (f % 7))
+                v.frame()
+            ms_viewer_moving = (time.perf_counter() - t1) / args.sync_each_frames * 1e3
+            v.mouse_button("left", 0, 400, 300)
+            v.close()           # drops what was traced ahead and hands the context back (viewer.cpp: spcbpt_viewer_destroy)
             rv.close()
 
     eye_paths = args.width * args.height
@@ -602,9 +612,11 @@ def main():
             "ms_per_frame_sync_each": None if ms_sync_each is None else round(ms_sync_each, 3),
             "ms_per_frame_sync_each_light_ahead": None if ms_sync_each_ahead is None else round(ms_sync_each_ahead, 3),
             "ms_per_frame_viewer": None if ms_viewer is None else round(ms_viewer, 3),
+            "ms_per_frame_viewer_moving": None if ms_viewer_moving is None else round(ms_viewer_moving, 3),
             "notes": {"ms_per_step_long": f"the same loop over {args.long_steps} more steps (steady state; value / ms_per_step are the contract's {args.steps} steps)",
                       "ms_per_frame_sync_each": "the reference's loop form (optixPathTracer.cpp:791-822): one light pass, one sampler build, one eye launch and a device sync per frame",
-                      "ms_per_frame_viewer": "spcbpt_viewer_frame in its default mode: one complete, displayable frame per call (the same frames as the reference's loop), the next frame traced while this one is shown"},
+                      "ms_per_frame_viewer": "spcbpt_viewer_frame in its default mode: one complete, displayable frame per call (the same frames as the reference's loop), the next frame traced while this one is shown",
+                      "ms_per_frame_viewer_moving": "the same loop while the camera is dragged (an event before every call: each frame is subframe 0 of a new view; nothing is traced ahead to be dropped)"},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} scene{' read from glTF' if args.scene_route == 'gltf' else ''} ({info['n_triangles']} triangles, SAH BVH of {info['n_bvh_nodes']} quantised 4-wide nodes, depth "
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "

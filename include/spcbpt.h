@@ -336,7 +336,12 @@ int spcbpt_sampler_read(spcbpt_ctx* ctx, spcbpt_subspace* subspace /*1000*/,
 int spcbpt_read_accum(spcbpt_ctx* ctx, float* rgba_out);
 int spcbpt_read_frame(spcbpt_ctx* ctx, uint8_t* rgba8_out);
 int spcbpt_accum_device_ptr(spcbpt_ctx* ctx, void** d_accum);
+/* SPCBPT_ERR_STATE while a deferred frame is outstanding (its merge would land in the cleared film). */
 int spcbpt_clear_accum(spcbpt_ctx* ctx);
+/* The film as of the LAST QUEUED merge (what spcbpt_sync_film waits for): accum (float4 per pixel) and / or the tone-mapped frame
+ * (either may be NULL).  Unlike spcbpt_read_accum / spcbpt_read_frame, which wait for every stream of the context, this does not
+ * wait for launches queued behind that merge -- a frame being traced ahead (spcbpt_launch_deferred), light passes ahead. */
+int spcbpt_read_film(spcbpt_ctx* ctx, float* accum_rgba_out, uint8_t* frame_rgba8_out);
 
 int spcbpt_get_counters(spcbpt_ctx* ctx, spcbpt_counters* out);
 int spcbpt_reset_counters(spcbpt_ctx* ctx);
@@ -425,7 +430,9 @@ int spcbpt_sync_light(spcbpt_ctx* ctx);
  * turn).  spcbpt_launch_deferred is spcbpt_launch("pt" | "SPCBPT_eye", ...) WITHOUT the film merge: the kernel renders into a buffer
  * of its own, accum / frame are untouched.  spcbpt_merge_deferred(ctx, 1) queues that merge -- from then on the frame is exactly
  * what spcbpt_launch would have produced -- and (ctx, 0) drops the frame (the camera moved: its samples belong to no image).  One
- * frame may be outstanding; every other render launch is refused until it is merged or dropped (spcbpt_resize drops it).
+ * frame may be outstanding; until it is merged or dropped every other render launch (spcbpt_launch "pt" / "SPCBPT_eye" /
+ * "SPCBPT_no_rmis", spcbpt_launch_deferred, spcbpt_launch_eye_batch), spcbpt_clear_accum and spcbpt_set_light_ahead return
+ * SPCBPT_ERR_STATE -- the film would otherwise take frames out of order (spcbpt_resize drops it).
  * spcbpt_sync_film makes the host wait for the LAST QUEUED film merge only: the frame to display is complete, work queued behind it
  * (the next frame's light pass, sampler build, deferred eye launch) keeps running.  csrc/viewer.cpp builds its default loop on
  * these: frame f+1 is traced while frame f is shown, and every displayed frame is the reference loop's frame. */
@@ -452,16 +459,31 @@ int spcbpt_launch_light_batch(spcbpt_ctx* ctx, uint32_t first_frame, int n_frame
  * passes -- with the kernels of ONE build (the frame in the grid's second dimension).  Same tables, same state afterwards; what
  * goes is the chain of 4 x n_builds small dependent launches in front of a batched eye launch that cannot start before the last
  * of them (0.12 ms per build on the bench scene).  With SPCBPT_SAMPLER_BUILD=hipcub, or for a cache whose counts the host has to
- * read back first, the call is n_builds times spcbpt_build_sampler.
- * 1 <= n_builds <= 32 (SPCBPT_ERR_INVALID_ARG). */
+ * read back first, the call is n_builds times spcbpt_build_sampler -- and also when the device cannot hold the batch's scratch
+ * (n_builds x the largest item bound among the builds x 16 B; it only grows, spcbpt_lvc_set_capacity and leaving light-ahead mode
+ * free it).  1 <= n_builds <= 32 (SPCBPT_ERR_INVALID_ARG). */
 int spcbpt_build_sampler_batch(spcbpt_ctx* ctx, int n_builds);
+/* Test hook: bytes and frames of that scratch, and how many batches fell back to single builds for want of it
+ * (SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT=<bytes> in the environment makes larger requests fail). */
+int spcbpt_debug_batch_scratch(spcbpt_ctx* ctx, int64_t* bytes, int* frames, int* fallbacks);
 
 /* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain
  * however few paths a rank traces, and the LVC exchange makes the host wait for it; with on != 0 the host may launch frame
  * f + 1's "light trace" BEFORE it exchanges and builds frame f's: every light pass queues its buffer set, and
  * spcbpt_lvc_export / spcbpt_lvc_import / spcbpt_sync_light / spcbpt_build_sampler address the OLDEST queued pass (sync_light
- * then waits for that pass only, not for the stream).  Off (default): they address the latest light pass. */
+ * then waits for that pass only, not for the stream).  Off (default): they address the latest light pass.  Either way a "light
+ * trace" launch invalidates the sampler for eye launches (SPCBPT_ERR_STATE until the next spcbpt_build_sampler), as the reference's
+ * loop implies.  Switching waits for the context's streams, clears the queue of unbuilt passes and, when switched off, frees the
+ * batched build's scratch. */
 int spcbpt_set_light_ahead(spcbpt_ctx* ctx, int on);
+/* What the context holds of a loop that runs ahead: light-ahead mode, the number of light passes launched but not built yet, whether
+ * the tables of the LAST sampler build are still intact (no later pass, import or re-allocation took their buffer set), whether a
+ * deferred frame is outstanding.  Any pointer may be NULL. */
+int spcbpt_get_pipeline_state(spcbpt_ctx* ctx, int* light_ahead, int* pending_passes, int* sampler_intact, int* deferred_outstanding);
+/* Render once more from the sampler built last although a later "light trace" has been launched since (with passes ahead it went to
+ * another buffer set): the interactive loop's re-render of a frame whose speculative launch was dropped.  SPCBPT_ERR_STATE if the
+ * tables are gone. */
+int spcbpt_reuse_sampler(spcbpt_ctx* ctx);
 /* spcbpt_lvc_import(..., is_device = 1) reads its source asynchronously (on the light stream, possibly behind light passes launched
  * ahead).  A host that alternates TWO staging buffers calls this before it overwrites one of them: it returns when the import
  * before the previous one -- the last reader of that buffer -- has copied. */
@@ -605,8 +627,15 @@ int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps);
  *      (spcbpt_launch_deferred) are queued before spcbpt_viewer_frame returns, which waits for the shown frame's merge only
  *      (spcbpt_sync_film).  The next call merges that frame if nothing it depends on has changed since -- camera, size, algorithm,
  *      subframe restart -- and drops it otherwise; light pass and sampler are kept either way, so the k-th "SPCBPT_eye" frame
- *      always uses the k-th light pass.  A call after an event costs what mode 1 costs; a steady view costs the eye kernel.
- * Modes 1 and 2 set spcbpt_set_light_ahead on the context.  spcbpt_viewer_set_light_ahead(v, on) = set_pipeline(v, on ? 1 : 0). */
+ *      always uses the k-th light pass.  Only a call that saw NO event speculates: while the camera is dragged (every call sees a
+ *      change) the loop runs as mode 1 -- no frame is queued just to be dropped by the next event -- and the first steady call
+ *      starts tracing ahead again.  A steady view costs the eye kernel per displayed frame.
+ * Modes 1 and 2 set spcbpt_set_light_ahead on the context; spcbpt_viewer_destroy drops what the viewer queued ahead and restores the
+ * mode it found, so a host can go on with the plain loop on the same context.  A host that touches the context BETWEEN two
+ * viewer frames (merges / drops the deferred frame, new tuple, sky, cache import) is tolerated: each frame re-validates the viewer's
+ * flags against spcbpt_get_pipeline_state.  To DISPLAY a frame read it with spcbpt_read_film (or spcbpt_accum_device_ptr after
+ * spcbpt_viewer_frame): spcbpt_read_frame / _accum wait for everything queued, i.e. also for the frame being traced ahead.
+ * spcbpt_viewer_set_light_ahead(v, on) = set_pipeline(v, on ? 1 : 0). */
 int spcbpt_viewer_set_pipeline(spcbpt_viewer* v, int mode);
 int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on);
 int spcbpt_viewer_frame(spcbpt_viewer* v);

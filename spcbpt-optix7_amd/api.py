@@ -516,6 +516,10 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_sync": [vp], "spcbpt_sync_film": [vp], "spcbpt_merge_deferred": [vp, i32], "spcbpt_launch_deferred": [vp, C.c_char_p, u32, i32, i32, i32],
         "spcbpt_sync_light": [vp],
         "spcbpt_set_light_ahead": [vp, i32],
+        "spcbpt_get_pipeline_state": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+        "spcbpt_reuse_sampler": [vp],
+        "spcbpt_read_film": [vp, vp, vp],
+        "spcbpt_debug_batch_scratch": [vp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32)],
         "spcbpt_lvc_import_wait": [vp],
         "spcbpt_kernel_time": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i32)],
         "spcbpt_reset_kernel_time": [vp],
@@ -580,7 +584,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_debug_trace_bench",
-    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_get_pipeline_state", "spcbpt_reuse_sampler", "spcbpt_read_film", "spcbpt_debug_batch_scratch", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -768,6 +772,27 @@ class Renderer:
 
     def clear_accum(self):
         self._chk(self.lib.spcbpt_clear_accum(self.h), "clear_accum")
+
+    def read_film(self, accum=True, frame=True):
+        """(accum, frame) as of the last queued film merge, without waiting for launches queued behind it (spcbpt_read_film)."""
+        self.image_size()
+        a = np.zeros((self.height, self.width, 4), dtype=np.float32) if accum else None
+        f = np.zeros((self.height, self.width, 4), dtype=np.uint8) if frame else None
+        self._chk(self.lib.spcbpt_read_film(self.h, a.ctypes.data if accum else None, f.ctypes.data if frame else None), "read_film")
+        return a, f
+
+    def pipeline_state(self):
+        v = [C.c_int32() for _ in range(4)]
+        self._chk(self.lib.spcbpt_get_pipeline_state(self.h, *[C.byref(x) for x in v]), "get_pipeline_state")
+        return dict(zip(("light_ahead", "pending_passes", "sampler_intact", "deferred"), (int(x.value) for x in v)))
+
+    def reuse_sampler(self):
+        self._chk(self.lib.spcbpt_reuse_sampler(self.h), "reuse_sampler")
+
+    def batch_scratch(self):
+        b, f, k = C.c_int64(), C.c_int32(), C.c_int32()
+        self._chk(self.lib.spcbpt_debug_batch_scratch(self.h, C.byref(b), C.byref(f), C.byref(k)), "debug_batch_scratch")
+        return {"bytes": int(b.value), "frames": int(f.value), "fallbacks": int(k.value)}
 
     def lvc_read(self, capacity=None):
         if capacity is None:

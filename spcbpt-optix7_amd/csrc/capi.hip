@@ -332,6 +332,8 @@ int Context::ensure_lvc_capacity(size_t n) {
     }
     for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; set_bound[s2] = -1; ev_exch_set[s2] = false; }   // the sets are empty again
     pending.clear();
+    built_sets.clear();   // samplers built in the old allocations went with them
+    free_batch_build_scratch();
     select_set(lset);
     HIP_TRY(this, dev_alloc(&d_keys, n)); HIP_TRY(this, dev_alloc(&d_keys2, n));
     HIP_TRY(this, dev_alloc(&d_vals, n));
@@ -458,10 +460,11 @@ int Context::launch_light(uint32_t frame) {
     else if (keys_set == lset) keys_ready = false;   // the set was rewritten by the other lane: lane 0's keys no longer describe it
     lvc_count = -1;  // known on the device only until the next host read
     set_count_host[lset] = -1;
-    // With passes running ahead (spcbpt_set_light_ahead) the sampler the eye launches read (set `eset`) stays valid while later
-    // passes fill OTHER sets of the ring -- an interactive loop that drops a speculative frame renders it again from that sampler
-    // (csrc/viewer.cpp); without, a new light pass means "build before you render", as in the reference's loop.
-    if (!light_ahead || eset == lset) have_sampler = false;
+    // A new light pass means "build before you render", as in the reference's loop -- also with passes running ahead: a host loop
+    // that launches a pass and forgets the build gets SPCBPT_ERR_STATE from its next eye launch, not last frame's sampler.  The
+    // tables of set `eset` are in fact still intact while later passes fill OTHER sets of the ring; a host that means to render
+    // from them once more (csrc/viewer.cpp: a speculative frame dropped and traced again) says so with spcbpt_reuse_sampler.
+    have_sampler = false;
     // (vertex_count, path_count) to pinned host memory, inside the event: the sampler build reads them after waiting for
     // THIS pass only, not for whatever else has been queued on the stream since
     HIP_TRY(this, hipMemcpyAsync(h_light_counts + 2 * lset, d_sampler_counts, 2 * sizeof(int), hipMemcpyDeviceToHost, ls));
@@ -684,6 +687,16 @@ int Context::build_sampler() {
     return 0;
 }
 
+void Context::free_batch_build_scratch() {
+    dev_free(sbb_keys); dev_free(sbb_weights); dev_free(sbb_wsorted); dev_free(sbb_hist);
+    sbb_keys = nullptr; sbb_weights = nullptr; sbb_wsorted = nullptr; sbb_hist = nullptr;
+    sbb_frames = 0; sbb_capacity = 0;
+}
+size_t Context::sbb_debug_limit() const {
+    const char* e = getenv("SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT");
+    return e ? (size_t)strtoull(e, nullptr, 10) : ~(size_t)0;
+}
+
 // LVC_Process for the n OLDEST light passes that have no sampler yet, as ONE set of four launches (kernels.hip: SamplerBuildBatch).
 // The tables are those of n build_sampler calls -- the same kernels with the frame in blockIdx.y -- and the sets end up in the same
 // state; what goes is n - 1 times the four dependent launches (0.12 ms per build: 2.4 ms in front of a 20-frame eye launch that
@@ -700,17 +713,41 @@ int Context::build_sampler_batch(int n) {
         for (int k = 0; k < n; k++) { const int rc = build_sampler(); if (rc) return rc; }
         return 0;
     }
-    if (!sbb_keys || sbb_frames < n || sbb_capacity < lvc_capacity) {   // scratch of the batch: per frame what d_keys / d_weights / d_wsorted / d_hist are to one build
+    // Scratch of the batch: per frame what d_keys / d_weights / d_wsorted / d_hist are to one build -- sized by the builds of THIS call
+    // (n frames x the largest item bound among them: a host-known count, a gathered import's bound, or the set capacity for a pass
+    // whose count only the device knows), not by the widest batch and the padded capacity the context could ever see: with an
+    // uncalibrated cache (core_count x padding) 32 x capacity x 16 B would be gigabytes.  It only grows; spcbpt_lvc_set_capacity
+    // and leaving light-ahead mode free it.  If the device cannot hold it the builds run one by one (build_sampler's own scratch).
+    size_t stride = 1;
+    for (int k = 0; k < n; k++) {
+        const int b = pending[(size_t)k];
+        const int count = set_bound[b] >= 0 ? set_bound[b] : set_count_host[b];
+        stride = std::max(stride, count < 0 ? lvc_capacity : std::min((size_t)count, lvc_capacity));
+    }
+    stride = (stride + 4095) / 4096 * 4096;
+    if (!sbb_keys || sbb_frames < n || sbb_capacity < stride) {
         if (sync_all()) return SPCBPT_ERR_HIP;
-        dev_free(sbb_keys); dev_free(sbb_weights); dev_free(sbb_wsorted); dev_free(sbb_hist);
-        sbb_keys = nullptr; sbb_weights = nullptr; sbb_wsorted = nullptr; sbb_hist = nullptr;
-        const int frames = std::max(n, std::min((int)kMaxBatchFrames, std::max(eye_batch, n)));
-        HIP_TRY(this, dev_alloc(&sbb_keys, (size_t)frames * lvc_capacity)); HIP_TRY(this, dev_alloc(&sbb_weights, (size_t)frames * lvc_capacity));
-        HIP_TRY(this, dev_alloc(&sbb_wsorted, (size_t)frames * lvc_capacity)); HIP_TRY(this, dev_alloc(&sbb_hist, (size_t)frames * sampler_build_hist_ints()));
-        sbb_frames = frames; sbb_capacity = lvc_capacity;
+        const int frames = std::max(n, sbb_frames);
+        const size_t cap = std::max(stride, sbb_capacity);
+        free_batch_build_scratch();
+        const size_t limit = sbb_debug_limit();   // tests: pretend the device refuses more than this many bytes of batch scratch
+        const size_t bytes = (size_t)frames * cap * (sizeof(uint32_t) + sizeof(float) + sizeof(double));
+        bool ok = bytes <= limit;
+        ok = ok && dev_alloc(&sbb_keys, (size_t)frames * cap) == hipSuccess;
+        ok = ok && dev_alloc(&sbb_weights, (size_t)frames * cap) == hipSuccess;
+        ok = ok && dev_alloc(&sbb_wsorted, (size_t)frames * cap) == hipSuccess;
+        ok = ok && dev_alloc(&sbb_hist, (size_t)frames * sampler_build_hist_ints()) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();   // (an allocation failure is sticky in hipGetLastError only)
+            free_batch_build_scratch();
+            sbb_fallbacks++;
+            for (int k = 0; k < n; k++) { const int rc = build_sampler(); if (rc) return rc; }
+            return 0;
+        }
+        sbb_frames = frames; sbb_capacity = cap;
     }
     SamplerBuildBatch B = {};
-    B.keys = sbb_keys; B.weights = sbb_weights; B.wsorted = sbb_wsorted; B.hist = sbb_hist; B.item_stride = lvc_capacity;
+    B.keys = sbb_keys; B.weights = sbb_weights; B.wsorted = sbb_wsorted; B.hist = sbb_hist; B.item_stride = sbb_capacity;
     int sets[kMaxBatchFrames];
     for (int k = 0; k < n; k++) {
         const int b = pending[(size_t)k];
@@ -916,6 +953,7 @@ int Context::sync_film() {
 }
 
 int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, int rs) {
+    if (deferred.active) { error = "a deferred frame is outstanding: spcbpt_merge_deferred(ctx, keep) first"; return SPCBPT_ERR_STATE; }
     if (!d_accum) { error = "render before spcbpt_resize"; return SPCBPT_ERR_STATE; }
     if (!have_camera) { error = "render before spcbpt_set_camera"; return SPCBPT_ERR_STATE; }
     if (!have_subspace) { error = "SPCBPT_eye needs a subspace tuple and a built sampler"; return SPCBPT_ERR_STATE; }
@@ -1065,6 +1103,7 @@ Context::~Context() {
         if (ev_merge[s]) (void)hipEventDestroy(ev_merge[s]);
         dev_free(d_result[s]); dev_free(d_spill_rs[s]);
     }
+    if (cstream) (void)hipStreamDestroy(cstream);
     if (stream) (void)hipStreamDestroy(stream);
     for (int s = 0; s < kMaxSets; s++) {
         if (ev_sampler[s]) (void)hipEventDestroy(ev_sampler[s]);
@@ -1375,6 +1414,7 @@ int spcbpt_lvc_set_capacity(spcbpt_ctx* c, int vertices) {
     CTX_CHECK(c);
     if (vertices < 0) { c->error = "lvc_set_capacity: negative capacity"; return SPCBPT_ERR_INVALID_ARG; }
     c->lvc_fixed = (size_t)vertices;
+    if (c->sbb_keys) { if (c->sync_all()) return SPCBPT_ERR_HIP; c->free_batch_build_scratch(); }   // sized for the old capacity's builds
     if (vertices == 0) { c->lvc_probe_needed = true; return SPCBPT_OK; }   // back to the probe pass (the sets only ever grow)
     c->lvc_probe_needed = false;
     return c->ensure_lvc_capacity((size_t)vertices);
@@ -1574,6 +1614,26 @@ int spcbpt_read_frame(spcbpt_ctx* c, uint8_t* out) {
     HIP_TRY(c, hipMemcpy(out, c->d_frame, (size_t)c->kp.width * c->kp.height * 4, hipMemcpyDeviceToHost));
     return SPCBPT_OK;
 }
+// The film as of the last queued merge (spcbpt_sync_film's wait), copied on a stream of its own: launches queued BEHIND that merge --
+// the interactive loop's speculative next frame, light passes ahead -- are not waited for, which spcbpt_read_accum / _frame do.
+int spcbpt_read_film(spcbpt_ctx* c, float* accum_out, uint8_t* frame_out) {
+    CTX_CHECK(c);
+    if (!c->d_accum || !c->d_frame) { c->error = "no film (spcbpt_resize first)"; return SPCBPT_ERR_STATE; }
+    if (!c->cstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+    if (c->last_merge_k >= 0 && c->ev_merge_set[c->last_merge_k]) HIP_TRY(c, hipStreamWaitEvent(c->cstream, c->ev_merge[c->last_merge_k], 0));
+    const size_t px = (size_t)c->kp.width * c->kp.height;
+    if (accum_out) HIP_TRY(c, hipMemcpyAsync(accum_out, c->d_accum, px * 16, hipMemcpyDeviceToHost, c->cstream));
+    if (frame_out) HIP_TRY(c, hipMemcpyAsync(frame_out, c->d_frame, px * 4, hipMemcpyDeviceToHost, c->cstream));
+    HIP_TRY(c, hipStreamSynchronize(c->cstream));
+    return c->check_diag();
+}
+int spcbpt_debug_batch_scratch(spcbpt_ctx* c, int64_t* bytes, int* frames, int* fallbacks) {
+    CTX_CHECK(c);
+    if (bytes) *bytes = c->sbb_keys ? (int64_t)((size_t)c->sbb_frames * c->sbb_capacity * 16 + (size_t)c->sbb_frames * sampler_build_hist_ints() * sizeof(int)) : 0;
+    if (frames) *frames = c->sbb_frames;
+    if (fallbacks) *fallbacks = c->sbb_fallbacks;
+    return SPCBPT_OK;
+}
 int spcbpt_accum_device_ptr(spcbpt_ctx* c, void** p) {
     CTX_CHECK(c);
     if (!p || !c->d_accum) return SPCBPT_ERR_STATE;
@@ -1583,6 +1643,7 @@ int spcbpt_accum_device_ptr(spcbpt_ctx* c, void** p) {
 int spcbpt_clear_accum(spcbpt_ctx* c) {
     CTX_CHECK(c);
     if (!c->d_accum) return SPCBPT_ERR_STATE;
+    if (c->deferred.active) { c->error = "clear_accum: a deferred frame is outstanding (its merge would land in the cleared film): spcbpt_merge_deferred(ctx, keep) first"; return SPCBPT_ERR_STATE; }
     if (c->sync_all()) return SPCBPT_ERR_HIP;   // merges of both render streams may still be pending
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->kp.width * c->kp.height * 16, c->rstreams[0]));
     HIP_TRY(c, hipStreamSynchronize(c->rstreams[0]));
@@ -1629,9 +1690,31 @@ int spcbpt_stream(spcbpt_ctx* c, void** s) { CTX_CHECK(c); if (!s) return SPCBPT
 // latest light pass, as the single-GPU loop expects.  Switching clears the queue.
 int spcbpt_set_light_ahead(spcbpt_ctx* c, int on) {
     CTX_CHECK(c);
+    if (c->deferred.active) { c->error = "set_light_ahead: a deferred frame is outstanding: spcbpt_merge_deferred(ctx, keep) first"; return SPCBPT_ERR_STATE; }
     if (c->sync_all()) return SPCBPT_ERR_HIP;
+    const bool was = c->light_ahead;
     c->light_ahead = on != 0;
     c->pending.clear();
+    if (was && !c->light_ahead) c->free_batch_build_scratch();   // only loops with passes ahead build in batches
+    return SPCBPT_OK;
+}
+
+// What a host loop that shares the context with other code (csrc/viewer.cpp) re-validates its own flags against.
+int spcbpt_get_pipeline_state(spcbpt_ctx* c, int* light_ahead, int* pending_passes, int* sampler_intact, int* deferred_outstanding) {
+    CTX_CHECK(c);
+    if (light_ahead) *light_ahead = c->light_ahead ? 1 : 0;
+    if (pending_passes) *pending_passes = (int)c->pending.size();
+    if (sampler_intact) *sampler_intact = c->sampler_intact() ? 1 : 0;
+    if (deferred_outstanding) *deferred_outstanding = c->deferred.active ? 1 : 0;
+    return SPCBPT_OK;
+}
+
+// The sampler built last serves eye launches again although a later light pass has been launched since -- if its tables are
+// intact (the pass went to another set of the ring; nothing re-installed the tuple, the sky or the cache geometry meanwhile).
+int spcbpt_reuse_sampler(spcbpt_ctx* c) {
+    CTX_CHECK(c);
+    if (!c->sampler_intact()) { c->error = "reuse_sampler: the tables of the last sampler build are gone (a light pass, an import or a new tuple took their set)"; return SPCBPT_ERR_STATE; }
+    c->have_sampler = true;
     return SPCBPT_OK;
 }
 

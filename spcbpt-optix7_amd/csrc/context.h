@@ -30,6 +30,7 @@ struct Context {
     // loop launch("light trace") -> build_sampler -> launch("SPCBPT_eye") keeps its meaning while frame f+1's light pass
     // fills the idle machine under frame f's drain.  SPCBPT_OVERLAP=0 puts everything back on one stream.
     hipStream_t rstream = nullptr;              // = rstreams[rk], the stream of the render launch being issued
+    hipStream_t cstream = nullptr;              // spcbpt_read_film's copies (created on first use)
     // Consecutive render launches alternate between two streams, each with its own work counter, spill area and `result`
     // buffer: frame f+1's eye kernel starts filling the machine while frame f's drains.  Only the film merges (running mean +
     // tone map from `result` into accum/frame) are chained, by ev_merge, so the image is the same as with one stream.
@@ -209,7 +210,12 @@ struct Context {
     int build_sampler();
     int build_sampler_batch(int n);   // the n oldest pending passes in one set of four launches (capi.hip)
     uint32_t* sbb_keys = nullptr; float* sbb_weights = nullptr; double* sbb_wsorted = nullptr; int* sbb_hist = nullptr;   // its scratch: per frame what d_keys .. d_hist are
-    int sbb_frames = 0; size_t sbb_capacity = 0;
+    int sbb_frames = 0; size_t sbb_capacity = 0;   // frames x items per frame it holds
+    int sbb_fallbacks = 0;                          // batches built one by one because the scratch could not be allocated
+    void free_batch_build_scratch();
+    size_t sbb_debug_limit() const;
+    // the tables of the last sampler build are still what that build left (no later pass, import or re-allocation took the set)
+    bool sampler_intact() const { return !built_sets.empty() && built_sets.back() == eset && ev_sampler_set[eset]; }
     int launch_render(const char* name, bool spcbpt_alg, uint32_t frame, int r0, int r1, int rs, bool full_mis = false, bool defer_merge = false);
     // spcbpt_launch_deferred: a render launch whose film merge (running mean + tone map from its `result` buffer) has not been queued:
     // the frame is either merged later (merge_deferred(true)) or never (false) -- the interactive loop's speculative next frame

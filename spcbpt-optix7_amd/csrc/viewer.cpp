@@ -136,7 +136,21 @@ struct spcbpt_viewer {
     int spec_alg = -1;                // ... of this algorithm
     uint32_t spec_subframe = 0;       // ... and subframe index
     long long frames = 0, spec_hits = 0, spec_drops = 0;
+    int ctx_light_ahead_at_create = 0;   // the context's mode as the viewer found it: restored by spcbpt_viewer_destroy
+    void revalidate();
 };
+
+// The viewer's flags describe work it queued on the context; a host that shares the context may have consumed or invalidated it
+// between two frames (merged / dropped the deferred frame, switched light-ahead mode, installed a new tuple or sky, imported a
+// cache).  Each frame starts from what the context says; the light-pass counter is wound back over passes that are gone.
+void spcbpt_viewer::revalidate() {
+    if (!ctx) return;
+    int ahead = 0, pend = 0, intact = 0, deferred = 0;
+    if (spcbpt_get_pipeline_state(ctx, &ahead, &pend, &intact, &deferred)) return;
+    if (spec_in_flight && !deferred) spec_in_flight = false;
+    if (light_pending && pend == 0) { light_pending = false; lt_launch_frame--; }
+    if (sampler_ready && !intact) { sampler_ready = false; lt_launch_frame--; }
+}
 
 extern "C" {
 
@@ -158,14 +172,26 @@ int spcbpt_viewer_create(spcbpt_ctx* ctx, const float eye[3], const float lookat
     v->trackball.setReferenceFrame(mk(1.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 1.0f), mk(0.0f, 1.0f, 0.0f));
     v->trackball.gimbalLock = true;
     if (ctx) {   // the default loop runs a frame ahead (pipeline 2): light passes may then be launched before their sampler is built
-        const int rc = spcbpt_set_light_ahead(ctx, 1);
+        int rc = spcbpt_get_pipeline_state(ctx, &v->ctx_light_ahead_at_create, nullptr, nullptr, nullptr);
+        if (!rc) rc = spcbpt_set_light_ahead(ctx, 1);
         if (rc) { delete v; return rc; }
     }
     *out = v;
     return SPCBPT_OK;
 }
 
-void spcbpt_viewer_destroy(spcbpt_viewer* v) { delete v; }
+// Leaves the context as spcbpt_viewer_create found it: the frame traced ahead is dropped, the light passes launched ahead leave
+// the queue and the light-ahead mode goes back to what it was -- a host that goes on with the plain loop (light pass, build, eye
+// launch) on the same context gets the reference's frames, not SPCBPT_ERR_STATE or the sampler of a pass the viewer queued.
+void spcbpt_viewer_destroy(spcbpt_viewer* v) {
+    if (!v) return;
+    if (v->ctx) {
+        int deferred = 0;
+        if (!spcbpt_get_pipeline_state(v->ctx, nullptr, nullptr, nullptr, &deferred) && deferred) (void)spcbpt_merge_deferred(v->ctx, 0);
+        (void)spcbpt_set_light_ahead(v->ctx, v->ctx_light_ahead_at_create);   // (waits for what is queued; clears the pending passes)
+    }
+    delete v;
+}
 
 // mouseButtonCallback (121-136).  GLFW codes: button 0 left, 1 right, 2 middle; action 1 press, 0 release.  The position is
 // the cursor's at the time of the click (glfwGetCursorPos).
@@ -284,6 +310,7 @@ int spcbpt_viewer_set_light_ahead(spcbpt_viewer* v, int on) { return spcbpt_view
 int spcbpt_viewer_frame(spcbpt_viewer* v) {
     if (!v) return SPCBPT_ERR_INVALID_ARG;
     const auto t0 = std::chrono::steady_clock::now();
+    v->revalidate();
     // updateState (372-379)
     const bool state_changed = v->camera_changed || v->resize_dirty || v->one_frame_render_only;   // what a frame traced ahead did not know
     if (state_changed) v->subframe_index = 0;
@@ -317,6 +344,8 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
             if (rc) return rc;
         }
         if (!have) {
+            // a frame traced ahead was dropped: its sampler (built a call ago, a later pass launched since) serves again if the context still has it
+            if (spcbpt && v->sampler_ready && spcbpt_reuse_sampler(v->ctx) != SPCBPT_OK) { v->sampler_ready = false; v->lt_launch_frame--; }
             if (spcbpt && !v->sampler_ready) {  // launchLVCTrace (515-522)
                 if (!v->light_pending) rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);   // (else: launched ahead by the previous frame)
                 if (rc) return rc;
@@ -329,12 +358,16 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
         }
         if (spcbpt) v->sampler_ready = false;   // consumed by the frame being shown
         // ---- ahead of the display
-        if (v->pipeline == 1 && spcbpt && !v->light_pending) {   // the next frame's light pass, beside this frame's eye kernel
+        // Mode 2 speculates only from a steady view: a call that itself saw an event (a drag in progress, a resize, a key) is likely to
+        // be followed by another, the frame queued here would be dropped by it -- after running to completion beside the real frame,
+        // i.e. two eye kernels per displayed frame for as long as the camera moves.  Such a call runs ahead as mode 1 does.
+        const bool speculate = v->pipeline == 2 && !v->one_frame_render_only && !state_changed;
+        if (v->pipeline >= 1 && !speculate && spcbpt && !v->light_pending) {   // the next frame's light pass, beside this frame's eye kernel
             rc = spcbpt_launch(v->ctx, "light trace", ++v->lt_launch_frame, 0, 0, 1);
             if (rc) return rc;
             v->light_pending = true;
         }
-        if (v->pipeline == 2 && !v->one_frame_render_only) {
+        if (speculate) {
             // frame f + 1, assuming that nothing changes: sampler build (its light pass was launched a call ago and ran beside the
             // eye kernel of f), eye launch without the film merge, and the light pass of f + 2 beside it
             if (spcbpt) {
@@ -353,6 +386,8 @@ int spcbpt_viewer_frame(spcbpt_viewer* v) {
                 v->light_pending = true;
             }
             rc = spcbpt_sync_film(v->ctx);   // the frame to show is complete; what was queued behind it keeps running
+        } else if (v->pipeline == 2) {
+            rc = spcbpt_sync_film(v->ctx);   // (the light pass launched ahead keeps running)
         } else {
             rc = spcbpt_sync(v->ctx);  // CUDA_SYNC_CHECK: the interactive loop shows every subframe
         }

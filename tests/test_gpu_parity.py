@@ -631,3 +631,50 @@ def test_batched_sampler_build_and_merge_equal_single_ones(gpu, pkg, monkeypatch
         r.build_sampler_batch(33)
     with pytest.raises(pkg.SpcbptError):
         r.build_sampler_batch(0)
+
+
+@pytest.mark.gpu
+def test_batched_build_scratch_is_sized_by_the_batch_and_falls_back_when_it_cannot_be_had(gpu, pkg, monkeypatch):
+    """The scratch of spcbpt_build_sampler_batch is n frames x the largest item bound of the builds at hand x 16 B (+ histograms) --
+    not 32 frames x the padded capacity; it is freed by spcbpt_lvc_set_capacity and by leaving light-ahead mode; and when the device
+    refuses it (SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT) the batch is built one pass at a time with the SAME tables."""
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    monkeypatch.setenv("SPCBPT_EYE_BATCH", "8")
+    r = pkg.Renderer(scene, 0)
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+    r.resize(64, 64)
+    r.set_light_trace(3000, 64, 1)
+    r.set_subspace()
+    r.set_light_ahead(True)
+    assert r.batch_scratch() == {"bytes": 0, "frames": 0, "fallbacks": 0}
+    r.launch_light_batch(1, 3)
+    r.build_sampler_batch(3)
+    cap, _ = r.lvc_capacity()
+    st = r.batch_scratch()
+    assert st["frames"] == 3 and st["fallbacks"] == 0          # 3, not the 8 (or 32) the context is sized for
+    assert 3 * cap * 16 <= st["bytes"] <= 3 * (cap + 4096) * 16 + 3 * (4 << 20)   # + the per-frame block histograms
+    want = r.sampler_read()
+    r.launch_eye_batch([0, 1, 2]); r.sync()
+    film = r.read_accum().copy()
+    # freed with the capacity it was sized for, and when passes stop running ahead
+    r.lvc_set_capacity(cap)
+    assert r.batch_scratch()["bytes"] == 0
+    r.launch_light_batch(1, 3); r.build_sampler_batch(3)
+    assert r.batch_scratch()["bytes"] > 0
+    r.launch_eye_batch([0, 1, 2]); r.sync()
+    r.set_light_ahead(False)
+    assert r.batch_scratch()["bytes"] == 0
+    # the device "refuses": single builds, same tables, same film
+    r.set_light_ahead(True)
+    monkeypatch.setenv("SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT", "4096")
+    r.clear_accum()
+    r.launch_light_batch(1, 3)
+    r.build_sampler_batch(3)
+    st = r.batch_scratch()
+    assert st["bytes"] == 0 and st["fallbacks"] == 1
+    got = r.sampler_read()
+    assert (got[3], got[4]) == (want[3], want[4])
+    assert all(np.array_equal(x, y) for x, y in zip(got[:3], want[:3]))
+    r.launch_eye_batch([0, 1, 2]); r.sync()
+    assert np.array_equal(r.read_accum(), film)

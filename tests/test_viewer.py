@@ -205,3 +205,132 @@ def test_deferred_launch_is_the_plain_launch_once_merged(gpu, pkg):
     assert np.array_equal(before, b.read_accum())
     with pytest.raises(pkg.SpcbptError, match="no deferred"):
         b.merge_deferred(True)
+
+
+def _small_renderer(pkg, size=64):
+    scene = pkg.scenes.cornell_box()
+    cam = scene.camera
+    r = pkg.Renderer(scene, 0)
+    r.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], 1.0)
+    r.resize(size, size)
+    r.set_light_trace(3000, 64, 1)
+    r.set_subspace()
+    return r, cam
+
+
+@pytest.mark.gpu
+def test_destroying_the_viewer_hands_the_context_back_as_it_was_found(gpu, pkg):
+    """After spcbpt_viewer_frame the context holds a frame traced ahead (deferred), a light pass launched ahead and light-ahead
+    mode.  spcbpt_viewer_destroy drops all of it and restores the mode it found: the plain loop (light pass, build, eye launch)
+    on the same context then renders what it renders on a fresh one -- no SPCBPT_ERR_STATE, no sampler of a queued pass."""
+    a, cam = _small_renderer(pkg)
+    b, _ = _small_renderer(pkg)
+    assert a.pipeline_state()["light_ahead"] == 0
+    v = pkg.api.Viewer(a, cam["eye"], cam["lookat"], cam["up"], cam["fov"], 64, 64)
+    assert a.pipeline_state()["light_ahead"] == 1
+    for _ in range(3):
+        v.frame()
+    st = a.pipeline_state()
+    assert st["deferred"] == 1 and st["pending_passes"] == 1 and st["sampler_intact"] == 1
+    with pytest.raises(pkg.SpcbptError, match="deferred"):
+        a.launch("SPCBPT_eye", 0)
+    v.close()
+    st = a.pipeline_state()
+    assert st == {"light_ahead": 0, "pending_passes": 0, "sampler_intact": st["sampler_intact"], "deferred": 0}
+    for r in (a, b):
+        r.clear_accum()
+        for f in range(3):
+            r.render_frame("SPCBPT_eye", f, launch_frame=100 + f)
+        r.sync()
+    assert np.array_equal(a.read_accum(), b.read_accum())
+    # a viewer created on a context that already runs passes ahead leaves that mode on
+    a.set_light_ahead(True)
+    v = pkg.api.Viewer(a, cam["eye"], cam["lookat"], cam["up"], cam["fov"], 64, 64)
+    v.frame(); v.close()
+    assert a.pipeline_state()["light_ahead"] == 1
+
+
+@pytest.mark.gpu
+def test_moving_camera_does_not_speculate_and_read_film_shows_the_frame(gpu, pkg):
+    """Mode 2 speculates from a steady view only: during a drag (every call sees a camera change) no frame is queued to be dropped
+    -- the context holds no deferred frame after such a call -- and the first steady calls trace ahead again.  The frames are the
+    reference order's (mode 0) bit for bit, read with spcbpt_read_film, which waits for the shown frame's merge only."""
+    shots = {}
+    for mode in (0, 2):
+        r, cam = _small_renderer(pkg)
+        v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], 64, 64)
+        if mode == 0:
+            v.set_pipeline(0)
+        out, deferred = [], []
+        v.frame(); v.frame()
+        deferred.append(r.pipeline_state()["deferred"])
+        v.mouse_button("left", 1, 30, 30)
+        for k in range(5):                                   # a drag in progress: one event per displayed frame
+            v.cursor_pos(31 + 2 * k, 30 + k)
+            v.frame()
+            deferred.append(r.pipeline_state()["deferred"])
+            out.append([x.copy() for x in r.read_film()])
+        v.mouse_button("left", 0, 41, 35)
+        for k in range(3):                                   # steady again
+            v.frame()
+            deferred.append(r.pipeline_state()["deferred"])
+            out.append([x.copy() for x in r.read_film()])
+        assert np.array_equal(out[-1][0], r.read_accum()) and np.array_equal(out[-1][1], r.read_frame())
+        shots[mode] = (out, deferred)
+        v.close()
+    assert shots[0][1] == [0] * 9
+    assert shots[2][1] == [1] + [0] * 5 + [1] * 3
+    for k, (x, y) in enumerate(zip(shots[0][0], shots[2][0])):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), k
+
+
+@pytest.mark.gpu
+def test_viewer_tolerates_a_host_that_consumes_what_it_queued(gpu, pkg):
+    """Between two viewer frames the host drops the deferred frame and resets the light-ahead queue itself: the next viewer frame
+    re-validates its flags against the context (spcbpt_get_pipeline_state) instead of failing in the middle."""
+    r, cam = _small_renderer(pkg)
+    v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], 64, 64)
+    v.frame(); v.frame()
+    r.merge_deferred(False)
+    r.set_light_ahead(True)            # clears the queue of unbuilt passes
+    v.frame(); v.frame()
+    a = r.read_accum()
+    assert np.isfinite(a).all() and a[..., :3].mean() > 0
+    assert v.state()["subframe_index"] == 4
+    v.close()
+
+
+@pytest.mark.gpu
+def test_deferred_frame_blocks_everything_that_would_reorder_the_film(gpu, pkg):
+    """While a deferred frame is outstanding spcbpt_launch_eye_batch, spcbpt_clear_accum and spcbpt_set_light_ahead are refused
+    like every other render launch (include/spcbpt.h); a light pass invalidates the sampler also in light-ahead mode, and
+    spcbpt_reuse_sampler brings back the last build's tables while they are intact."""
+    r, _ = _small_renderer(pkg)
+    r.set_light_ahead(True)
+    r.launch("light trace", 1); r.build_sampler()
+    r.launch_deferred("SPCBPT_eye", 0)
+    with pytest.raises(pkg.SpcbptError, match="deferred"):
+        r.launch_eye_batch([1])
+    with pytest.raises(pkg.SpcbptError, match="deferred"):
+        r.clear_accum()
+    with pytest.raises(pkg.SpcbptError, match="deferred"):
+        r.set_light_ahead(False)
+    r.merge_deferred(True)
+    r.launch("light trace", 2)                       # a pass ahead: "build before you render"
+    with pytest.raises(pkg.SpcbptError, match="built sampler"):
+        r.launch("SPCBPT_eye", 1)
+    assert r.pipeline_state()["sampler_intact"] == 1
+    r.reuse_sampler()                                # ... unless the host says it means the last build's tables
+    r.launch("SPCBPT_eye", 1)
+    r.sync()
+    want, _ = _small_renderer(pkg)
+    want.launch("light trace", 1); want.build_sampler()
+    want.launch("SPCBPT_eye", 0); want.launch("SPCBPT_eye", 1); want.sync()
+    assert np.array_equal(r.read_accum(), want.read_accum())
+    # once a pass has taken the set, the tables are gone
+    sets = r.lvc_capacity()[1]
+    for k in range(sets):
+        r.launch("light trace", 3 + k)
+    assert r.pipeline_state()["sampler_intact"] == 0
+    with pytest.raises(pkg.SpcbptError, match="reuse_sampler"):
+        r.reuse_sampler()

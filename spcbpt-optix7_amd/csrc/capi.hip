@@ -185,12 +185,14 @@ int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_t
     if (!d_gamma) HIP_TRY(this, dev_alloc(&d_gamma, (size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE));
     HIP_TRY(this, hipMemcpyAsync(d_Q, h_Q.data(), h_Q.size() * 4, hipMemcpyHostToDevice, stream));
     HIP_TRY(this, hipMemcpyAsync(d_gamma, h_gamma.data(), h_gamma.size() * 4, hipMemcpyHostToDevice, stream));
-    {   // two-level copy for first-stage sampling (device_lib.h: sample_first_stage)
+    {   // three-level copy for first-stage sampling (device_lib.h: sample_first_stage3; layout.h: CMF2_*)
         std::vector<float> two((size_t)SPCBPT_NUM_SUBSPACE * CMF2_ROW, 2.0f);
         for (int e = 0; e < SPCBPT_NUM_SUBSPACE; e++) {
             float* row = &two[(size_t)e * CMF2_ROW];
-            memcpy(row + CMF2_COARSE, &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE], SPCBPT_NUM_SUBSPACE * sizeof(float));
-            for (int k = 0; k < CMF2_COARSE; k++) row[k] = row[CMF2_COARSE + 32 * k + 31];
+            float* fine = row + CMF2_COARSE + CMF2_MID;
+            memcpy(fine, &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE], SPCBPT_NUM_SUBSPACE * sizeof(float));
+            for (int m = 0; m < CMF2_MID; m++) row[CMF2_COARSE + m] = fine[8 * m + 7];
+            for (int k = 0; k < CMF2_COARSE; k++) row[k] = fine[64 * k + 63];
         }
         if (!d_gamma2) HIP_TRY(this, dev_alloc(&d_gamma2, two.size()));
         HIP_TRY(this, hipMemcpy(d_gamma2, two.data(), two.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1005,7 +1007,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     if (percent < 100) max_blocks = std::max(1, max_blocks * percent / 100);
     // the spill area is indexed by the thread of the grid ACTUALLY launched: n frames' tiles, capped by the resident slots
     // (sizing it for one frame's tiles let the blocks beyond one frame's share write past its end whenever that share was below max_blocks)
-    int rc = ensure_spill((size_t)spcbpt_batch_blocks(kp, max_blocks) * 256, true);
+    int rc = ensure_spill((size_t)spcbpt_batch_blocks(kp, max_blocks) * (size_t)spcbpt_block_threads(), true);
     if (rc) return rc;
     time_begin("spcbpt_render", rstream);
     launch_spcbpt_batch(kp, max_blocks, rstream);

@@ -392,10 +392,10 @@ SPC_DEV float quad_permf(float v) { return __uint_as_float(quad_perm<CTRL>(__flo
 // nearest hit and throws the others into the bag; a quad without a node takes one out.  Measured before this existed: 47 % of
 // the quad-tail iterations ran with one or two rays -- 56 lanes waiting for a dependent chain of fetches that they can now share.
 // An unoccluded ray visits exactly the nodes it visited before (all that its segment touches); an occluded one may find its
-// occluder earlier or later.  s_vis gets the same answers either way, so the film does not change.
+// occluder earlier or later.  The pass records the same answers either way, so the film does not change.
 template <bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV void fan_tail(const DeviceScene& S, const TravStack<BLOCK, STACK_LDS>& st, bool live, f3 o, f3 d, float tmax, uint32_t cur, int sp,
-                      int owner, uint32_t vis_slot, uint8_t* s_vis, uint8_t* list, Counts<COUNT>& cn) {
+                      int owner, uint32_t vis_slot, float4* s_rayw, uint8_t* list, Counts<COUNT>& cn) {
     static_assert(STACK_LDS == 16, "one bag row per ray of the quad tail, four entries per lane in the move");
     constexpr uint32_t NONE = 0xffffffffu;
     const uint32_t lane = lane_id_fresh(), qr = lane & 3u;
@@ -537,7 +537,7 @@ SPC_DEV void fan_tail(const DeviceScene& S, const TravStack<BLOCK, STACK_LDS>& s
             const bool more = sp != 0 || hb != 0 || (__ballot(cur != NONE) & gm) != 0ull;
             if (blocked || !more) {
                 live = false;
-                if (lane == gbase) s_vis[vis_slot] = blocked ? (uint8_t)0 : (uint8_t)1;
+                if (lane == gbase && blocked) s_rayw[vis_slot].w = -1.0f;   // an occluded pair is no connection (kernels.hip: the connect phase's test)
             }
 #undef SPC_FAN_SPILL__
         }
@@ -555,8 +555,8 @@ SPC_DEV void fan_tail(const DeviceScene& S, const TravStack<BLOCK, STACK_LDS>& s
 // (45 % of the shadow rays are occluded after a few nodes, others cross the whole scene): with one ray per lane per phase
 // the wave waits for its longest ray (measured: 21 % VALU lane utilisation in any-hit traversal); pulling keeps lanes busy.
 //   s_org[64]   origin of the shadow rays owned by lane l (its eye vertex)
-//   s_ray[192]  shadow ray it * 64 + l: direction.xyz, length (< 0: no ray in this slot)
-//   s_vis[192]  out: 1 = unoccluded
+//   s_ray[192]  shadow ray it * 64 + l: direction.xyz, length (< 0: no ray in this slot); out: the length of an OCCLUDED ray is
+//               set to -1 -- after the pass the slots that still hold a ray are the unoccluded pairs
 //   s_next      pool cursor, must be 0 on entry
 // Wave-scope fences around the call order the LDS traffic; all 64 lanes must call this together.
 static constexpr int POOL_RAYS = 64 * SPCBPT_CONNECTION_N;
@@ -578,8 +578,8 @@ SPC_DEV uint32_t pool_ray_list(const float4* s_ray, uint8_t* s_list) {
 //                   empty draw cost the whole wave an LDS atomic round trip with one lane active, and half the 192 slots are empty
 template <bool COUNT, int BLOCK, int STACK_LDS>
 SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, bool own, f3 own_o, f3 own_d, HitRec& own_hit,
-                        const float4* s_org, const float4* s_ray, uint8_t* s_vis, uint32_t* s_next, const uint8_t* s_list, uint32_t n_rays,
-                        Counts<COUNT>& cn) {
+                        const float4* s_org, float4* s_ray, uint32_t* s_next, const uint8_t* s_list, uint32_t n_rays,
+                        Counts<COUNT>& cn, const float4* s_hot = nullptr, const int n_hot = 0) {
     uint32_t r = 0;
     bool closest = own, done = false;
     unsigned long long quad_live = 0ull;   // != 0: the lanes whose rays the quad tail takes over
@@ -602,9 +602,15 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
     float4 R0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), R1 = R0, R2 = R0, R3 = R0;
 #define SPC_FETCH_STEP__()                                                                                            \
     do {                                                                                                              \
+        if ((uint32_t)node < (uint32_t)n_hot) {                                                                       \
+            /* one of the hottest nodes (lbvh.cpp numbers them first): the block's LDS copy, no trip through the vector L1 */ \
+            const float4* h__ = s_hot + node * 4;                                                                     \
+            R0 = h__[0]; R1 = h__[1]; R2 = h__[2]; R3 = h__[3];                                                       \
+        } else {                                                                                                      \
         /* one base: the triangle records follow the node records (DeviceScene::tri_base = n_nodes) */                \
         const size_t rb__ = (size_t)(uint32_t)(node < 0 ? S.tri_base + ~node : node) * 4;                             \
         R0 = ldq(S.nodes, rb__); R1 = ldq(S.nodes, rb__ + 1); R2 = ldq(S.nodes, rb__ + 2); R3 = ldq(S.nodes, rb__ + 3); \
+        }                                                                                                             \
     } while (0)
     if (node != kTravDone) SPC_FETCH_STEP__();
 #endif
@@ -683,7 +689,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                 closest = false;
                 best_tri = -1;
             } else {
-                s_vis[r] = occluded ? (uint8_t)0 : (uint8_t)1;
+                if (occluded) s_ray[r].w = -1.0f;   // the answer of a shadow ray: an occluded pair's slot holds no ray any more (the connect phase's test)
             }
         }
     }
@@ -802,7 +808,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                 }
                 if (finished) {
                     q_done = true;
-                    if (!q_closest && qr == 0u) s_vis[q_r] = q_occluded ? (uint8_t)0 : (uint8_t)1;
+                    if (!q_closest && qr == 0u && q_occluded) s_ray[q_r].w = -1.0f;
                 }
             }
         }
@@ -832,7 +838,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
         (void)q_done;
         if (SPC_FAN_TAIL && S.fan_tail && __any(q_node != kTravDone))
             fan_tail<COUNT, BLOCK, STACK_LDS>(S, st, q_node != kTravDone, qo, qd, q_best, q_node == kTravDone ? 0xffffffffu : stack_word(q_node, q_leaf > 0 ? q_leaf : 0), q_sp, owner,
-                                              q_r, s_vis, list, cn);
+                                              q_r, s_ray, list, cn);
     }
 }
 
@@ -1110,41 +1116,87 @@ SPC_DEV int uniform_sample(const int32_t* jump, int vertex_count, uint32_t& seed
 }
 
 // sampleFirstStage (cuProg.h:290-301) = binary_sample over the 1000-entry CMF row of the eye subspace: ten DEPENDENT probes.
-// For a non-decreasing CMF the bisection returns the first bin with u < cmf[bin], i.e. the number of entries <= u, which two
-// counting passes over 32 values each find in two round trips (coarse: every 32nd entry; fine: the 32 entries of that
-// segment; 8 independent 16-B loads per pass), plus one for the two CMF values of the pmf.  Same bin, same pmf, same random
-// number; the probe counter (algorithmic bytes) is charged what the bisection would have probed.
-template <bool COUNT, bool EXEC = false>   // EXEC: charge the 2 x 32 + 2 values the counting form really reads, not the bisection's probes
+// For a non-decreasing CMF the bisection returns the first bin with u < cmf[bin], i.e. the number of entries <= u, which THREE
+// counting passes find in three round trips of 4 / 2 / 2 independent 16-B loads (layout.h CMF2_*: 16 coarse entries row[64 k + 63],
+// the 8 middle entries row[8 m + 7] of coarse group k, the 8 entries of middle group m).  The two CMF values of the pmf need no
+// fetch of their own: in a non-decreasing row cmf[l] is the smallest value > u of the last group and cmf[l - 1] the largest value
+// <= u among everything the passes have read (the previous entry of the same group, or -- at a group's first entry -- the last
+// entry of the group before, which IS the middle / coarse value in front of the one that was counted).  Same bin, same pmf, same
+// random number; the probe counter (algorithmic bytes) is charged what the bisection would have probed.
+// (Rounds 1-4 ran two levels of 32: 16 loads and two more for the pmf per sample, 54 per vertex; this form reads 8 per sample and,
+// with the coarse level shared by the CONNECTION_N samples of a vertex, 16 per vertex.)
+struct Cmf3 { int count; float lo, hi; };   // entries <= u so far; largest entry <= u (-inf: none); smallest entry > u of the LAST pass
+SPC_DEV void cmf3_pass(float4 q, float u, Cmf3& c) {
+    const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool le = v[i] <= u;
+        c.count += le ? 1 : 0;
+        c.lo = fmaxf(c.lo, le ? v[i] : -INFINITY);
+        c.hi = fminf(c.hi, le ? INFINITY : v[i]);
+    }
+}
+// the CONNECTION_N (or fewer) samples of ONE eye subspace with the random numbers u[0 .. N): the coarse quads are fetched once
+template <int N, bool SERIAL = false>   // SERIAL: the middle and fine passes of one sample after the other (fewer registers in flight)
+SPC_DEV void sample_first_stage_n(const float* cmf_gamma2, int eye_subspace, const float u[N], int l[N], float pmf[N]) {
+    const float4* R = reinterpret_cast<const float4*>(cmf_gamma2 + (size_t)eye_subspace * CMF2_ROW);
+    const float4 c0 = R[0], c1 = R[1], c2 = R[2], c3 = R[3];
+    Cmf3 s[N];
+    float4 a[N], b[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i].count = 0; s[i].lo = -INFINITY; s[i].hi = INFINITY;
+        cmf3_pass(c0, u[i], s[i]); cmf3_pass(c1, u[i], s[i]); cmf3_pass(c2, u[i], s[i]); cmf3_pass(c3, u[i], s[i]);
+    }
+    if (SERIAL) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const float4* M = R + CMF2_COARSE / 4 + (size_t)s[i].count * 2;
+            const float4 m0 = M[0], m1 = M[1];
+            s[i].count *= 8; cmf3_pass(m0, u[i], s[i]); cmf3_pass(m1, u[i], s[i]);
+            const float4* F = R + (CMF2_COARSE + CMF2_MID) / 4 + (size_t)s[i].count * 2;
+            const float4 f0 = F[0], f1 = F[1];
+            s[i].count *= 8; s[i].hi = INFINITY;
+            cmf3_pass(f0, u[i], s[i]); cmf3_pass(f1, u[i], s[i]);
+            l[i] = s[i].count;
+            pmf[i] = s[i].count == 0 ? s[i].hi : s[i].hi - s[i].lo;
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) { const float4* M = R + CMF2_COARSE / 4 + (size_t)s[i].count * 2; a[i] = M[0]; b[i] = M[1]; }
+#pragma unroll
+    for (int i = 0; i < N; i++) { s[i].count *= 8; cmf3_pass(a[i], u[i], s[i]); cmf3_pass(b[i], u[i], s[i]); }
+#pragma unroll
+    for (int i = 0; i < N; i++) { const float4* F = R + (CMF2_COARSE + CMF2_MID) / 4 + (size_t)s[i].count * 2; a[i] = F[0]; b[i] = F[1]; }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i].count *= 8; s[i].hi = INFINITY;
+        cmf3_pass(a[i], u[i], s[i]); cmf3_pass(b[i], u[i], s[i]);
+        l[i] = s[i].count;
+        pmf[i] = s[i].count == 0 ? s[i].hi : s[i].hi - s[i].lo;
+    }
+}
+SPC_DEV int bisection_probes(int l, int size) {   // the probes of the reference's bisection on its way to bin l
+    int n = 0, mid = size / 2 - 1, a = 0, b = size;
+    while (b - a > 1) {
+        n++;
+        if (l <= mid) b = mid + 1; else a = mid + 1;
+        mid = (a + b) / 2 - 1;
+    }
+    return n;
+}
+template <bool COUNT, bool EXEC = false>   // EXEC: charge the 16 + 8 + 8 values the counting form really reads, not the bisection's probes
 SPC_DEV int sample_first_stage(const KParams& p, int eye_subspace, uint32_t& seed, float& pmf, Counts<COUNT>& cn) {
     // a caller-supplied matrix with a decreasing row (not a CMF) keeps the bisection, whose answer is then its own definition
     if (!p.cmf_gamma2) return binary_sample(p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, seed, pmf, cn);
-    const float u = rnd(seed);
-    const float4* R = reinterpret_cast<const float4*>(p.cmf_gamma2 + (size_t)eye_subspace * CMF2_ROW);
-    float4 q[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) q[i] = R[i];
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) k += (q[i].x <= u ? 1 : 0) + (q[i].y <= u ? 1 : 0) + (q[i].z <= u ? 1 : 0) + (q[i].w <= u ? 1 : 0);
-    const float4* F = R + (CMF2_COARSE / 4) + (size_t)k * 8;
-#pragma unroll
-    for (int i = 0; i < 8; i++) q[i] = F[i];
-    int l = 32 * k;
-#pragma unroll
-    for (int i = 0; i < 8; i++) l += (q[i].x <= u ? 1 : 0) + (q[i].y <= u ? 1 : 0) + (q[i].z <= u ? 1 : 0) + (q[i].w <= u ? 1 : 0);
-    const float* row = p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE;
-    const float hi = row[l], lo = l == 0 ? 0.0f : row[l - 1];
-    pmf = l == 0 ? hi : hi - lo;
-    if (COUNT && EXEC) cn.add(C_CMF, 66);
-    if (COUNT && !EXEC) {  // the probes of the reference's bisection on its way to bin l
-        int mid = SPCBPT_NUM_SUBSPACE / 2 - 1, a = 0, b = SPCBPT_NUM_SUBSPACE;
-        while (b - a > 1) {
-            cn.add(C_CMF);
-            if (l <= mid) b = mid + 1; else a = mid + 1;
-            mid = (a + b) / 2 - 1;
-        }
-    }
-    return l;
+    const float u[1] = {rnd(seed)};
+    int l[1];
+    float pm[1];
+    sample_first_stage_n<1>(p.cmf_gamma2, eye_subspace, u, l, pm);
+    pmf = pm[0];
+    if (COUNT) cn.add(C_CMF, EXEC ? 32u : (unsigned)bisection_probes(l[0], SPCBPT_NUM_SUBSPACE));
+    return l[0];
 }
 
 // ---- recursive MIS (rmis.h) ------------------------------------------------------

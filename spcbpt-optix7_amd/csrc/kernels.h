@@ -8,6 +8,7 @@
 namespace spc {
 
 int render_thread_count(const KParams& p);
+int spcbpt_block_threads();   // threads per block of the eye megakernel (kernels.hip: EYE_BLOCK)
 void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s);   // 0 timed, 1 reference order + counters (generic), 2 timed + counters
 int spcbpt_blocks_per_cu(int variant, bool batch, bool general);
 int render_tile_count(const KParams& p);

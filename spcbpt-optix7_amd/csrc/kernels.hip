@@ -14,6 +14,19 @@
 namespace spc {
 
 static constexpr int BLOCK = 256;
+// The eye megakernel's block.  Its waves share nothing but the LDS copy of the hottest BVH nodes (s_hot below), and a CU holds 16 of
+// them whatever the block size (4 per SIMD at 128 VGPRs; 16 x (4 KB of stack + a 5 840-B pool record) = 155 KB of its 160 KB of
+// LDS): the larger the block, the fewer copies of that table share what is left -- 19 nodes in each of four 256-thread blocks, 38
+// in each of two 512-thread blocks, 64 (all the builder numbers first) in ONE block of 1 024 threads per CU.
+#ifndef SPC_EYE_BLOCK
+#define SPC_EYE_BLOCK 256
+#endif
+#ifndef SPC_JOINT_FIRST_STAGE
+#define SPC_JOINT_FIRST_STAGE 0   // 1 / 2: the first stages of a vertex's connections on one coarse fetch (below: measured, slower)
+#endif
+static constexpr int EYE_BLOCK = SPC_EYE_BLOCK;
+static constexpr int EYE_HOT = SPC_EYE_BLOCK >= 1024 ? 64 : (SPC_EYE_BLOCK >= 512 ? 38 : 19);   // node records [0, EYE_HOT) live in LDS
+static_assert(EYE_HOT <= HOT_NODES, "the builder numbers HOT_NODES nodes first (layout.h)");
 static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
 static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye vertex through the traversal-stack LDS");
 #ifndef SPC_WAVES
@@ -52,7 +65,8 @@ static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye
 // ENV = false (timed forms only, chosen by the launcher for a scene with neither an environment map nor a material flagged
 // `brdf`, DeviceScene::general == 0): the direction tests and the flag's divisions (device_lib.h brdf_div) are compiled out.
 template <bool COUNT, bool BATCH, bool CACHE, bool ENV = true>
-__global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
+__global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p) {
+    constexpr int BLOCK = EYE_BLOCK;   // (this kernel's; the other kernels of the file run 256-thread blocks)
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
     // everything else a wave keeps in LDS sits in ONE record per wave: every field is then the wave's base (one SGPR) plus a
     // constant that folds into the ds instruction's offset.  As eight separate arrays the eight wave-uniform bases were spilled
@@ -62,13 +76,17 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         float4 org[64];             // eye vertex of lane l: position.xyz (= origin of its shadow rays), lastNormalProjection
         int32_t slot[POOL_RAYS];    // LVC slot of connection it * 64 + lane
         float pmf[POOL_RAYS];       // its resampling pmf (path_count * pmf2 * pmf1)
-        uint8_t vis[POOL_RAYS];     // 1 = unoccluded
         uint8_t job[POOL_RAYS];     // before the pass: slots that hold a ray; after it: the unoccluded connections, compacted
+                                    // (the pass answers a shadow ray in the ray's own slot: an occluded pair's length becomes -1 = no ray)
         uint32_t next;              // pool cursor
         uint32_t pad[3];
     };
     __shared__ WavePool s_pool[BLOCK / 64];
+    // the hottest nodes of the BVH (layout.h: HOT_NODES, numbered first by the builder), one copy per block
+    __shared__ float4 s_hot[EYE_HOT * 4];
     const DeviceScene& S = p.scene;
+    for (int i = (int)threadIdx.x; i < EYE_HOT * 4; i += BLOCK) s_hot[i] = i < S.tri_base * 4 ? ldq(S.nodes, (size_t)i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     // wave_in_block through readfirstlane: the per-wave LDS base below is then a wave-uniform value the compiler keeps in an SGPR
     const uint32_t lane = threadIdx.x & 63, wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WavePool* wp = s_pool + wave_in_block;
@@ -78,7 +96,6 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
     uint32_t* w_stack = s_stack + wave_in_block * 64;      // [entry * BLOCK + lane]: free between two traversal passes
     float4* w_ray = wp->ray;
     float4* w_org = wp->org;
-    uint8_t* w_vis = wp->vis;
     uint32_t* w_next = &wp->next;
     Counts<COUNT> cn;
     cn.clear();
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
         HitRec h;
         // (the next segment starts at the path's last vertex -- or at the camera for a path that was started in this iteration, whose
         // `cur` still holds the parked path's vertex: w.origin would be a copy kept alive across the pass for nothing)
-        trace_pool(S, st, alive && has_ray, fresh ? ld3(p.eye) : cur.c.pos, w.dir, h, w_org, w_ray, w_vis, w_next, w_job, n_rays, cn);
+        trace_pool(S, st, alive && has_ray, fresh ? ld3(p.eye) : cur.c.pos, w.dir, h, w_org, w_ray, w_next, w_job, n_rays, cn, s_hot, EYE_HOT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cur.sub = (int)(ids_a & 1023u); cur.lastZone = (int)((ids_a >> 10) & 1023u); cur.depth = (int)(ids_a >> 20);
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
             uint32_t my_live = 0u, n_jobs = 0u;
 #pragma unroll
             for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                const bool live = has_vertex && w_ray[it * 64 + lane].w >= 0.0f && w_vis[it * 64 + lane] != 0;
+                const bool live = has_vertex && w_ray[it * 64 + lane].w >= 0.0f;   // a ray was shot and found nothing in the way
                 const unsigned long long m = __ballot(live);
                 if (live) {
                     w_job[n_jobs + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(it * 64 + lane);
@@ -311,8 +328,41 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                     float pmf1_[SPCBPT_CONNECTION_N], pmf2_[SPCBPT_CONNECTION_N], u2_[SPCBPT_CONNECTION_N];
                     int lslot_[SPCBPT_CONNECTION_N], bias_[SPCBPT_CONNECTION_N], size_[SPCBPT_CONNECTION_N];
 #pragma unroll
+                    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { pmf1_[it] = 1.0f; pmf2_[it] = 0.0f; u2_[it] = 0.0f; lslot_[it] = -1; bias_[it] = 0; size_[it] = 0; }
+                    // The random numbers of a vertex's connections are ONE stream -- u1, [u2 unless the light subspace drawn with u1 is
+                    // empty], u1, ... -- so connection k's first number is known only when connection k - 1's subspace record has arrived:
+                    // four dependent round trips per connection, twelve per vertex.  An empty subspace is never drawn from a trained
+                    // matrix (its Gamma column is zero) and rarely otherwise, so the numbers are drawn as if none were empty: the
+                    // CONNECTION_N first stages then run side by side on one coarse fetch (sample_first_stage_n: three round trips for all
+                    // of them), the subspace records follow together, and the guess is checked -- a vertex with an empty subspace in
+                    // front of its last connection starts over in the reference's order (the loop below), with the seed as it was.
+                    bool in_order = SPC_JOINT_FIRST_STAGE == 0 || p.uniform_lvc != 0 || p.cmf_gamma2 == nullptr;
+                    if (!in_order) {
+                        uint32_t sd = w.seed;
+                        float u1[SPCBPT_CONNECTION_N], u2[SPCBPT_CONNECTION_N], pm[SPCBPT_CONNECTION_N];
+                        uint32_t after_u1[SPCBPT_CONNECTION_N];
+                        int l[SPCBPT_CONNECTION_N];
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { u1[it] = rnd(sd); after_u1[it] = sd; u2[it] = rnd(sd); }
+                        sample_first_stage_n<SPCBPT_CONNECTION_N, SPC_JOINT_FIRST_STAGE == 2>(p.cmf_gamma2, cur.sub, u1, l, pm);
+                        DSubspace ss[SPCBPT_CONNECTION_N];
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) ss[it] = f_subspace[l[it]];
+#pragma unroll
+                        for (int it = 0; it + 1 < SPCBPT_CONNECTION_N; it++) in_order = in_order || ss[it].size == 0;
+                        if (!in_order) {
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                                pmf1_[it] = pm[it];
+                                if (ss[it].size != 0) { bias_[it] = ss[it].jump_bias; size_[it] = ss[it].size; u2_[it] = u2[it]; }
+                                if (COUNT) cn.add(C_CMF, CACHE ? (it == 0 ? 32u : 16u) : (unsigned)bisection_probes(l[it], SPCBPT_NUM_SUBSPACE));
+                            }
+                            w.seed = ss[SPCBPT_CONNECTION_N - 1].size != 0 ? sd : after_u1[SPCBPT_CONNECTION_N - 1];
+                        }
+                    }
+                    if (in_order) {
+#pragma unroll
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
-                        pmf1_[it] = 1.0f; pmf2_[it] = 0.0f; u2_[it] = 0.0f; lslot_[it] = -1; bias_[it] = 0; size_[it] = 0;
                         if (p.uniform_lvc) {   // the comparator of BASELINE config 5: uniformSample (cuProg.h:283-289), one random number
                             const int vc = f_counts[0];
                             if (vc > 0) lslot_[it] = uniform_sample(f_jump, vc, w.seed, pmf2_[it]);
@@ -321,6 +371,7 @@ __global__ __launch_bounds__(BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KParams p
                             const DSubspace ss = f_subspace[l];
                             if (ss.size != 0) { bias_[it] = ss.jump_bias; size_[it] = ss.size; u2_[it] = rnd(w.seed); }
                         }
+                    }
                     }
                     {   // binary_sample (cuProg.h:245-264) of the three, level by level
                         int lo_[SPCBPT_CONNECTION_N], hi_[SPCBPT_CONNECTION_N], mid_[SPCBPT_CONNECTION_N];
@@ -1377,9 +1428,15 @@ static inline int render_blocks(const KParams& p) {
     const int step = p.row_step < 1 ? 1 : p.row_step;
     const int nb = band_end > band_begin ? (band_end - band_begin + step - 1) / step : 0;
     const int waves = tiles_x * nb;
-    return (waves + (BLOCK / 64) - 1) / (BLOCK / 64);
+    return (waves + (BLOCK / 64) - 1) / (BLOCK / 64);   // (k_pt, the film merges: one wave per tile, 256-thread blocks)
 }
-int render_thread_count(const KParams& p) { return render_blocks(p) * BLOCK; }
+// threads of the widest grid a render launch of these bands may run ("pt": one wave per tile; "SPCBPT_eye": the same waves in the eye
+// kernel's blocks) -- what the traversal stack's HBM area is sized for
+int render_thread_count(const KParams& p) {
+    const int waves = render_blocks(p) * (BLOCK / 64);
+    return (waves + (EYE_BLOCK / 64) - 1) / (EYE_BLOCK / 64) * EYE_BLOCK;
+}
+int spcbpt_block_threads() { return EYE_BLOCK; }
 
 // variant: 0 = timed (label caching, no counters), 1 = reference order with counters (also the generic form), 2 = the timed
 // kernel's own events, counted
@@ -1387,38 +1444,38 @@ void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s)
     // persistent grid: at most `max_blocks` (resident) blocks, never more than the tile queue can feed
     const int tiles = (int)p.n_tiles;
     if (tiles <= 0) return;
-    int blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
+    int blocks = (tiles + (EYE_BLOCK / 64) - 1) / (EYE_BLOCK / 64);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    if (variant == 1) hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else if (variant == 2) hipLaunchKernelGGL((k_spcbpt<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, false, true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL((k_spcbpt<false, false, true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (variant == 1) hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
+    else if (variant == 2) hipLaunchKernelGGL((k_spcbpt<true, false, true>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
+    else if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, false, true, true>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_spcbpt<false, false, true, false>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
 }
 // p.frames / p.n_frames describe the batch; p.n_tiles is the tile count of ONE frame
 int spcbpt_batch_blocks(const KParams& p, int max_blocks) {
     const long long tiles = (long long)p.n_tiles * p.n_frames;
     if (tiles <= 0) return 0;
-    long long blocks = (tiles + (BLOCK / 64) - 1) / (BLOCK / 64);
+    long long blocks = (tiles + (EYE_BLOCK / 64) - 1) / (EYE_BLOCK / 64);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
     return (int)blocks;
 }
 void launch_spcbpt_batch(const KParams& p, int max_blocks, hipStream_t s) {
     const int blocks = spcbpt_batch_blocks(p, max_blocks);
     if (blocks <= 0) return;
-    if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, true, true, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL((k_spcbpt<false, true, true, false>), dim3((unsigned)blocks), dim3(BLOCK), 0, s, p);
+    if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, true, true, true>), dim3((unsigned)blocks), dim3(EYE_BLOCK), 0, s, p);
+    else hipLaunchKernelGGL((k_spcbpt<false, true, true, false>), dim3((unsigned)blocks), dim3(EYE_BLOCK), 0, s, p);
 }
 // resident blocks per CU of the instantiation launch_spcbpt / launch_spcbpt_batch will really launch for (variant, batch, general):
 // the forms differ in registers and scratch (the ENV = false form exists because of that), so each is asked for itself
 int spcbpt_blocks_per_cu(int variant, bool batch, bool general) {
     int n = 0;
     hipError_t e;
-    if (variant == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, false>, BLOCK, 0);
-    else if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, true>, BLOCK, 0);
-    else if (batch) e = general ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, true, true, true>, BLOCK, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, true, true, false>, BLOCK, 0);
-    else e = general ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true, true>, BLOCK, 0)
-                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true, false>, BLOCK, 0);
+    if (variant == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, false>, EYE_BLOCK, 0);
+    else if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<true, false, true>, EYE_BLOCK, 0);
+    else if (batch) e = general ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, true, true, true>, EYE_BLOCK, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, true, true, false>, EYE_BLOCK, 0);
+    else e = general ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true, true>, EYE_BLOCK, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_spcbpt<false, false, true, false>, EYE_BLOCK, 0);
     return e == hipSuccess && n > 0 ? n : 1;
 }
 int render_tile_count(const KParams& p) {

@@ -22,6 +22,7 @@ namespace spc {
 // grows: the nearest hit found is unchanged.
 static const int LEAF_MAX = 4;
 static const int NODE_QUADS = 4;
+static const int HOT_NODES = 64;   // lbvh.cpp numbers the nodes of largest surface area 0 .. HOT_NODES - 1 (largest first; node 0 is the root)
 static const uint32_t NODE_EMPTY = 0x80000000u;  // decodes to a leaf of zero triangles: harmless even if a ray "hits" the slot
 
 // One triangle = 64 B = 4 x float4 in BVH order; the intersection test reads the
@@ -78,9 +79,10 @@ static const uint32_t TREE_LEAF_BIT = 0x80000000u;
 typedef spcbpt_light_vertex LightVertex;  // 96 B = 6 x float4, AoS because it is fetched by random gather
 static_assert(sizeof(LightVertex) == 96, "LightVertex");
 
-// First-stage sampling table: per eye subspace 32 coarse entries (every 32nd CMF value) followed by the row padded to 1024
-// entries (padding 2.0 > any random number), all 16-B aligned.
-static const int CMF2_COARSE = 32, CMF2_FINE = 1024, CMF2_ROW = CMF2_COARSE + CMF2_FINE;
+// First-stage sampling table (three counting levels, 16 x 8 x 8): per eye subspace 16 coarse entries (row[64 k + 63]), 128 middle
+// entries (row[8 m + 7]) and the row itself padded to 1024 entries (padding 2.0 > any random number), all 16-B aligned: a level is
+// 4 / 2 / 2 quads, and the CONNECTION_N samples of a vertex share the coarse ones (device_lib.h: sample_first_stage3).
+static const int CMF2_COARSE = 16, CMF2_MID = 128, CMF2_FINE = 1024, CMF2_ROW = CMF2_COARSE + CMF2_MID + CMF2_FINE;
 
 struct DSubspace {  // 16 B
     int32_t jump_bias;
@@ -147,7 +149,7 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     const float* light_tree;
     const float* Q;
     const float* cmf_gamma;
-    const float* cmf_gamma2;  // two-level copy of cmf_gamma for first-stage sampling (CMF2_ROW floats per row, see device_lib.h)
+    const float* cmf_gamma2;  // three-level copy of cmf_gamma for first-stage sampling (CMF2_ROW floats per row, see device_lib.h)
     // sampler (SubspaceSampler)
     const LightVertex* lvc;
     const DSubspace* subspace;

@@ -31,7 +31,7 @@ PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 13998, "_ZN3
 
 
 def _traversal_loops(lines, quad=False, fan=False):
-    """The traversal loop of a kernel -- the smallest loop around four global_load_dwordx4 in a row (the step's record fetch) and the
+    """The traversal loop of a kernel -- the smallest loop around the pool cursor's ds_add_rtn_u32, the step's record fetch and the
     slab test's v_pk_fma_f32 -- as
     [(instructions, scratch stores, scratch loads)]; with quad=True the quad tail's loop instead (the smallest loop that holds a
     quad_perm DPP instruction and a global_load_dwordx4, and no ds_bpermute); with fan=True the loop of fan_tail (the same WITH the
@@ -56,7 +56,10 @@ def _traversal_loops(lines, quad=False, fan=False):
         if quad or fan:
             ok = any("quad_perm" in x for x in blk) and any("global_load_dwordx4" in x for x in blk) and any("ds_bpermute" in x for x in blk) == fan
         else:
-            ok = any(all("global_load_dwordx4" in x for x in blk[j:j + 4]) for j in range(len(blk) - 3)) and any("v_pk_fma_f32" in x for x in blk)
+            # (the pooled pass's loop: the pool cursor's ds_add_rtn_u32, the slab test's packed FMAs, a record fetch -- from memory or,
+            # for the hottest nodes, from the block's LDS copy, so the four global loads need not stand in a row any more)
+            # (... which the compiler issues as flat_load_dwordx4 on a generic address: FLAT routes each lane to LDS or to memory)
+            ok = any("ds_add_rtn_u32" in x for x in blk) and any("v_pk_fma_f32" in x for x in blk) and sum("_load_dwordx4" in x for x in blk) >= 4
         if ok and (best is None or b - a < best[1] - best[0]):
             best = (a, b)
     if best is None:

@@ -5,6 +5,7 @@
 //   shadow rays       between pairs of area-weighted surface points (what connections look like),
 // and prints node visits and triangle tests per ray.  mesh file: int32 nv, nt; float32 vertices[nv][3]; uint32 indices[nt][3]
 //   g++ -O2 -std=c++17 -o /tmp/bvh_eval tools/bvh_eval.cpp && /tmp/bvh_eval mesh.bin [rays]
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -25,6 +26,7 @@ static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 static V3 norm(V3 a) { float l = std::sqrt(dot(a, a)); return a * (1.0f / l); }
 
+static std::vector<uint64_t> g_visits;   // per node: how often it was visited (top-of-tree share, printed at the end)
 struct Stats { double nodes = 0, tris = 0, leaves = 0, rays = 0, hits = 0, leaves_exact = 0, tris_exact = 0; };   // *_exact: leaf visits / tests left if the leaf's child box were the exact bounds of its triangles
 
 static bool tri_hit(const float* q, V3 o, V3 d, float tmin, float tmax, float& t) {
@@ -77,6 +79,7 @@ static bool traverse(const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any
             continue;
         }
         st.nodes++;
+        if (!g_visits.empty()) g_visits[cur]++;
         uint32_t w[16];
         memcpy(w, &B.nodes[(size_t)cur * 16], sizeof(w));
         float org[3]; memcpy(org, w, 12);
@@ -142,6 +145,7 @@ int main(int argc, char** argv) {
         N = norm(cross(vert(t, 1) - vert(t, 0), vert(t, 2) - vert(t, 0)));
     };
     Stats sc, ss;
+    g_visits.assign(B.nodes.size() / 16, 0);
     for (int i = 0; i < n_rays; i++) {
         V3 P, N;
         surface_point(P, N);
@@ -161,5 +165,20 @@ int main(int argc, char** argv) {
     printf("nodes %zu  depth %d  build %.2f s\n", B.nodes.size() / 16, B.depth, build_s);
     printf("closest: node visits %.2f  leaf visits %.2f  triangle tests %.2f  hit rate %.3f   with exact leaf boxes: leaf visits %.2f  tests <= %.2f\n", sc.nodes / sc.rays, sc.leaves / sc.rays, sc.tris / sc.rays, sc.hits / sc.rays, sc.leaves_exact / sc.rays, sc.tris_exact / sc.rays);
     printf("shadow : node visits %.2f  leaf visits %.2f  triangle tests %.2f  occluded %.3f   with exact leaf boxes: leaf visits %.2f  tests <= %.2f\n", ss.nodes / ss.rays, ss.leaves / ss.rays, ss.tris / ss.rays, ss.hits / ss.rays, ss.leaves_exact / ss.rays, ss.tris_exact / ss.rays);
+    {   // how concentrated the visits are: share of all node visits that go to the K most visited nodes (what a K-node LDS copy would
+        // serve), and to the first K nodes in memory order
+        std::vector<uint64_t> v = g_visits;
+        double total = 0;
+        for (uint64_t x : v) total += (double)x;
+        std::vector<uint64_t> sorted = v;
+        std::sort(sorted.begin(), sorted.end(), [](uint64_t a, uint64_t b) { return a > b; });
+        printf("visit share of the K hottest nodes / of nodes [0, K):");
+        for (int K : {1, 5, 16, 32, 64, 128, 256, 1024, 4096}) {
+            double hot = 0, first = 0;
+            for (int i = 0; i < K && i < (int)v.size(); i++) { hot += (double)sorted[i]; first += (double)v[i]; }
+            printf("  K=%d %.3f/%.3f", K, hot / total, first / total);
+        }
+        printf("\n");
+    }
     return 0;
 }

@@ -217,6 +217,9 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_QUAD_TAIL
 #define SPC_ONE_FETCH 1
+#ifndef SPC_ROOT_AHEAD
+#define SPC_ROOT_AHEAD 1  // trace_pool: a lane that is about to draw a ray requests the root with the other lanes' next records
+#endif
 #define SPC_QUAD_TAIL 1   // the last <= 16 rays of a pooled pass continue on four lanes each (trace_pool); 0 = the lane loop to the end
 #define SPC_FAN_TAIL 1    // ... and its shadow rays on as many quads as the wave has idle (fan_tail); 0 = one quad per ray to the end
 #endif
@@ -600,19 +603,24 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
     // the next iteration: a lane advances one step per iteration.  Same steps, same order per ray: the films do not change.
     static_assert(NODE_QUADS == 4, "node and triangle records are both four quads");
     float4 R0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), R1 = R0, R2 = R0, R3 = R0;
+    // A lane WITHOUT a ray that may still draw one (node == kTravDone, !done) requests the ROOT here, with everybody else's next
+    // record: the ray it draws at the top of the next iteration then finds its first record under way, and the loop has ONE request
+    // site.  (A root fetch at the draw was a second site writing R0..R3 from LDS while the other lanes' records were in flight to the
+    // same registers from memory: the compiler has to wait for those first -- vmcnt(0) in nearly every iteration.)
 #define SPC_FETCH_STEP__()                                                                                            \
     do {                                                                                                              \
-        if ((uint32_t)node < (uint32_t)n_hot) {                                                                       \
+        const int fn__ = (SPC_ROOT_AHEAD && node == kTravDone) ? 0 : node;                                            \
+        if ((uint32_t)fn__ < (uint32_t)n_hot) {                                                                \
             /* one of the hottest nodes (lbvh.cpp numbers them first): the block's LDS copy, no trip through the vector L1 */ \
-            const float4* h__ = s_hot + node * 4;                                                                     \
+            const float4* h__ = s_hot + fn__ * 4;                                                                     \
             R0 = h__[0]; R1 = h__[1]; R2 = h__[2]; R3 = h__[3];                                                       \
         } else {                                                                                                      \
         /* one base: the triangle records follow the node records (DeviceScene::tri_base = n_nodes) */                \
-        const size_t rb__ = (size_t)(uint32_t)(node < 0 ? S.tri_base + ~node : node) * 4;                             \
+        const size_t rb__ = (size_t)(uint32_t)(fn__ < 0 ? S.tri_base + ~fn__ : fn__) * 4;                             \
         R0 = ldq(S.nodes, rb__); R1 = ldq(S.nodes, rb__ + 1); R2 = ldq(S.nodes, rb__ + 2); R3 = ldq(S.nodes, rb__ + 3); \
         }                                                                                                             \
     } while (0)
-    if (node != kTravDone) SPC_FETCH_STEP__();
+    if (SPC_ROOT_AHEAD || node != kTravDone) SPC_FETCH_STEP__();
 #endif
     while (true) {
         if (node == kTravDone && !done) {  // acquire the next shadow ray of the pool
@@ -628,7 +636,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             node = 0; st.sp = 0;
             cn.add(C_SHADOW);
 #if SPC_ONE_FETCH
-            SPC_FETCH_STEP__();   // the root
+            if (!SPC_ROOT_AHEAD) SPC_FETCH_STEP__();   // the root
 #endif
             }
         }
@@ -681,7 +689,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
 #undef SPC_POOL_STEP__
         }
 #if SPC_ONE_FETCH
-        if (node != kTravDone) SPC_FETCH_STEP__();   // the next step's record: ONE request site after the step, outside its branches
+        if (node != kTravDone || (SPC_ROOT_AHEAD && !done)) SPC_FETCH_STEP__();   // the next step's record: ONE request site after the step, outside its branches
 #endif
         if (finished) {
             if (closest) {

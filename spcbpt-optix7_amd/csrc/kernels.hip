@@ -21,6 +21,9 @@ static constexpr int BLOCK = 256;
 #ifndef SPC_EYE_BLOCK
 #define SPC_EYE_BLOCK 256
 #endif
+#ifndef SPC_SECOND_STAGE_ARY
+#define SPC_SECOND_STAGE_ARY 2    // 4: sampleSecondStage as a 4-ary search (below)
+#endif
 #ifndef SPC_JOINT_FIRST_STAGE
 #define SPC_JOINT_FIRST_STAGE 0   // 1 / 2: the first stages of a vertex's connections on one coarse fetch (below: measured, slower)
 #endif
@@ -375,6 +378,43 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     }
                     {   // binary_sample (cuProg.h:245-264) of the three, level by level
                         int lo_[SPCBPT_CONNECTION_N], hi_[SPCBPT_CONNECTION_N], mid_[SPCBPT_CONNECTION_N];
+#if SPC_SECOND_STAGE_ARY == 4
+                        // ... as a 4-ary search: the sampler's CMFs are non-decreasing by construction (k_sb_cmf: a normalised prefix sum,
+                        // a zero-weight subspace is uniform), so the bisection's bin is the first k with u < cmf[k], size - 1 if there is
+                        // none -- three probes per level find it in half the dependent round trips (five for 263 entries instead of nine)
+                        (void)mid_;
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lo_[it] = 0; hi_[it] = size_[it] > 0 ? size_[it] - 1 : 0; }
+                        bool any_open = false;
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) any_open = any_open || hi_[it] > lo_[it];
+                        while (any_open) {
+                            float a_[SPCBPT_CONNECTION_N], b_[SPCBPT_CONNECTION_N], c_[SPCBPT_CONNECTION_N];
+                            int m1_[SPCBPT_CONNECTION_N], m2_[SPCBPT_CONNECTION_N], m3_[SPCBPT_CONNECTION_N];
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                                const int n = hi_[it] - lo_[it];
+                                m1_[it] = lo_[it] + (n >> 2); m2_[it] = lo_[it] + (n >> 1); m3_[it] = lo_[it] + ((3 * n) >> 2);
+                                const bool open = n > 0;
+                                a_[it] = open ? f_cmfs[bias_[it] + m1_[it]] : 0.0f;
+                                b_[it] = open ? f_cmfs[bias_[it] + m2_[it]] : 0.0f;
+                                c_[it] = open ? f_cmfs[bias_[it] + m3_[it]] : 0.0f;
+                            }
+                            any_open = false;
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                                if (hi_[it] > lo_[it]) {
+                                    if (COUNT) cn.add(C_CMF, 3);
+                                    const float u = u2_[it];
+                                    if (u < a_[it]) hi_[it] = m1_[it];
+                                    else if (u < b_[it]) { lo_[it] = m1_[it] + 1; hi_[it] = m2_[it]; }
+                                    else if (u < c_[it]) { lo_[it] = m2_[it] + 1; hi_[it] = m3_[it]; }
+                                    else lo_[it] = m3_[it] + 1;
+                                }
+                                any_open = any_open || hi_[it] > lo_[it];
+                            }
+                        }
+#else
 #pragma unroll
                         for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { lo_[it] = 0; hi_[it] = size_[it]; mid_[it] = size_[it] / 2 - 1; }
                         bool any_open = false;
@@ -396,6 +436,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                                 any_open = any_open || hi_[it] - lo_[it] > 1;
                             }
                         }
+#endif
 #pragma unroll
                         for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                             if (size_[it] != 0) {

@@ -217,6 +217,9 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_QUAD_TAIL
 #define SPC_ONE_FETCH 1
+#ifndef SPC_TRI_BATCH
+#define SPC_TRI_BATCH 8   // trace_pool: N > 1 = lanes on a leaf wait until N of them are (or nobody is on an internal node) before the triangle step
+#endif
 #ifndef SPC_ROOT_AHEAD
 #define SPC_ROOT_AHEAD 1  // trace_pool: a lane that is about to draw a ray requests the root with the other lanes' next records
 #endif
@@ -689,6 +692,11 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
         const bool tail = COUNT && __any(done);   // (counting build) some lane found the pool empty: what follows is the pass's tail
         bool finished = false, occluded = false;
         const bool shallow__ = !__any(node != kTravDone && st.sp + 3 > STACK_LDS);   // no lane near the end of its LDS entries (wave-uniform)
+        bool hold__ = false;
+        if (SPC_TRI_BATCH > 1) {
+            const unsigned long long leaf_m = __ballot(node < 0), inner_m = __ballot(node >= 0 && node != kTravDone);
+            hold__ = node < 0 && __popcll(leaf_m) < SPC_TRI_BATCH && inner_m != 0ull;
+        }
         if (node != kTravDone) {
             if (COUNT && tail && node >= 0) {
                 cn.add(closest ? C_U_TAIL_CLOSEST : C_U_TAIL_SHADOW);
@@ -705,6 +713,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             do {                                                                                                      \
                 const bool at_leaf = node < 0;                                                                        \
                 if (!at_leaf) { SPC_NODE_STEP_Q(kEps, best_t, R0, R1, R2, R3, PUSH, POP); finished = node == kTravDone; } \
+                else if (hold__) { /* SPC_TRI_BATCH: the triangle step waits for company (its record stays in R0..R3) */ } \
                 else if (leaf_count <= 0) {                                                                           \
                     SPC_TRAV_POP_(POP);  /* an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test */ \
                     finished = node == kTravDone;                                                                     \
@@ -730,7 +739,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
 #undef SPC_POOL_STEP__
         }
 #if SPC_ONE_FETCH
-        if (node != kTravDone || (SPC_ROOT_AHEAD && !done)) SPC_FETCH_STEP__();   // the next step's record: ONE request site after the step, outside its branches
+        if ((node != kTravDone || (SPC_ROOT_AHEAD && !done)) && !hold__) SPC_FETCH_STEP__();   // the next step's record: ONE request site after the step, outside its branches
 #endif
         if (finished) {
             if (closest) {

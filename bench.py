@@ -601,7 +601,7 @@ def main():
         saturating = {k: v for k, v in units.items() if k in ("ta_busy_frac", "tcp_tag_lookups_per_cu_cycle", "valu_issue_frac", "hbm_measured_frac_high")}
         nearest = max(saturating, key=saturating.get) if saturating else None
         # bytes no implementation of the path can avoid fetching: per event the LESSER of the reference's order and the order executed
-        # (the executed order reads 66 CMF values per first stage where the bisection probes 10, and 1 tree descent per vertex where
+        # (the executed order reads 32 CMF values per first stage where the bisection probes 10, and 1 tree descent per vertex where
         # the reference re-descends per connection: neither order is the lesser on every event)
         bytes_min_per_launch = pkg.algorithmic_bytes({k: min(c_eye[k], c_ref[k]) for k in c_eye}) * batch
         out = {

@@ -415,7 +415,7 @@ int spcbpt_debug_trace_bench(spcbpt_ctx* ctx, const float* rays, int n, int mode
 /* Event counting in the kernels (off for timed runs).  1: the counting instantiations evaluate in the REFERENCE's order and charge
  * its events (two relabels per connection and one per RMIS update, a ten-probe bisection per first sampling stage): the contract's
  * byte table of SURVEY.md 8(d).  2: the instantiations the timed runs use, with counters -- the events that really execute (labels
- * cached per vertex; 2 x 32 + 2 CMF values per first stage): what the roofline fraction is computed from. */
+ * cached per vertex; 16 + 8 + 8 CMF values per first stage): what the roofline fraction is computed from. */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 
 /* Streams.  A context owns two non-blocking HIP streams: the one returned here (hipStream_t as void*) carries "light trace",

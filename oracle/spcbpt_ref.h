@@ -897,7 +897,7 @@ inline const BDPTVertex& uniformSample(const Params& P, uint32_t& seed, float& s
 }
 inline int sampleFirstStage(const Params& P, int eye_subspace, uint32_t& seed, float& sample_pmf) {  // cuProg.h:290-301
     int begin_index = eye_subspace * SPCBPT_NUM_SUBSPACE;
-    if (P.count_as_executed && P.counters) P.counters->cmf_probes += 66;   // two counting passes over 32 values + the bin's two
+    if (P.count_as_executed && P.counters) P.counters->cmf_probes += 32;   // the product's three counting passes over 16 + 8 + 8 values (the pmf's two are among them)
     return binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf, !P.count_as_executed);
 }
 

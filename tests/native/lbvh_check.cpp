@@ -1,5 +1,6 @@
 // Host-side structural check of the BVH builders (csrc/lbvh.cpp): every triangle sits in exactly one leaf, every slot box
 // contains what hangs below it, empty slots are point boxes at 1e30.  Usage: lbvh_check <n_triangles> <seed>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -103,6 +104,36 @@ int main(int argc, char** argv) {
     std::vector<int> perm(out.tri_orig.begin(), out.tri_orig.end());
     std::sort(perm.begin(), perm.end());
     for (int i = 0; i < n; i++) if (perm[i] != i) c.ok = false;
+    // every node is reachable exactly once (the walk counts them), and the first HOT_NODES records are the hottest-first crown of the
+    // tree (lbvh.cpp: hot_nodes_first): node 0 is the root, the parent of a hot node is hot and comes before it, and no node outside
+    // the crown has a larger box than the crown's last (the crown is the top of the area order, ties aside)
+    const int n_nodes = (int)(out.nodes.size() / 16);
+    if (c.nodes != n_nodes) { c.ok = false; printf("walk reached %lld of %d nodes\n", c.nodes, n_nodes); }
+    {
+        std::vector<int> parent((size_t)n_nodes, -1);
+        std::vector<float> area((size_t)n_nodes, 0.0f);
+        for (int node = 0; node < n_nodes; node++) {
+            uint32_t w[16];
+            memcpy(w, &out.nodes[(size_t)node * 16], sizeof(w));
+            float org[3]; memcpy(org, w, 12);
+            float sc[3];
+            for (int k = 0; k < 3; k++) { const uint32_t e = ((w[3] >> (8 * k)) & 0xffu) << 23; memcpy(&sc[k], &e, 4); }
+            for (int i = 0; i < 4; i++) {
+                const uint32_t ref = w[10 + i];
+                if (ref & 0x80000000u) continue;
+                float e[3];
+                for (int k = 0; k < 3; k++) e[k] = (float)((w[7 + k] >> (8 * i)) & 0xffu) * sc[k] - (float)((w[4 + k] >> (8 * i)) & 0xffu) * sc[k];
+                parent[ref] = node; area[ref] = e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+            }
+        }
+        const int hot = std::min(n_nodes, (int)HOT_NODES);
+        for (int i = 1; i < hot; i++) {
+            if (parent[i] < 0 || parent[i] >= i) { c.ok = false; printf("hot node %d: parent %d\n", i, parent[i]); }
+            if (i > 1 && area[i] > area[i - 1] * 1.0001f) { c.ok = false; printf("hot node %d: area %g after %g\n", i, area[i], area[i - 1]); }
+        }
+        for (int i = hot; i < n_nodes && hot > 1; i++)
+            if (parent[i] >= 0 && parent[i] < hot && area[i] > area[hot - 1] * 1.0001f) { c.ok = false; printf("node %d (area %g) should be in the crown (last %g)\n", i, area[i], area[hot - 1]); break; }
+    }
     printf("%s n=%d nodes=%lld leaves=%lld depth=%d sah=%.1f build=%.3fs\n", c.ok ? "OK" : "FAIL", n, c.nodes, c.leaves, out.depth, c.sah, sec);
     return c.ok ? 0 : 1;
 }

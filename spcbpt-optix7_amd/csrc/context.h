@@ -132,7 +132,7 @@ struct Context {
     float* d_light_tree = nullptr;
     float* d_Q = nullptr;
     float* d_gamma = nullptr;
-    float* d_gamma2 = nullptr;   // two-level copy of d_gamma (layout.h: CMF2_ROW)
+    float* d_gamma2 = nullptr;   // three-level copy of d_gamma (layout.h: CMF2_ROW)
     bool gamma_monotone = false; // every row of the installed matrix is a proper CMF: first-stage sampling may count instead of bisect
     std::vector<spcbpt_tree_node> h_eye_tree, h_light_tree;
     std::vector<float> h_Q, h_gamma;

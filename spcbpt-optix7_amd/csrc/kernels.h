@@ -69,6 +69,6 @@ void launch_unit(const KParams& p, int op, const uint32_t* in, int in_words, uin
 #ifndef SPC_STACK_LDS
 #define SPC_STACK_LDS 16
 #endif
-static const int kStackLds = SPC_STACK_LDS;  // LDS traversal-stack entries per lane (16 KB per block): with the ray pool and the connection tables of k_spcbpt a block takes 40 464 B and four blocks fit the 160 KB of a CU; deeper stacks spill to HBM (TravStack)
+static const int kStackLds = SPC_STACK_LDS;  // LDS traversal-stack entries per lane (16 KB per block): with the ray pool (4 x 5 840 B) and the hot-node table (1 216 B) of k_spcbpt a block takes exactly 40 960 B and four blocks fit the 160 KB of a CU; deeper stacks spill to HBM (TravStack)
 
 }  // namespace spc

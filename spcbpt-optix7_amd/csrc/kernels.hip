@@ -24,6 +24,19 @@ static constexpr int BLOCK = 256;
 #ifndef SPC_SECOND_STAGE_ARY
 #define SPC_SECOND_STAGE_ARY 2    // 4: sampleSecondStage as a 4-ary search (below)
 #endif
+// Issue priority of a wave by phase (s_setprio, 0 .. 3): see the traversal pass in k_spcbpt
+#ifndef SPC_PRIO_TRAV
+#define SPC_PRIO_TRAV 1
+#endif
+#ifndef SPC_PRIO_CONNECT
+#define SPC_PRIO_CONNECT 0
+#endif
+#ifndef SPC_PRIO_SHADE
+#define SPC_PRIO_SHADE 0
+#endif
+#ifndef SPC_PRIO_LIGHT
+#define SPC_PRIO_LIGHT 0   // ... of the light pass's waves (they share CUs with the eye megakernel when passes run ahead)
+#endif
 #ifndef SPC_JOINT_FIRST_STAGE
 #define SPC_JOINT_FIRST_STAGE 0   // 1 / 2: the first stages of a vertex's connections on one coarse fetch (below: measured, slower)
 #endif
@@ -194,7 +207,13 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
         HitRec h;
         // (the next segment starts at the path's last vertex -- or at the camera for a path that was started in this iteration, whose
         // `cur` still holds the parked path's vertex: w.origin would be a copy kept alive across the pass for nothing)
+        // Issue priority by phase (s_setprio): the traversal pass is the phase whose instructions are the kernel's throughput (three quarters
+        // of what it issues), connect and shading are chains of dependent fetches with little to issue in between -- a wave in the pass
+        // goes first when both are ready.  Measured (profiles/r05_experiments.md, section 16): pass 1 / others 0: +1.1 % paths per second;
+        // any phase but the pass raised: the light pass that shares the CUs (priority 0 throughout) starves and the step gets longer.
+        if (SPC_PRIO_TRAV != SPC_PRIO_SHADE) __builtin_amdgcn_s_setprio(SPC_PRIO_TRAV);
         trace_pool(S, st, alive && has_ray, fresh ? ld3(p.eye) : cur.c.pos, w.dir, h, w_org, w_ray, w_next, w_job, n_rays, cn, s_hot, EYE_HOT);
+        if (SPC_PRIO_CONNECT != SPC_PRIO_TRAV) __builtin_amdgcn_s_setprio(SPC_PRIO_CONNECT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cur.sub = (int)(ids_a & 1023u); cur.lastZone = (int)((ids_a >> 10) & 1023u); cur.depth = (int)(ids_a >> 20);
@@ -294,6 +313,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
         has_vertex = false;
         bool finished = alive && !has_ray;  // the path ended at that vertex (Russian roulette / depth): nothing was traced
         SPC_PHASE(C_T_CONNECT);
+        if (SPC_PRIO_SHADE != SPC_PRIO_CONNECT) __builtin_amdgcn_s_setprio(SPC_PRIO_SHADE);
         // ---- the new segment: miss, emitter, or a new vertex with its CONNECTION_N resampled light vertices
         if (alive && has_ray) {
             has_ray = false;
@@ -623,6 +643,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
 template <bool COUNT, bool CACHE>
 __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams p) {
     __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
+    if (SPC_PRIO_LIGHT) __builtin_amdgcn_s_setprio(SPC_PRIO_LIGHT);
     const DeviceScene& S = p.scene;
     const uint32_t lane = threadIdx.x & 63;
     Counts<COUNT> cn;

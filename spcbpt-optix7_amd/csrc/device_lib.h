@@ -217,6 +217,9 @@ SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, f
 static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_QUAD_TAIL
 #define SPC_ONE_FETCH 1
+#ifndef SPC_PRIO_TAIL
+#define SPC_PRIO_TAIL -1  // >= 0: s_setprio at the entry of the quad / fan tails (kernels.hip sets the pass's and resets after it)
+#endif
 #ifndef SPC_TRI_BATCH
 #define SPC_TRI_BATCH 8   // trace_pool: N > 1 = lanes on a leaf wait until N of them are (or nobody is on an internal node) before the triangle step
 #endif
@@ -753,6 +756,9 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
     }
 #undef SPC_FETCH_STEP__
     if (SPC_QUAD_TAIL && quad_live != 0ull) {
+#if SPC_PRIO_TAIL >= 0
+        __builtin_amdgcn_s_setprio(SPC_PRIO_TAIL);   // (experiment: the tails at another priority than the lane loop; the caller resets it after the pass)
+#endif
         // ---- quad tail: the k-th ray still in flight continues on lanes 4 k .. 4 k + 3 -------------------------------------------
         // Lane r of a quad loads record r of the node (one coalesced 64-B line per ray), tests ITS child, and the four entry
         // distances are ranked across the quad: the same keys, the same order, the same pushes as SPC_NODE_STEP -- onto the SAME

@@ -211,9 +211,9 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
         // of what it issues), connect and shading are chains of dependent fetches with little to issue in between -- a wave in the pass
         // goes first when both are ready.  Measured (profiles/r05_experiments.md, section 16): pass 1 / others 0: +1.1 % paths per second;
         // any phase but the pass raised: the light pass that shares the CUs (priority 0 throughout) starves and the step gets longer.
-        if (SPC_PRIO_TRAV != SPC_PRIO_SHADE) __builtin_amdgcn_s_setprio(SPC_PRIO_TRAV);
+        if (SPC_PRIO_TRAV != SPC_PRIO_SHADE || SPC_PRIO_TAIL >= 0) __builtin_amdgcn_s_setprio(SPC_PRIO_TRAV);
         trace_pool(S, st, alive && has_ray, fresh ? ld3(p.eye) : cur.c.pos, w.dir, h, w_org, w_ray, w_next, w_job, n_rays, cn, s_hot, EYE_HOT);
-        if (SPC_PRIO_CONNECT != SPC_PRIO_TRAV) __builtin_amdgcn_s_setprio(SPC_PRIO_CONNECT);
+        if (SPC_PRIO_CONNECT != SPC_PRIO_TRAV || SPC_PRIO_TAIL >= 0) __builtin_amdgcn_s_setprio(SPC_PRIO_CONNECT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cur.sub = (int)(ids_a & 1023u); cur.lastZone = (int)((ids_a >> 10) & 1023u); cur.depth = (int)(ids_a >> 20);

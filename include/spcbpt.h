@@ -631,7 +631,7 @@ int spcbpt_viewer_set_fps(spcbpt_viewer* v, float fps);
  *      change) the loop runs as mode 1 -- no frame is queued just to be dropped by the next event -- and the first steady call
  *      starts tracing ahead again.  A steady view costs the eye kernel per displayed frame.
  * Modes 1 and 2 set spcbpt_set_light_ahead on the context; spcbpt_viewer_destroy drops what the viewer queued ahead and restores the
- * mode it found, so a host can go on with the plain loop on the same context.  A host that touches the context BETWEEN two
+ * mode it found, so a host can go on with the plain loop on the same context (destroy the viewer BEFORE its context: it calls into it).  A host that touches the context BETWEEN two
  * viewer frames (merges / drops the deferred frame, new tuple, sky, cache import) is tolerated: each frame re-validates the viewer's
  * flags against spcbpt_get_pipeline_state.  To DISPLAY a frame read it with spcbpt_read_film (or spcbpt_accum_device_ptr after
  * spcbpt_viewer_frame): spcbpt_read_frame / _accum wait for everything queued, i.e. also for the frame being traced ahead.

@@ -5,7 +5,8 @@ csrc/Makefile builds the kernels with LLVM-internal switches (-fno-slp-vectorize
 ROCm update changed what they do -- the images would stay right and the bench would quietly lose.  This test reads the gfx950 code
 object the library actually carries (llvm-objdump --offloading on a copy, llvm-readelf --notes, llvm-objdump -d) and pins, for the
 timed instantiations of k_spcbpt, the resources that decide occupancy and the two symptoms the switches exist to prevent:
-  * 128 VGPRs (4 waves per SIMD) and <= 40 960 B of LDS (4 blocks per CU) -- the occupancy the launch sizes its persistent grid for;
+  * 128 VGPRs (4 waves per SIMD) and <= 40 960 B of LDS (4 blocks per CU; exactly that since round 5: 16 KB of stack, 4 x 5 840 B
+    of ray pool, 1 216 B of hot-node records) -- the occupancy the launch sizes its persistent grid for;
   * private segment (scratch) <= 160 B per lane -- spills are the kernel's writes to HBM (profiles/r03_experiments.md); SLP
     vectorisation or loop-invariant hoisting in the traversal loop pushed it to 264-384 B;
   * packed-float instructions: only the hand-written v_pk_fma_f32 of the slab test (12, in two instantiations of the step) -- the SLP
@@ -26,8 +27,8 @@ ARGS = "EEEvNS_7KParamsE"
 # <COUNT, BATCH, CACHE, ENV>: the timed forms (COUNT = false, CACHE = true)
 TIMED = {"single frame, plain scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS, "batched, plain scene (bench.py)": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS,
          "single frame, general scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS, "batched, general scene": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS}
-PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 13998, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13181,
-                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 15998, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 15154}   # profiles/r04i_*
+PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 14093, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13248,
+                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 16093, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 15252}   # profiles/r05e_*
 
 
 def _traversal_loops(lines, quad=False, fan=False):
@@ -118,7 +119,7 @@ def test_timed_megakernel_resources(code_object, form):
     assert m["private_segment_fixed_size"] <= (176 if "general" in form else 160), report   # scratch per lane: the kernel's HBM writes
     assert d["packed"] <= 28, report                                # the slab test's 12 v_pk_fma_f32, in the two instantiations of the pooled step; SLP vectorisation made thousands
     want = PROFILED_INSTRUCTIONS[name]
-    assert abs(d["instructions"] - want) <= 0.10 * want, report     # the code the profiles/ numbers were measured on
+    assert abs(d["instructions"] - want) <= 0.06 * want, report     # the code the profiles/ numbers were measured on
     # The spills of this kernel (its 144-160 B of scratch) are path state parked ACROSS the traversal pass: the traversal loop itself
     # -- the innermost loop around the four-quad node fetch -- must hold no scratch access.  (Measured on the profiled build: 0 of
     # the ~245 scratch instructions sit in the 675-instruction loop; they run once per path segment, < 1.5 % of the instructions

@@ -329,8 +329,8 @@ int Context::ensure_lvc_capacity(size_t n) {
     dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_weights);
     dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < n_sets; s++) {   // what the eye pass reads exists once per frame in flight (see context.h)
-        dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
-        HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
+        dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
+        HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_lvc_sorted[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
     }
     for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; set_bound[s2] = -1; ev_exch_set[s2] = false; }   // the sets are empty again
     pending.clear();
@@ -521,7 +521,7 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     int grid_cap = light_batch_blocks;
     if (grid_cap == 0) {
         // ... in proportion to the light paths per pixel of this context's share of the frame (kp.row_step: the band step of the last
-        // eye launch), so that the batch stays shorter than the eye launch it runs beside: 480 blocks per (path / pixel), i.e. 24 for
+        // eye launch), so that the batch stays shorter than the eye launch it runs beside: 640 blocks per (path / pixel), i.e. 32 for
         // 100 000 paths against 1920 x 1080 pixels -- or against an eighth of both
         const double px = std::max(1.0, (double)kp.width * kp.height / std::max(1, (int)kp.row_step));
         const double ratio = (double)lt.core_count * std::max(1, lt.m_per_core) / px;
@@ -531,7 +531,11 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
         // (round 4: 400 -> 480 blocks per (path / pixel).  With the eye kernel 13 % faster the 20 blocks of 400 finished a 20-frame batch in
         // 75 ms beside an eye launch of 83 -- and 16 blocks, too few, cost 10 %: the batch became the critical path.  24 keep a fifth in hand
         // at no measurable cost: 20 / 24 / 28 / 32 blocks 4.176 / 4.204 / 4.181 / 4.231 ms per step)
-        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, std::ceil(480.0 * ratio)));
+        // (round 5: 480 -> 640, i.e. 32.  The eye kernel is another 8 % faster and runs its traversal pass at a raised issue priority, under
+        // which the light pass that shares its CUs is slower: with 24 blocks the batch for the NEXT eye launch took 101-113 ms beside an eye
+        // launch of 116 (tools/timeline_long.sh), so that its sampler build -- 1.3 ms -- ran in the gap between two eye kernels instead of
+        // under the first.  Steady-state ms per step, 24 / 32 / 40 / 48 / 64 blocks: 3.706 / 3.661 / 3.70-3.77 / 3.75 / 3.87)
+        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, std::ceil(640.0 * ratio)));
     }
     // (cores that trace many paths one after the other -- the reference's geometry -- are long jobs: never two of them per lane)
     if (lt.m_per_core >= 8) grid_cap = std::max(grid_cap, (int)(((long long)n * lt.core_count + 255) / 256));
@@ -645,7 +649,7 @@ int Context::build_sampler() {
         const bool count_paths = !dev_count && !lazy && !(keys_ready && keys_set == bset);   // (a light pass has left the path count in its set)
         if (count_paths) HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
         launch_sampler_build(d_lvc, n, (dev_count || lazy) ? d_sampler_counts : nullptr, d_keys, d_weights, d_hist, count_paths ? d_sampler_counts + 1 : nullptr,
-                             d_subspace, d_vals2, d_wsorted, d_cmfs, stream);
+                             d_subspace, d_vals2, d_wsorted, d_cmfs, set_lvc_sorted[bset], stream);
         keys_ready = false;
     } else {
     if (dev_count) {
@@ -667,6 +671,7 @@ int Context::build_sampler() {
         launch_gather_weights(d_weights, d_vals2, d_sampler_counts, d_wsorted, n, stream);
         HIP_TRY(this, hipcub::DeviceScan::InclusiveSum(d_temp, tb2, d_wsorted, d_prefix, n, stream));
         launch_cmf(d_prefix, d_keys2, d_sampler_counts, d_subspace, d_cmfs, n, stream);
+        launch_lvc_sorted_copy(d_lvc, d_vals2, d_sampler_counts, set_lvc_sorted[bset], n, stream);
     }
     }
     time_end();
@@ -764,7 +769,7 @@ int Context::build_sampler_batch(int n) {
         // (spcbpt_lvc_import) has it counted by the build, as build_sampler does
         const bool count_paths = !dev_count && !light_counts_valid[b];
         B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = (dev_count || lazy) ? set_counts[b] : nullptr; B.path_count[k] = count_paths ? set_counts[b] + 1 : nullptr;
-        B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b];
+        B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b]; B.lvc_sorted[k] = set_lvc_sorted[b];
         if (count_paths) HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));
     }
     time_begin("sampler_build");
@@ -873,7 +878,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     kp.result = d_result[rk];
     if (spcbpt_alg) {
         // the sampler tables this launch reads (set `eset`) were built on `stream`
-        kp.lvc = set_lvc[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset];
+        kp.lvc = set_lvc[eset]; kp.lvc_sorted = set_lvc_sorted[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset];
         kp.jump = reinterpret_cast<const int32_t*>(set_vals2[eset]); kp.sampler_counts = set_counts[eset];
         if (rstream != stream && ev_sampler_set[eset]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[eset], 0));
     }
@@ -986,7 +991,7 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
         const int e = built_sets[built_sets.size() - (size_t)n + (size_t)k];   // oldest of the last n first
         sets[k] = e;
         if (!d_result_b[rk][k]) HIP_TRY(this, dev_alloc(&d_result_b[rk][k], px * 4));
-        hf[k].lvc = set_lvc[e]; hf[k].subspace = set_subspace[e]; hf[k].cmfs = set_cmfs[e];
+        hf[k].lvc = set_lvc[e]; hf[k].lvc_sorted = set_lvc_sorted[e]; hf[k].subspace = set_subspace[e]; hf[k].cmfs = set_cmfs[e];
         hf[k].jump = reinterpret_cast<const int32_t*>(set_vals2[e]); hf[k].sampler_counts = set_counts[e];
         hf[k].result = d_result_b[rk][k]; hf[k].subframe = subframes[k];
         if (rstream != stream && ev_sampler_set[e]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[e], 0));
@@ -1090,7 +1095,7 @@ Context::~Context() {
     dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
-    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); }
+    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); }
     dev_free(d_set_counts_all); dev_free(lb_scratch); dev_free(lb_core_counts); dev_free(lb_core_offsets); dev_free(lb_path_counts); dev_free(lb_spill);
     dev_free(d_counters); dev_free(d_diag); dev_free(d_work_counter); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
     for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
@@ -1916,7 +1921,7 @@ int spcbpt_debug_unit(spcbpt_ctx* c, int op, const uint32_t* in, int in_words, u
     if (e == hipSuccess) {
         KParams kp = c->kp;
         const int es = c->eset;   // the tables of the last sampler build
-        kp.lvc = c->set_lvc[es]; kp.subspace = c->set_subspace[es]; kp.cmfs = c->set_cmfs[es];
+        kp.lvc = c->set_lvc[es]; kp.lvc_sorted = c->set_lvc_sorted[es]; kp.subspace = c->set_subspace[es]; kp.cmfs = c->set_cmfs[es];
         kp.jump = reinterpret_cast<const int32_t*>(c->set_vals2[es]); kp.sampler_counts = c->set_counts[es];
         kp.counters = nullptr;
         if (op == SPCBPT_UNIT_EYE_STEP) {

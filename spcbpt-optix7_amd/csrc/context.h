@@ -96,6 +96,7 @@ struct Context {
     int launch_light_batch(uint32_t first_frame, int n);
     int* d_set_counts_all = nullptr;         // one allocation behind set_counts[]: set s at + 2 s (a batch copies its sets' counts to the host as ranges)
     LightVertex* set_lvc[kMaxSets] = {};
+    LightVertex* set_lvc_sorted[kMaxSets] = {};   // the set's cache in its sampler's order (written by the sampler build, read by the eye megakernel)
     uint32_t* set_vals2[kMaxSets] = {};
     float* set_cmfs[kMaxSets] = {};
     DSubspace* set_subspace[kMaxSets] = {};

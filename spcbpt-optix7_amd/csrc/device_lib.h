@@ -1173,10 +1173,12 @@ SPC_DEV int binary_sample(const float* cmf, int size, uint32_t& seed, float& pmf
 // uniformSample (cuProg.h:283-289): "plain BDPT" draws the light vertex uniformly over the whole cache, pmf 1 / vertex_count
 // (double division, as `1.0 / vertex_count` is written).  `rnd * vertex_count` can round up to vertex_count in FP32 for large
 // caches -- the reference would then read one past jump_buffer; clamped here.
-SPC_DEV int uniform_sample(const int32_t* jump, int vertex_count, uint32_t& seed, float& pmf) {
+SPC_DEV int uniform_sample_index(int vertex_count, uint32_t& seed, float& pmf) {   // the place in the jump buffer
     pmf = (float)(1.0 / (double)vertex_count);
-    const int index = min((int)(rnd(seed) * (float)vertex_count), vertex_count - 1);
-    return jump[index];
+    return min((int)(rnd(seed) * (float)vertex_count), vertex_count - 1);
+}
+SPC_DEV int uniform_sample(const int32_t* jump, int vertex_count, uint32_t& seed, float& pmf) {
+    return jump[uniform_sample_index(vertex_count, seed, pmf)];
 }
 
 // sampleFirstStage (cuProg.h:290-301) = binary_sample over the 1000-entry CMF row of the eye subspace: ten DEPENDENT probes.

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     a.pdf = __uint_as_float(col[12 * BLOCK]); a.singlePdf = __uint_as_float(col[13 * BLOCK]);
                     const uint32_t ids = col[14 * BLOCK];
                     a.sub = (int)(ids & 1023u); a.lastZone = (int)((ids >> 10) & 1023u); a.depth = (int)((ids >> 20) & 63u);
-                    const LightVertex* job_lvc = BATCH ? p.frames[ids >> 26].lvc : p.lvc;
+                    const LightVertex* job_lvc = BATCH ? p.frames[ids >> 26].lvc_sorted : p.lvc_sorted;   // (w_slot holds the vertex's place in the sampler's order)
                     a.c.mat = (int)(col[15 * BLOCK] & 0xffffu); a.lsub = (int)(col[15 * BLOCK] >> 16);
                     LightVertex b;
                     const float4* src = reinterpret_cast<const float4*>(job_lvc + w_slot[slot]);
@@ -335,13 +335,14 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     // CONNECTION_N resampled connections through the subspace sampling matrix (raygen.cu:390-419).  Only the
                     // position quad of the light vertex is fetched here (visibilityTest, cuProg.h:463-487); the connection
                     // itself does not consume random numbers, so drawing all three first leaves the RNG stream unchanged.
-                    const LightVertex* f_lvc = p.lvc; const DSubspace* f_subspace = p.subspace; const float* f_cmfs = p.cmfs;
-                    const int32_t* f_jump = p.jump;
+                    // (the light vertices in the sampler's order: the vertex drawn at place k of a subspace's CMF is record jump_bias + k,
+                    // next to the other vertices of its subspace -- no trip through `jump`)
+                    const LightVertex* f_lvc = p.lvc_sorted; const DSubspace* f_subspace = p.subspace; const float* f_cmfs = p.cmfs;
                     int f_path_count = path_count;
                     const int32_t* f_counts = p.sampler_counts;
                     if (BATCH) {   // the sampler tables of this path's frame
                         const FrameDesc& D = p.frames[fid];
-                        f_lvc = D.lvc; f_subspace = D.subspace; f_cmfs = D.cmfs; f_jump = D.jump; f_path_count = D.sampler_counts[1];
+                        f_lvc = D.lvc_sorted; f_subspace = D.subspace; f_cmfs = D.cmfs; f_path_count = D.sampler_counts[1];
                         f_counts = D.sampler_counts;
                     }
                     // Three stages, each over all CONNECTION_N connections, so that what does not depend on each other is in flight together:
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                         if (p.uniform_lvc) {   // the comparator of BASELINE config 5: uniformSample (cuProg.h:283-289), one random number
                             const int vc = f_counts[0];
-                            if (vc > 0) lslot_[it] = uniform_sample(f_jump, vc, w.seed, pmf2_[it]);
+                            if (vc > 0) lslot_[it] = uniform_sample_index(vc, w.seed, pmf2_[it]);   // (place in the jump buffer = record of the sorted cache)
                         } else {
                             const int l = sample_first_stage<COUNT, CACHE>(p, cur.sub, w.seed, pmf1_[it], cn);
                             const DSubspace ss = f_subspace[l];
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                                 const float* cmf = f_cmfs + bias_[it];
                                 const int k = lo_[it];
                                 pmf2_[it] = k == 0 ? cmf[k] : cmf[k] - cmf[k - 1];
-                                lslot_[it] = f_jump[bias_[it] + k];
+                                lslot_[it] = bias_[it] + k;   // its record in the sorted cache (what jump[bias + k] names in the cache's own order)
                             }
                         }
                     }
@@ -1212,6 +1213,22 @@ __global__ __launch_bounds__(64) void k_sb_scatter(const SamplerBuildBatch B) {
         }
     }
 }
+// the cache in the sampler's order: record i = lvc[jump[i]], one lane per QUAD (six consecutive lanes read one 96-B vertex and write
+// its six quads next to each other: the stores of a wave are contiguous, the loads are whole records)
+__global__ __launch_bounds__(256) void k_sb_copy(const SamplerBuildBatch B) {
+    const int f = blockIdx.y;
+    float4* __restrict__ dst = reinterpret_cast<float4*>(B.lvc_sorted[f]);
+    if (!dst) return;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(B.lvc[f]);
+    const uint32_t* __restrict__ jump = B.jump[f];
+    const int* __restrict__ n_dev = B.n_dev[f];
+    const long long n = n_dev ? n_dev[0] : B.n_host[f];
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 6; t += (long long)gridDim.x * 256) {
+        const long long i = t / 6;
+        const int q = (int)(t - i * 6);
+        dst[t] = src[(size_t)jump[i] * 6 + q];
+    }
+}
 __global__ __launch_bounds__(256) void k_sb_cmf(const SamplerBuildBatch B) {
     DSubspace* __restrict__ sub = B.sub[blockIdx.y];
     const double* __restrict__ wsorted = B.wsorted + (size_t)blockIdx.y * B.item_stride;
@@ -1257,11 +1274,28 @@ void launch_sampler_build_batch(const SamplerBuildBatch& b, int frames, hipStrea
     hipLaunchKernelGGL(k_sb_scan, dim3(1, frames), dim3(1024), 0, s, b);
     hipLaunchKernelGGL(k_sb_scatter, dim3(SB_BLOCKS, frames), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sb_cmf, dim3(SPCBPT_NUM_SUBSPACE, frames), dim3(256), 0, s, b);
+    hipLaunchKernelGGL(k_sb_copy, dim3(256, frames), dim3(256), 0, s, b);
+}
+__global__ __launch_bounds__(256) void k_lvc_sorted_copy(const LightVertex* __restrict__ lvc, const uint32_t* __restrict__ jump, const int* __restrict__ counts,
+                                                        LightVertex* __restrict__ out, int capacity) {
+    const int n = min(counts[0], capacity);
+    const float4* src = reinterpret_cast<const float4*>(lvc);
+    float4* dst = reinterpret_cast<float4*>(out);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const size_t from = jump[i];
+#pragma unroll
+        for (int q = 0; q < 6; q++) dst[(size_t)i * 6 + q] = src[from * 6 + q];
+    }
+}
+void launch_lvc_sorted_copy(const LightVertex* lvc, const uint32_t* jump, const int* sampler_counts, LightVertex* lvc_sorted, int capacity, hipStream_t s) {
+    if (capacity <= 0 || !lvc_sorted) return;
+    hipLaunchKernelGGL(k_lvc_sorted_copy, dim3(512), dim3(256), 0, s, lvc, jump, sampler_counts, lvc_sorted, capacity);
 }
 void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
-                          uint32_t* jump, double* wsorted, float* cmfs, hipStream_t s) {
+                          uint32_t* jump, double* wsorted, float* cmfs, LightVertex* lvc_sorted, hipStream_t s) {
     SamplerBuildBatch b = {};
     b.lvc[0] = lvc; b.n_host[0] = n_host; b.n_dev[0] = n_dev; b.path_count[0] = path_count; b.sub[0] = sub; b.jump[0] = jump; b.cmfs[0] = cmfs;
+    b.lvc_sorted[0] = lvc_sorted;
     b.keys = keys; b.weights = weights; b.hist = hist; b.wsorted = wsorted; b.item_stride = 0;
     launch_sampler_build_batch(b, 1, s);
 }

@@ -128,9 +128,11 @@ struct FrameDesc {  // 64 B
     const int32_t* jump;
     const int32_t* sampler_counts;
     float* result;       // float4 per pixel: the radiance of this frame's samples (merged in frame order afterwards)
+    const spcbpt_light_vertex* lvc_sorted;   // the cache in the sampler's order (KParams::lvc_sorted)
     uint32_t subframe;
-    uint32_t pad[3];
+    uint32_t pad[1];
 };
+static_assert(sizeof(FrameDesc) == 64, "FrameDesc");
 static const int kMaxBatchFrames = 32;  // the frame id of a published eye vertex travels in 6 bits next to its subspace ids and depth
 static_assert(kMaxBatchFrames <= 64, "the frame id of a batched launch is packed into 6 bits (kernels.hip: published eye vertex)");
 
@@ -152,6 +154,9 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     const float* cmf_gamma2;  // three-level copy of cmf_gamma for first-stage sampling (CMF2_ROW floats per row, see device_lib.h)
     // sampler (SubspaceSampler)
     const LightVertex* lvc;
+    const LightVertex* lvc_sorted;  // the same vertices in the sampler's order (record i = lvc[jump[i]]): the vertices of a light subspace
+                                    // are contiguous, and the eye megakernel fetches the vertex it has drawn by its position in the CMF
+                                    // -- no read of `jump` in between (written by the sampler build, kernels.hip k_sb_scatter)
     const DSubspace* subspace;
     const float* cmfs;
     const int32_t* jump;

@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--light-batch", type=int, default=-1,
                     help="1: the light passes of a batch of frames as ONE persistent launch too (spcbpt_launch_light_batch), a batch ahead; "
                          "0: one launch per pass (a pass is a ~1.2 ms dependent chain however few paths a rank traces; a batch of them in one thin, long-lived grid costs the eye kernels beside it less)")
+    ap.add_argument("--build-ahead", type=int, default=1, help="1 (default, one GPU): the sampler builds of the next eye launch are queued behind this one (they run under it); 0: built when their eye launch is issued")
     ap.add_argument("--build-batch", type=int, default=1, help="1 (default): the sampler builds of a batch of frames as one set of four launches (spcbpt_build_sampler_batch); 0: one build per step")
     ap.add_argument("--light-ahead", type=int, default=0, help="light passes launched ahead of their sampler build (0 = 1, or the batch size when eye launches are batched)")
     ap.add_argument("--no-light-ahead", action="store_true", help="launch each frame's light pass only when its sampler build / exchange is due (the host then waits for it)")
@@ -374,14 +375,44 @@ def main():
     # cannot start before the last (2.4 ms of the 86 a 20-step run takes)
     bbatch = lbatch and args.build_batch != 0 and (comm is None or xbatch)   # (a per-frame exchange addresses the oldest UNBUILT pass: its build cannot wait)
 
-    def flush(isolate=False):
+    # ... and a batch AHEAD (one GPU): the builds of the NEXT eye launch are queued right behind this one -- their light passes were
+    # launched at this batch's first step, a batch ago by the time they are needed -- so that they run under the eye kernel that does
+    # not need them instead of between two eye kernels.  Every step still has its one build (of a later frame, like its light pass);
+    # spcbpt_launch_eye_batch renders the samplers of the last n builds, in build order, so the frames keep their passes.
+    build_ahead = bbatch and comm is None and ex is None and hasattr(r.lib, "spcbpt_get_pipeline_state") and args.build_ahead != 0
+    state["prebuilt"] = 0
+
+    def flush(isolate=False, ahead_at_end=False):
         if queued:
+            need = len(queued)
             if bbatch:
-                r.build_sampler_batch(len(queued))
+                have = state["prebuilt"]
+                if have not in (0, need):
+                    raise SystemExit(f"bench loop: {have} samplers were built ahead for a batch of {need}")
+                if have == 0:
+                    r.build_sampler_batch(need)
+                state["prebuilt"] = 0
                 if isolate:
                     r.sync()
             r.launch_eye_batch(queued, rows)
             queued.clear()
+            if build_ahead and not isolate and (state["phase_left"] > 0 or ahead_at_end):
+                # (at the end of the timed phases too: the builds of the batch AFTER the phase -- a timed step has its build like its
+                # light pass, whether or not anything renders it; at the end of the warm-up and isolation phases nothing is built ahead:
+                # single launches follow, which would get between these samplers and their eye launch)
+                pend = r.pipeline_state()["pending_passes"]
+                n_next = min(batch, state["phase_left"]) if state["phase_left"] > 0 else min(batch, pend)
+                if 0 < n_next <= pend:
+                    r.build_sampler_batch(n_next)
+                    state["prebuilt"] = n_next
+
+    def prebuild_first_batch(steps):
+        """The samplers of a phase's first eye launch, built under the phase before it (its light passes were traced there too)."""
+        if build_ahead and state["prebuilt"] == 0 and not queued:
+            n = min(batch, steps)
+            if 0 < n <= r.pipeline_state()["pending_passes"]:
+                r.build_sampler_batch(n)
+                state["prebuilt"] = n
 
     def barrier():
         if dist is not None:
@@ -447,12 +478,13 @@ def main():
 
     r.clear_accum()
     r.reset_kernel_time()
+    prebuild_first_batch(args.steps)
     barrier()
     t0 = time.perf_counter()
     state["phase_left"] = args.steps
     for f in range(args.steps):
         step(f)
-    flush()
+    flush(ahead_at_end=True)
     if ex is not None:
         ex.reduce_framebuffer()
     elif comm is not None:
@@ -475,7 +507,7 @@ def main():
         state["phase_left"] = nl
         for f in range(nl):
             step(2000 + f)
-        flush()
+        flush(ahead_at_end=True)
         barrier()
         ms_long = (time.perf_counter() - t1) / nl * 1e3
         if dist is not None:
@@ -622,7 +654,7 @@ def main():
                                    f"{info['bvh_depth']}), {args.width}x{args.height}, SPCBPT: {M} light paths + "
                                    f"{eye_paths} eye paths per subframe, CONNECTION_N=3, subspace tuple: {args.tuple}, light pass geometry "
                                    f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
-                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "parallelism": "1 GPU" if world == 1 and comm is None else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu: ' + comm_transport + ' transport, ' + str(comm_world) + ' ranks seen by the communicator' if comm is not None else 'torch.distributed harness (--exchange python)'}" + (f", shard capacity {comm.shard_capacity} vertices, {'one exchange per light batch' if xbatch else 'one exchange per frame'}" if comm is not None else "") + ")",
+                       "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "sampler_builds_ahead": batch if build_ahead else 0, "parallelism": "1 GPU" if world == 1 and comm is None else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu: ' + comm_transport + ' transport, ' + str(comm_world) + ' ranks seen by the communicator' if comm is not None else 'torch.distributed harness (--exchange python)'}" + (f", shard capacity {comm.shard_capacity} vertices, {'one exchange per light batch' if xbatch else 'one exchange per frame'}" if comm is not None else "") + ")",
                        "host": "single context" if dist is None else ("libspcbpt_mgpu" if comm is not None else "torch.distributed harness"), "rccl_ranks": comm_world if comm is not None else (world if dist is not None else 0)},
             "roofline": {"bound": "latency" if nearest else "hbm",
                          "bound_note": ("contract roofline = algorithmic HBM bytes / kernel time / 8 TB/s (frac); the kernel is NOT HBM-bound: "

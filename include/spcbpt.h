@@ -466,6 +466,11 @@ int spcbpt_build_sampler_batch(spcbpt_ctx* ctx, int n_builds);
 /* Test hook: bytes and frames of that scratch, and how many batches fell back to single builds for want of it
  * (SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT=<bytes> in the environment makes larger requests fail). */
 int spcbpt_debug_batch_scratch(spcbpt_ctx* ctx, int64_t* bytes, int* frames, int* fallbacks);
+/* Test hook: host copies of the tables the eye kernel samples through (no reference counterpart; csrc/layout.h KParams::guide,
+ * cmf_guide1, gamma_q).  guide2: one entry per light vertex of the last sampler build, in the order of spcbpt_sampler_read's cmfs
+ * (capacity2 entries at least the vertex count, else SPCBPT_ERR_CAPACITY); guide1: 1000 x 1024 entries; gamma_q: 1000 x 1000.
+ * Any of the three may be NULL. */
+int spcbpt_debug_read_sampling_tables(spcbpt_ctx* ctx, uint32_t* guide2, int capacity2, uint16_t* guide1, float* gamma_q);
 
 /* Light passes running ahead (multi-GPU host loops; no reference counterpart).  The light pass is a ~1 ms dependent chain
  * however few paths a rank traces, and the LVC exchange makes the host wait for it; with on != 0 the host may launch frame

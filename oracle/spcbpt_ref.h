@@ -149,7 +149,7 @@ struct Params {  // MyParams (optixPathTracer.h:191-199 + whitted.h:64-84)
 
     float Gamma(int eye_id, int light_id) const {
         if (CMFGamma && Q) {
-            if (counters) counters->gamma_q_reads += light_id == 0 ? 1 : 2;
+            if (counters && !count_as_executed) counters->gamma_q_reads += light_id == 0 ? 1 : 2;   // (executed order: one read of the product's Gamma / Q table, charged by gamma_ss)
             return light_id == 0 ? CMFGamma[eye_id * SPCBPT_NUM_SUBSPACE + light_id]
                                  : CMFGamma[eye_id * SPCBPT_NUM_SUBSPACE + light_id] -
                                        CMFGamma[eye_id * SPCBPT_NUM_SUBSPACE + light_id - 1];
@@ -882,10 +882,33 @@ inline int binary_sample(const Params& P, const float* cmf, int size, uint32_t& 
     pmf = l == 0 ? cmf[l] : cmf[l] - cmf[l - 1];
     return l;
 }
+// What the product's guided search reads on its way to the bisection's bin (executed-order counters only; csrc/device_lib.h
+// guide_window): one guide entry, then aligned windows of eight CMF values from the entry in front of the guide's place up to the
+// window that holds the first value above u.  `base` = the CMF's place in the array the windows are aligned in.
+inline unsigned guided_search_reads(const float* cmf, int size, int base, int guide_place, int answer) {
+    (void)cmf; (void)size;
+    const int c0 = guide_place > 0 ? guide_place - 1 : 0;
+    const int pos = (base + c0) & ~3;
+    return 1u + 8u * (unsigned)((base + answer - pos) / 8 + 1);
+}
 inline const BDPTVertex& sampleSecondStage(const Params& P, int subspaceId, uint32_t& seed, float& sample_pmf) {  // cuProg.h:268-280
     const SubspaceSampler& s = P.sampler;
     int begin_index = s.subspace[subspaceId].jump_bias;
-    int index = binary_sample(P, s.cmfs + begin_index, s.subspace[subspaceId].size, seed, sample_pmf) + begin_index;
+    const int size = s.subspace[subspaceId].size;
+    uint32_t peek = seed;
+    const float u = rnd(peek);
+    const int k = binary_sample(P, s.cmfs + begin_index, size, seed, sample_pmf, !P.count_as_executed);
+    if (P.count_as_executed && P.counters && size > 0) {
+        // the second-stage guide table (csrc/kernels.hip build_guide): bucket (int)(u * n), place = the first k with cmf[k] > (j / n)(1 - 2^-20)
+        const float* cmf = s.cmfs + begin_index;
+        int j = (int)(u * (float)size);
+        if (j > size - 1) j = size - 1;
+        const double tj = (double)j / (double)size * (1.0 - 1.0 / 1048576.0);
+        int g = 0, hi = size - 1;
+        while (g < hi) { const int m = (g + hi) >> 1; if ((double)cmf[m] > tj) hi = m; else g = m + 1; }
+        P.counters->cmf_probes += guided_search_reads(cmf, size, begin_index, g, k);
+    }
+    int index = k + begin_index;
     return s.LVC[s.jump_buffer[index]];
 }
 inline const BDPTVertex& uniformSample(const Params& P, uint32_t& seed, float& sample_pmf) {  // cuProg.h:283-289
@@ -897,8 +920,19 @@ inline const BDPTVertex& uniformSample(const Params& P, uint32_t& seed, float& s
 }
 inline int sampleFirstStage(const Params& P, int eye_subspace, uint32_t& seed, float& sample_pmf) {  // cuProg.h:290-301
     int begin_index = eye_subspace * SPCBPT_NUM_SUBSPACE;
-    if (P.count_as_executed && P.counters) P.counters->cmf_probes += 32;   // the product's three counting passes over 16 + 8 + 8 values (the pmf's two are among them)
-    return binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf, !P.count_as_executed);
+    uint32_t peek = seed;
+    const float u = rnd(peek);
+    const int l = binary_sample(P, P.CMFGamma + begin_index, SPCBPT_NUM_SUBSPACE, seed, sample_pmf, !P.count_as_executed);
+    if (P.count_as_executed && P.counters) {
+        // the first-stage guide table (csrc/capi.hip): 1024 buckets per row, place = the first entry above bucket / 1024; each row is
+        // aligned on its own (base 0)
+        const float* cmf = P.CMFGamma + begin_index;
+        const float t = (float)(int)(u * 1024.0f) / 1024.0f;
+        int g = 0, hi = SPCBPT_NUM_SUBSPACE;   // (a non-decreasing row: the executed-order counters are those of a trained or uniform matrix)
+        while (g < hi) { const int m = (g + hi) >> 1; if (cmf[m] > t) hi = m; else g = m + 1; }
+        P.counters->cmf_probes += guided_search_reads(cmf, SPCBPT_NUM_SUBSPACE, 0, g, l);
+    }
+    return l;
 }
 
 // connectVertex_SPCBPT (raygen.cu:253-303)

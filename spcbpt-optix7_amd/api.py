@@ -520,6 +520,7 @@ def load_library(path: str = LIB_PATH):
         "spcbpt_reuse_sampler": [vp],
         "spcbpt_read_film": [vp, vp, vp],
         "spcbpt_debug_batch_scratch": [vp, C.POINTER(C.c_int64), C.POINTER(i32), C.POINTER(i32)],
+        "spcbpt_debug_read_sampling_tables": [vp, vp, i32, vp, vp],
         "spcbpt_lvc_import_wait": [vp],
         "spcbpt_kernel_time": [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(i32)],
         "spcbpt_reset_kernel_time": [vp],
@@ -584,7 +585,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_debug_trace_bench",
-    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_get_pipeline_state", "spcbpt_reuse_sampler", "spcbpt_read_film", "spcbpt_debug_batch_scratch", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_get_pipeline_state", "spcbpt_reuse_sampler", "spcbpt_read_film", "spcbpt_debug_batch_scratch", "spcbpt_debug_read_sampling_tables", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",
@@ -793,6 +794,15 @@ class Renderer:
         b, f, k = C.c_int64(), C.c_int32(), C.c_int32()
         self._chk(self.lib.spcbpt_debug_batch_scratch(self.h, C.byref(b), C.byref(f), C.byref(k)), "debug_batch_scratch")
         return {"bytes": int(b.value), "frames": int(f.value), "fallbacks": int(k.value)}
+
+    def sampling_tables(self, vertex_count):
+        """(guide2, guide1, gamma_q): the tables the eye kernel samples through (spcbpt_debug_read_sampling_tables)."""
+        g2 = np.zeros(max(vertex_count, 1), dtype=np.uint32)
+        g1 = np.zeros((NUM_SUBSPACE, 1024), dtype=np.uint16)
+        gq = np.zeros((NUM_SUBSPACE, NUM_SUBSPACE), dtype=np.float32)
+        self._chk(self.lib.spcbpt_debug_read_sampling_tables(self.h, g2.ctypes.data if vertex_count > 0 else None, len(g2), g1.ctypes.data, gq.ctypes.data),
+                  "debug_read_sampling_tables")
+        return g2[:vertex_count], g1, gq
 
     def lvc_read(self, capacity=None):
         if capacity is None:

@@ -196,6 +196,32 @@ int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_t
         }
         if (!d_gamma2) HIP_TRY(this, dev_alloc(&d_gamma2, two.size()));
         HIP_TRY(this, hipMemcpy(d_gamma2, two.data(), two.size() * sizeof(float), hipMemcpyHostToDevice));
+        {   // gamma_ss as a table (layout.h: KParams::gamma_q): the device's own FP32 subtraction and division, done once here
+            std::vector<float> gq((size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE);
+            for (int e = 0; e < SPCBPT_NUM_SUBSPACE; e++) {
+                const float* row = &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE];
+                for (int l = 0; l < SPCBPT_NUM_SUBSPACE; l++) {
+                    const float g = l == 0 ? row[0] : row[l] - row[l - 1];
+                    gq[(size_t)e * SPCBPT_NUM_SUBSPACE + l] = g / h_Q[l];
+                }
+            }
+            if (!d_gamma_q) HIP_TRY(this, dev_alloc(&d_gamma_q, gq.size()));
+            HIP_TRY(this, hipMemcpy(d_gamma_q, gq.data(), gq.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        {   // first-stage guide table (layout.h: KParams::cmf_guide1): per row, the first entry above b / CMF_GUIDE1 for every bucket b
+            std::vector<uint16_t> guide((size_t)SPCBPT_NUM_SUBSPACE * CMF_GUIDE1);
+            for (int e = 0; e < SPCBPT_NUM_SUBSPACE; e++) {
+                const float* row = &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE];
+                int k = 0;
+                for (int b = 0; b < CMF_GUIDE1; b++) {
+                    const float t = (float)b / (float)CMF_GUIDE1;   // exact; u * CMF_GUIDE1 is exact too, so every u of bucket b is >= t
+                    while (k < SPCBPT_NUM_SUBSPACE && !(row[k] > t)) k++;
+                    guide[(size_t)e * CMF_GUIDE1 + b] = (uint16_t)k;
+                }
+            }
+            if (!d_guide1) HIP_TRY(this, dev_alloc(&d_guide1, guide.size()));
+            HIP_TRY(this, hipMemcpy(d_guide1, guide.data(), guide.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
         gamma_monotone = true;   // counting equals bisecting only on a non-decreasing row that ends above every random number
         for (int e = 0; e < SPCBPT_NUM_SUBSPACE && gamma_monotone; e++) {
             const float* row = &h_gamma[(size_t)e * SPCBPT_NUM_SUBSPACE];
@@ -204,7 +230,7 @@ int Context::install_subspace(const spcbpt_tree_node* et, int ne, const spcbpt_t
         }
     }
     HIP_TRY(this, hipStreamSynchronize(stream));
-    kp.eye_tree = d_eye_tree; kp.light_tree = d_light_tree; kp.Q = d_Q; kp.cmf_gamma = d_gamma; kp.cmf_gamma2 = gamma_monotone ? d_gamma2 : nullptr;
+    kp.eye_tree = d_eye_tree; kp.light_tree = d_light_tree; kp.Q = d_Q; kp.cmf_gamma = d_gamma; kp.cmf_gamma2 = gamma_monotone ? d_gamma2 : nullptr; kp.cmf_guide1 = d_guide1; kp.gamma_q = d_gamma_q;
     have_subspace = true;
     return 0;
 }
@@ -329,8 +355,10 @@ int Context::ensure_lvc_capacity(size_t n) {
     dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_weights);
     dev_free(d_wsorted); dev_free(d_prefix);
     for (int s = 0; s < n_sets; s++) {   // what the eye pass reads exists once per frame in flight (see context.h)
-        dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]);
-        HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_lvc_sorted[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n)); HIP_TRY(this, dev_alloc(&set_cmfs[s], n));
+        dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_guide[s]);
+        HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_lvc_sorted[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n));
+        HIP_TRY(this, dev_alloc(&set_cmfs[s], n + 8));   // (the eye kernel reads a CMF in aligned windows of eight: kernels.hip guide_window)
+        HIP_TRY(this, dev_alloc(&set_guide[s], n));
     }
     for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; set_bound[s2] = -1; ev_exch_set[s2] = false; }   // the sets are empty again
     pending.clear();
@@ -649,7 +677,7 @@ int Context::build_sampler() {
         const bool count_paths = !dev_count && !lazy && !(keys_ready && keys_set == bset);   // (a light pass has left the path count in its set)
         if (count_paths) HIP_TRY(this, hipMemsetAsync(d_sampler_counts + 1, 0, sizeof(int), stream));
         launch_sampler_build(d_lvc, n, (dev_count || lazy) ? d_sampler_counts : nullptr, d_keys, d_weights, d_hist, count_paths ? d_sampler_counts + 1 : nullptr,
-                             d_subspace, d_vals2, d_wsorted, d_cmfs, set_lvc_sorted[bset], stream);
+                             d_subspace, d_vals2, d_wsorted, d_cmfs, set_lvc_sorted[bset], set_guide[bset], stream);
         keys_ready = false;
     } else {
     if (dev_count) {
@@ -672,6 +700,7 @@ int Context::build_sampler() {
         HIP_TRY(this, hipcub::DeviceScan::InclusiveSum(d_temp, tb2, d_wsorted, d_prefix, n, stream));
         launch_cmf(d_prefix, d_keys2, d_sampler_counts, d_subspace, d_cmfs, n, stream);
         launch_lvc_sorted_copy(d_lvc, d_vals2, d_sampler_counts, set_lvc_sorted[bset], n, stream);
+        launch_sampler_guide(d_subspace, d_cmfs, set_guide[bset], stream);
     }
     }
     time_end();
@@ -769,7 +798,7 @@ int Context::build_sampler_batch(int n) {
         // (spcbpt_lvc_import) has it counted by the build, as build_sampler does
         const bool count_paths = !dev_count && !light_counts_valid[b];
         B.lvc[k] = set_lvc[b]; B.n_host[k] = count; B.n_dev[k] = (dev_count || lazy) ? set_counts[b] : nullptr; B.path_count[k] = count_paths ? set_counts[b] + 1 : nullptr;
-        B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b]; B.lvc_sorted[k] = set_lvc_sorted[b];
+        B.sub[k] = set_subspace[b]; B.jump[k] = set_vals2[b]; B.cmfs[k] = set_cmfs[b]; B.lvc_sorted[k] = set_lvc_sorted[b]; B.guide[k] = set_guide[b];
         if (count_paths) HIP_TRY(this, hipMemsetAsync(set_counts[b] + 1, 0, sizeof(int), stream));
     }
     time_begin("sampler_build");
@@ -878,7 +907,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     kp.result = d_result[rk];
     if (spcbpt_alg) {
         // the sampler tables this launch reads (set `eset`) were built on `stream`
-        kp.lvc = set_lvc[eset]; kp.lvc_sorted = set_lvc_sorted[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset];
+        kp.lvc = set_lvc[eset]; kp.lvc_sorted = set_lvc_sorted[eset]; kp.subspace = set_subspace[eset]; kp.cmfs = set_cmfs[eset]; kp.guide = set_guide[eset];
         kp.jump = reinterpret_cast<const int32_t*>(set_vals2[eset]); kp.sampler_counts = set_counts[eset];
         if (rstream != stream && ev_sampler_set[eset]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[eset], 0));
     }
@@ -991,8 +1020,8 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
         const int e = built_sets[built_sets.size() - (size_t)n + (size_t)k];   // oldest of the last n first
         sets[k] = e;
         if (!d_result_b[rk][k]) HIP_TRY(this, dev_alloc(&d_result_b[rk][k], px * 4));
-        hf[k].lvc = set_lvc[e]; hf[k].lvc_sorted = set_lvc_sorted[e]; hf[k].subspace = set_subspace[e]; hf[k].cmfs = set_cmfs[e];
-        hf[k].jump = reinterpret_cast<const int32_t*>(set_vals2[e]); hf[k].sampler_counts = set_counts[e];
+        hf[k].lvc = set_lvc[e]; hf[k].lvc_sorted = set_lvc_sorted[e]; hf[k].subspace = set_subspace[e]; hf[k].cmfs = set_cmfs[e]; hf[k].guide = set_guide[e];
+        hf[k].sampler_counts = set_counts[e];
         hf[k].result = d_result_b[rk][k]; hf[k].subframe = subframes[k];
         if (rstream != stream && ev_sampler_set[e]) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_sampler[e], 0));
     }
@@ -1092,10 +1121,10 @@ Context::~Context() {
     free_preprocess();
     dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_nodes_q2); /* d_tris lives in d_nodes' allocation */ dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
-    dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2);
+    dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2); dev_free(d_guide1); dev_free(d_gamma_q);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);
     dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
-    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_subspace[s]); }
+    for (int s = 0; s < kMaxSets; s++) { dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_guide[s]); dev_free(set_subspace[s]); }
     dev_free(d_set_counts_all); dev_free(lb_scratch); dev_free(lb_core_counts); dev_free(lb_core_offsets); dev_free(lb_path_counts); dev_free(lb_spill);
     dev_free(d_counters); dev_free(d_diag); dev_free(d_work_counter); if (h_import_counts) (void)hipHostFree(h_import_counts); if (h_light_counts) (void)hipHostFree(h_light_counts);
     for (int s2 = 0; s2 < kMaxRender; s2++) { for (int k = 0; k < kMaxBatchFrames; k++) dev_free(d_result_b[s2][k]); if (d_frames[s2]) (void)hipFree(d_frames[s2]); }
@@ -1641,6 +1670,21 @@ int spcbpt_debug_batch_scratch(spcbpt_ctx* c, int64_t* bytes, int* frames, int* 
     if (fallbacks) *fallbacks = c->sbb_fallbacks;
     return SPCBPT_OK;
 }
+int spcbpt_debug_read_sampling_tables(spcbpt_ctx* c, uint32_t* guide2, int capacity2, uint16_t* guide1, float* gamma_q) {
+    CTX_CHECK(c);
+    if (c->sync_all()) return SPCBPT_ERR_HIP;
+    if (guide2) {
+        if (!c->have_sampler) { c->error = "no sampler built"; return SPCBPT_ERR_STATE; }
+        int hc[2] = {0, 0};
+        HIP_TRY(c, hipMemcpy(hc, c->set_counts[c->eset], sizeof(hc), hipMemcpyDeviceToHost));
+        if (capacity2 < hc[0]) { c->error = "debug_read_sampling_tables: buffer too small"; return SPCBPT_ERR_CAPACITY; }
+        HIP_TRY(c, hipMemcpy(guide2, c->set_guide[c->eset], (size_t)hc[0] * 4, hipMemcpyDeviceToHost));
+    }
+    if ((guide1 || gamma_q) && !c->d_guide1) { c->error = "no subspace tuple installed"; return SPCBPT_ERR_STATE; }
+    if (guide1) HIP_TRY(c, hipMemcpy(guide1, c->d_guide1, (size_t)SPCBPT_NUM_SUBSPACE * CMF_GUIDE1 * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (gamma_q) HIP_TRY(c, hipMemcpy(gamma_q, c->d_gamma_q, (size_t)SPCBPT_NUM_SUBSPACE * SPCBPT_NUM_SUBSPACE * sizeof(float), hipMemcpyDeviceToHost));
+    return SPCBPT_OK;
+}
 int spcbpt_accum_device_ptr(spcbpt_ctx* c, void** p) {
     CTX_CHECK(c);
     if (!p || !c->d_accum) return SPCBPT_ERR_STATE;
@@ -1921,7 +1965,7 @@ int spcbpt_debug_unit(spcbpt_ctx* c, int op, const uint32_t* in, int in_words, u
     if (e == hipSuccess) {
         KParams kp = c->kp;
         const int es = c->eset;   // the tables of the last sampler build
-        kp.lvc = c->set_lvc[es]; kp.lvc_sorted = c->set_lvc_sorted[es]; kp.subspace = c->set_subspace[es]; kp.cmfs = c->set_cmfs[es];
+        kp.lvc = c->set_lvc[es]; kp.lvc_sorted = c->set_lvc_sorted[es]; kp.subspace = c->set_subspace[es]; kp.cmfs = c->set_cmfs[es]; kp.guide = c->set_guide[es];
         kp.jump = reinterpret_cast<const int32_t*>(c->set_vals2[es]); kp.sampler_counts = c->set_counts[es];
         kp.counters = nullptr;
         if (op == SPCBPT_UNIT_EYE_STEP) {

@@ -99,6 +99,7 @@ struct Context {
     LightVertex* set_lvc_sorted[kMaxSets] = {};   // the set's cache in its sampler's order (written by the sampler build, read by the eye megakernel)
     uint32_t* set_vals2[kMaxSets] = {};
     float* set_cmfs[kMaxSets] = {};
+    uint32_t* set_guide[kMaxSets] = {};   // the set's second-stage guide table (layout.h KParams::guide)
     DSubspace* set_subspace[kMaxSets] = {};
     int* set_counts[kMaxSets] = {};
     uint32_t* d_spill_rs[kMaxRender] = {};   // traversal-stack spill areas of the render streams (d_spill serves `stream`)
@@ -134,6 +135,8 @@ struct Context {
     float* d_Q = nullptr;
     float* d_gamma = nullptr;
     float* d_gamma2 = nullptr;   // three-level copy of d_gamma (layout.h: CMF2_ROW)
+    float* d_gamma_q = nullptr;     // Gamma / Q table (layout.h: KParams::gamma_q)
+    uint16_t* d_guide1 = nullptr;   // first-stage guide table (layout.h: KParams::cmf_guide1)
     bool gamma_monotone = false; // every row of the installed matrix is a proper CMF: first-stage sampling may count instead of bisect
     std::vector<spcbpt_tree_node> h_eye_tree, h_light_tree;
     std::vector<float> h_Q, h_gamma;

@@ -1149,6 +1149,9 @@ SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA
 // Gamma(e,l)/Q[l] (optixPathTracer.h:173-189); the product always runs with a full tuple installed
 template <bool COUNT>
 SPC_DEV float gamma_ss(const KParams& p, int e, int l, Counts<COUNT>& cn) {
+    // the timed kernels read the quotient from a table of the same FP32 operations done once per tuple (layout.h KParams::gamma_q):
+    // one load instead of three and no division per evaluation, ~12 evaluations per eye path
+    if (p.gamma_q) { cn.add(C_GQ, 1); return p.gamma_q[(size_t)e * SPCBPT_NUM_SUBSPACE + l]; }
     const float* row = p.cmf_gamma + (size_t)e * SPCBPT_NUM_SUBSPACE;
     const float g = l == 0 ? row[0] : row[l] - row[l - 1];
     cn.add(C_GQ, l == 0 ? 2 : 3);
@@ -1243,6 +1246,66 @@ SPC_DEV void sample_first_stage_n(const float* cmf_gamma2, int eye_subspace, con
         pmf[i] = s[i].count == 0 ? s[i].hi : s[i].hi - s[i].lo;
     }
 }
+// Guided form (round 5, the cutpoint method): a guide table names, for the bucket (int)(u * buckets) of the random number, a place g
+// that the answer cannot precede (layout.h: KParams::guide, cmf_guide1), and the entries from g - 1 on are read in aligned windows of
+// eight (two 16-B loads) until one is above u: in a non-decreasing CMF the answer is the number of entries <= u, cmf[answer] the
+// smallest entry > u of the last window and cmf[answer - 1] the largest entry <= u read (entry g - 1 is in the first window for that).
+// One guide entry and -- nearly always -- one window per sample instead of 32 values in three round trips (first stage) or one
+// probe per level and two for the pmf (second stage); same bin, same pmf, same random number.
+#ifndef SPC_GUIDE
+#define SPC_GUIDE 1
+#endif
+struct GuideScan { int cnt; float lo, hi; };   // entries <= u so far; the largest of them; the smallest entry > u
+// the entries at places [pos, pos + 8) of an array, of which [first, end) take part
+SPC_DEV void guide_window(float4 q0, float4 q1, int pos, int first, int end, float u, GuideScan& s) {
+    const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const bool in = pos + i >= first && pos + i < end;
+        const bool le = in && v[i] <= u, gt = in && !(v[i] <= u);
+        s.cnt += le ? 1 : 0;
+        s.lo = fmaxf(s.lo, le ? v[i] : -INFINITY);
+        s.hi = fminf(s.hi, gt ? v[i] : INFINITY);
+    }
+}
+// sampleFirstStage through the guide table; returns the number of windows read (the executed-order probe count)
+SPC_DEV int sample_first_stage_guided(const float* cmf_gamma2, const uint16_t* guide1, int eye_subspace, float u, int& l, float& pmf) {
+    const float* fine = cmf_gamma2 + (size_t)eye_subspace * CMF2_ROW + CMF2_COARSE + CMF2_MID;   // 1000 entries, 2.0 up to CMF2_FINE
+    const int g = guide1[(size_t)eye_subspace * CMF_GUIDE1 + (int)(u * (float)CMF_GUIDE1)];
+    const int c0 = max(g - 1, 0);
+    GuideScan s = {c0, -INFINITY, INFINITY};
+    int pos = c0 & ~3, windows = 0;
+    do {
+        const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = *reinterpret_cast<const float4*>(fine + pos + 4);
+        guide_window(q0, q1, pos, c0, CMF2_FINE, u, s);
+        pos += 8; windows++;
+    } while (!(s.hi < INFINITY) && pos < CMF2_FINE);
+    l = s.cnt;
+    pmf = l == 0 ? s.hi : s.hi - s.lo;
+    return windows;
+}
+// ... of the CONNECTION_N samples of one eye subspace: the guide entries in flight together, the windows one after the other
+template <int N>
+SPC_DEV void sample_first_stage_guided_n(const float* cmf_gamma2, const uint16_t* guide1, int eye_subspace, const float u[N], int l[N], float pmf[N], int windows[N]) {
+    const float* fine = cmf_gamma2 + (size_t)eye_subspace * CMF2_ROW + CMF2_COARSE + CMF2_MID;
+    int g[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) g[i] = guide1[(size_t)eye_subspace * CMF_GUIDE1 + (int)(u[i] * (float)CMF_GUIDE1)];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int c0 = max(g[i] - 1, 0);
+        GuideScan s = {c0, -INFINITY, INFINITY};
+        int pos = c0 & ~3;
+        windows[i] = 0;
+        do {
+            const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = *reinterpret_cast<const float4*>(fine + pos + 4);
+            guide_window(q0, q1, pos, c0, CMF2_FINE, u[i], s);
+            pos += 8; windows[i]++;
+        } while (!(s.hi < INFINITY) && pos < CMF2_FINE);
+        l[i] = s.cnt;
+        pmf[i] = s.cnt == 0 ? s.hi : s.hi - s.lo;
+    }
+}
 SPC_DEV int bisection_probes(int l, int size) {   // the probes of the reference's bisection on its way to bin l
     int n = 0, mid = size / 2 - 1, a = 0, b = size;
     while (b - a > 1) {
@@ -1252,16 +1315,22 @@ SPC_DEV int bisection_probes(int l, int size) {   // the probes of the reference
     }
     return n;
 }
-template <bool COUNT, bool EXEC = false>   // EXEC: charge the 16 + 8 + 8 values the counting form really reads, not the bisection's probes
+template <bool COUNT, bool EXEC = false>   // EXEC: charge what the guided form really reads (one guide entry, eight values per window), not the bisection's probes
 SPC_DEV int sample_first_stage(const KParams& p, int eye_subspace, uint32_t& seed, float& pmf, Counts<COUNT>& cn) {
     // a caller-supplied matrix with a decreasing row (not a CMF) keeps the bisection, whose answer is then its own definition
     if (!p.cmf_gamma2) return binary_sample(p.cmf_gamma + (size_t)eye_subspace * SPCBPT_NUM_SUBSPACE, SPCBPT_NUM_SUBSPACE, seed, pmf, cn);
     const float u[1] = {rnd(seed)};
     int l[1];
     float pm[1];
+#if SPC_GUIDE
+    const int windows = sample_first_stage_guided(p.cmf_gamma2, p.cmf_guide1, eye_subspace, u[0], l[0], pm[0]);
+    pmf = pm[0];
+    if (COUNT) cn.add(C_CMF, EXEC ? 1u + 8u * (unsigned)windows : (unsigned)bisection_probes(l[0], SPCBPT_NUM_SUBSPACE));
+#else
     sample_first_stage_n<1>(p.cmf_gamma2, eye_subspace, u, l, pm);
     pmf = pm[0];
     if (COUNT) cn.add(C_CMF, EXEC ? 32u : (unsigned)bisection_probes(l[0], SPCBPT_NUM_SUBSPACE));
+#endif
     return l[0];
 }
 

@@ -39,12 +39,14 @@ struct SamplerBuildBatch {
     const LightVertex* lvc[kMaxBatchFrames]; const int* n_dev[kMaxBatchFrames]; int* path_count[kMaxBatchFrames];
     DSubspace* sub[kMaxBatchFrames]; uint32_t* jump[kMaxBatchFrames]; float* cmfs[kMaxBatchFrames];
     LightVertex* lvc_sorted[kMaxBatchFrames];   // out: lvc_sorted[i] = lvc[jump[i]] (may be null)
+    uint32_t* guide[kMaxBatchFrames];           // out: the second-stage guide table (layout.h KParams::guide; may be null)
     int n_host[kMaxBatchFrames];
     uint32_t* keys; float* weights; int* hist; double* wsorted; size_t item_stride;
 };
 void launch_sampler_build_batch(const SamplerBuildBatch& b, int frames, hipStream_t s);
 void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
-                          uint32_t* jump, double* wsorted, float* cmfs, LightVertex* lvc_sorted, hipStream_t s);
+                          uint32_t* jump, double* wsorted, float* cmfs, LightVertex* lvc_sorted, uint32_t* guide, hipStream_t s);
+void launch_sampler_guide(const DSubspace* sub, const float* cmfs, uint32_t* guide, hipStream_t s);   // (the radix-sort form of the build)
 void launch_lvc_sorted_copy(const LightVertex* lvc, const uint32_t* jump, const int* sampler_counts, LightVertex* lvc_sorted, int capacity, hipStream_t s);   // (the radix-sort form of the build)
 void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s);
 void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s);

@@ -337,12 +337,12 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     // itself does not consume random numbers, so drawing all three first leaves the RNG stream unchanged.
                     // (the light vertices in the sampler's order: the vertex drawn at place k of a subspace's CMF is record jump_bias + k,
                     // next to the other vertices of its subspace -- no trip through `jump`)
-                    const LightVertex* f_lvc = p.lvc_sorted; const DSubspace* f_subspace = p.subspace; const float* f_cmfs = p.cmfs;
+                    const LightVertex* f_lvc = p.lvc_sorted; const DSubspace* f_subspace = p.subspace; const float* f_cmfs = p.cmfs; const uint32_t* f_guide = p.guide;
                     int f_path_count = path_count;
                     const int32_t* f_counts = p.sampler_counts;
                     if (BATCH) {   // the sampler tables of this path's frame
                         const FrameDesc& D = p.frames[fid];
-                        f_lvc = D.lvc_sorted; f_subspace = D.subspace; f_cmfs = D.cmfs; f_path_count = D.sampler_counts[1];
+                        f_lvc = D.lvc_sorted; f_subspace = D.subspace; f_cmfs = D.cmfs; f_guide = D.guide; f_path_count = D.sampler_counts[1];
                         f_counts = D.sampler_counts;
                     }
                     // Three stages, each over all CONNECTION_N connections, so that what does not depend on each other is in flight together:
@@ -368,7 +368,12 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                         int l[SPCBPT_CONNECTION_N];
 #pragma unroll
                         for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { u1[it] = rnd(sd); after_u1[it] = sd; u2[it] = rnd(sd); }
+#if SPC_GUIDE
+                        int windows[SPCBPT_CONNECTION_N];
+                        sample_first_stage_guided_n<SPCBPT_CONNECTION_N>(p.cmf_gamma2, p.cmf_guide1, cur.sub, u1, l, pm, windows);
+#else
                         sample_first_stage_n<SPCBPT_CONNECTION_N, SPC_JOINT_FIRST_STAGE == 2>(p.cmf_gamma2, cur.sub, u1, l, pm);
+#endif
                         DSubspace ss[SPCBPT_CONNECTION_N];
 #pragma unroll
                         for (int it = 0; it < SPCBPT_CONNECTION_N; it++) ss[it] = f_subspace[l[it]];
@@ -379,7 +384,11 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                             for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                                 pmf1_[it] = pm[it];
                                 if (ss[it].size != 0) { bias_[it] = ss[it].jump_bias; size_[it] = ss[it].size; u2_[it] = u2[it]; }
+#if SPC_GUIDE
+                                if (COUNT) cn.add(C_CMF, CACHE ? 1u + 8u * (unsigned)windows[it] : (unsigned)bisection_probes(l[it], SPCBPT_NUM_SUBSPACE));
+#else
                                 if (COUNT) cn.add(C_CMF, CACHE ? (it == 0 ? 32u : 16u) : (unsigned)bisection_probes(l[it], SPCBPT_NUM_SUBSPACE));
+#endif
                             }
                             w.seed = ss[SPCBPT_CONNECTION_N - 1].size != 0 ? sd : after_u1[SPCBPT_CONNECTION_N - 1];
                         }
@@ -397,6 +406,81 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                         }
                     }
                     }
+#if SPC_GUIDE
+                    if (f_guide) {   // binary_sample (cuProg.h:245-264) of the three through the guide table (device_lib.h: guide_window), side by side
+                        GuideScan s_[SPCBPT_CONNECTION_N];
+                        int pos_[SPCBPT_CONNECTION_N], first_[SPCBPT_CONNECTION_N];
+                        bool open_[SPCBPT_CONNECTION_N];
+                        uint32_t g_[SPCBPT_CONNECTION_N];
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++)
+                            g_[it] = size_[it] > 0 ? f_guide[bias_[it] + min((int)(u2_[it] * (float)size_[it]), size_[it] - 1)] : 0u;
+#ifndef SPC_GUIDE_SIDE_BY_SIDE
+#define SPC_GUIDE_SIDE_BY_SIDE 0   // 1: the windows of the three connections in flight together (24 registers of CMF values: spills, measured)
+#endif
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                            const int c0 = max((int)g_[it] - 1, 0);
+                            s_[it].cnt = c0; s_[it].lo = -INFINITY; s_[it].hi = INFINITY;
+                            first_[it] = bias_[it] + c0; pos_[it] = first_[it] & ~3;
+                            open_[it] = size_[it] > 0;
+                            if (COUNT && CACHE && open_[it]) cn.add(C_CMF);   // (the guide entry; the reference-order form charges the bisection's probes below)
+                        }
+#if SPC_GUIDE_SIDE_BY_SIDE
+                        bool any_open = false;
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) any_open = any_open || open_[it];
+                        while (any_open) {
+                            float4 a_[SPCBPT_CONNECTION_N], b_[SPCBPT_CONNECTION_N];
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                                if (open_[it]) {
+                                    a_[it] = *reinterpret_cast<const float4*>(f_cmfs + pos_[it]);
+                                    b_[it] = *reinterpret_cast<const float4*>(f_cmfs + pos_[it] + 4);
+                                }
+                            }
+                            any_open = false;
+#pragma unroll
+                            for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                                if (open_[it]) {
+                                    if (COUNT && CACHE) cn.add(C_CMF, 8);
+                                    guide_window(a_[it], b_[it], pos_[it], first_[it], bias_[it] + size_[it], u2_[it], s_[it]);
+                                    pos_[it] += 8;
+                                    open_[it] = !(s_[it].hi < INFINITY) && pos_[it] < bias_[it] + size_[it];
+                                }
+                                any_open = any_open || open_[it];
+                            }
+                        }
+#else
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                            while (open_[it]) {
+                                const float4 a = *reinterpret_cast<const float4*>(f_cmfs + pos_[it]);
+                                const float4 b = *reinterpret_cast<const float4*>(f_cmfs + pos_[it] + 4);
+                                if (COUNT && CACHE) cn.add(C_CMF, 8);
+                                guide_window(a, b, pos_[it], first_[it], bias_[it] + size_[it], u2_[it], s_[it]);
+                                pos_[it] += 8;
+                                open_[it] = !(s_[it].hi < INFINITY) && pos_[it] < bias_[it] + size_[it];
+                            }
+                        }
+#endif
+#pragma unroll
+                        for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
+                            if (size_[it] != 0) {
+                                int k = s_[it].cnt;
+                                if (k >= size_[it]) {   // no entry above u (the build ends every CMF with 1: not reached): the bisection's last bin
+                                    const float* cmf = f_cmfs + bias_[it];
+                                    k = size_[it] - 1;
+                                    pmf2_[it] = k == 0 ? cmf[k] : cmf[k] - cmf[k - 1];
+                                } else {
+                                    pmf2_[it] = k == 0 ? s_[it].hi : s_[it].hi - s_[it].lo;
+                                }
+                                lslot_[it] = bias_[it] + k;   // its record in the sorted cache (what jump[bias + k] names in the cache's own order)
+                                if (COUNT && !CACHE) cn.add(C_CMF, (unsigned)bisection_probes(k, size_[it]));
+                            }
+                        }
+                    } else
+#endif
                     {   // binary_sample (cuProg.h:245-264) of the three, level by level
                         int lo_[SPCBPT_CONNECTION_N], hi_[SPCBPT_CONNECTION_N], mid_[SPCBPT_CONNECTION_N];
 #if SPC_SECOND_STAGE_ARY == 4
@@ -1229,10 +1313,23 @@ __global__ __launch_bounds__(256) void k_sb_copy(const SamplerBuildBatch B) {
         dst[t] = src[(size_t)jump[i] * 6 + q];
     }
 }
+// KParams::guide of one subspace: entry j = the first place k with cmf[k] > (j / n)(1 - 2^-20).  A random number u of bucket j --
+// (int)(u * (float)n) == j, the product rounded to FP32 -- is at least (j / n)(1 - 2^-24), so no entry before that place is above u.
+SPC_DEV void build_guide(const float* cmf, int n, uint32_t* guide, int t, int stride) {
+    for (int j = t; j < n; j += stride) {
+        const double tj = (double)j / (double)n * (1.0 - 1.0 / 1048576.0);
+        int lo = 0, hi = n - 1;   // (the last entry is 1)
+        while (lo < hi) {
+            const int m = (lo + hi) >> 1;
+            if ((double)cmf[m] > tj) hi = m; else lo = m + 1;
+        }
+        guide[j] = (uint32_t)lo;
+    }
+}
 __global__ __launch_bounds__(256) void k_sb_cmf(const SamplerBuildBatch B) {
     DSubspace* __restrict__ sub = B.sub[blockIdx.y];
     const double* __restrict__ wsorted = B.wsorted + (size_t)blockIdx.y * B.item_stride;
-    float* __restrict__ cmfs = B.cmfs[blockIdx.y];
+    float* cmfs = B.cmfs[blockIdx.y];   // (read back for the guide table below: not __restrict__)
     __shared__ double sh[256];
     const int k = blockIdx.x, t = threadIdx.x;
     const int b = sub[k].jump_bias, sz = sub[k].size;
@@ -1266,6 +1363,15 @@ __global__ __launch_bounds__(256) void k_sb_cmf(const SamplerBuildBatch B) {
         __syncthreads();
     }
     if (t == 0) sub[k].sum_pmf = (float)total;
+    if (B.guide[blockIdx.y]) build_guide(cmfs + b, sz, B.guide[blockIdx.y] + b, t, 256);   // (the loop above ends on a barrier: the block's CMF is written)
+}
+// the second-stage guide table next to a CMF that another path has written (the radix-sort build)
+__global__ __launch_bounds__(256) void k_sb_guide(const DSubspace* __restrict__ sub, const float* cmfs, uint32_t* __restrict__ guide) {
+    const int b = sub[blockIdx.x].jump_bias, sz = sub[blockIdx.x].size;
+    if (sz > 0) build_guide(cmfs + b, sz, guide + b, threadIdx.x, 256);
+}
+void launch_sampler_guide(const DSubspace* sub, const float* cmfs, uint32_t* guide, hipStream_t s) {
+    if (guide) hipLaunchKernelGGL(k_sb_guide, dim3(SPCBPT_NUM_SUBSPACE), dim3(256), 0, s, sub, cmfs, guide);
 }
 size_t sampler_build_hist_ints() { return (size_t)(SB_BLOCKS + 1) * 1024; }
 void launch_sampler_build_batch(const SamplerBuildBatch& b, int frames, hipStream_t s) {
@@ -1292,8 +1398,9 @@ void launch_lvc_sorted_copy(const LightVertex* lvc, const uint32_t* jump, const 
     hipLaunchKernelGGL(k_lvc_sorted_copy, dim3(512), dim3(256), 0, s, lvc, jump, sampler_counts, lvc_sorted, capacity);
 }
 void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
-                          uint32_t* jump, double* wsorted, float* cmfs, LightVertex* lvc_sorted, hipStream_t s) {
+                          uint32_t* jump, double* wsorted, float* cmfs, LightVertex* lvc_sorted, uint32_t* guide, hipStream_t s) {
     SamplerBuildBatch b = {};
+    b.guide[0] = guide;
     b.lvc[0] = lvc; b.n_host[0] = n_host; b.n_dev[0] = n_dev; b.path_count[0] = path_count; b.sub[0] = sub; b.jump[0] = jump; b.cmfs[0] = cmfs;
     b.lvc_sorted[0] = lvc_sorted;
     b.keys = keys; b.weights = weights; b.hist = hist; b.wsorted = wsorted; b.item_stride = 0;
@@ -1542,7 +1649,11 @@ void launch_spcbpt(const KParams& p, int variant, int max_blocks, hipStream_t s)
     if (tiles <= 0) return;
     int blocks = (tiles + (EYE_BLOCK / 64) - 1) / (EYE_BLOCK / 64);
     if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    if (variant == 1) hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
+    if (variant == 1) {   // the reference's own evaluation of Gamma / Q (three reads, one division), counted as such
+        KParams q = p;
+        q.gamma_q = nullptr;
+        hipLaunchKernelGGL((k_spcbpt<true, false, false>), dim3(blocks), dim3(EYE_BLOCK), 0, s, q);
+    }
     else if (variant == 2) hipLaunchKernelGGL((k_spcbpt<true, false, true>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
     else if (p.scene.general) hipLaunchKernelGGL((k_spcbpt<false, false, true, true>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
     else hipLaunchKernelGGL((k_spcbpt<false, false, true, false>), dim3(blocks), dim3(EYE_BLOCK), 0, s, p);
@@ -1647,7 +1758,11 @@ int light_trace_blocks(const KParams& p, int max_blocks) {
 void launch_light_trace(const KParams& p, int variant, int max_blocks, hipStream_t s) {   // variants as launch_spcbpt
     const int blocks = light_trace_blocks(p, max_blocks);   // p.work_counter (the core queue head) must have been zeroed on `s`
     if (blocks <= 0) return;
-    if (variant == 1) hipLaunchKernelGGL((k_light_trace<true, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (variant == 1) {   // (the reference's own evaluation of Gamma / Q, counted as such: launch_spcbpt)
+        KParams q = p;
+        q.gamma_q = nullptr;
+        hipLaunchKernelGGL((k_light_trace<true, false>), dim3(blocks), dim3(BLOCK), 0, s, q);
+    }
     else if (variant == 2) hipLaunchKernelGGL((k_light_trace<true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL((k_light_trace<false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
 }

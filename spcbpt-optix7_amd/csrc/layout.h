@@ -83,6 +83,7 @@ static_assert(sizeof(LightVertex) == 96, "LightVertex");
 // entries (row[8 m + 7]) and the row itself padded to 1024 entries (padding 2.0 > any random number), all 16-B aligned: a level is
 // 4 / 2 / 2 quads, and the CONNECTION_N samples of a vertex share the coarse ones (device_lib.h: sample_first_stage3).
 static const int CMF2_COARSE = 16, CMF2_MID = 128, CMF2_FINE = 1024, CMF2_ROW = CMF2_COARSE + CMF2_MID + CMF2_FINE;
+static const int CMF_GUIDE1 = 1024;   // buckets of the first-stage guide table per row (a power of two: u * CMF_GUIDE1 is exact)
 
 struct DSubspace {  // 16 B
     int32_t jump_bias;
@@ -125,7 +126,7 @@ struct FrameDesc {  // 64 B
     const spcbpt_light_vertex* lvc;
     const struct DSubspace* subspace;
     const float* cmfs;
-    const int32_t* jump;
+    const uint32_t* guide;   // KParams::guide of this frame's sampler
     const int32_t* sampler_counts;
     float* result;       // float4 per pixel: the radiance of this frame's samples (merged in frame order afterwards)
     const spcbpt_light_vertex* lvc_sorted;   // the cache in the sampler's order (KParams::lvc_sorted)
@@ -152,6 +153,9 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
     const float* Q;
     const float* cmf_gamma;
     const float* cmf_gamma2;  // three-level copy of cmf_gamma for first-stage sampling (CMF2_ROW floats per row, see device_lib.h)
+    const float* gamma_q;     // Gamma(e, l) / Q[l] = (cmf_gamma[e][l] - cmf_gamma[e][l - 1]) / Q[l], the quotient gamma_ss evaluates (null: evaluated from
+                              // cmf_gamma and Q, the reference-order counting form)
+    const uint16_t* cmf_guide1;   // first-stage guide table: row e, bucket b of CMF_GUIDE1 = the first entry of row e above b / CMF_GUIDE1
     // sampler (SubspaceSampler)
     const LightVertex* lvc;
     const LightVertex* lvc_sorted;  // the same vertices in the sampler's order (record i = lvc[jump[i]]): the vertices of a light subspace
@@ -159,6 +163,9 @@ struct KParams {  // passed by value as the kernel argument block (the MyParams 
                                     // -- no read of `jump` in between (written by the sampler build, kernels.hip k_sb_scatter)
     const DSubspace* subspace;
     const float* cmfs;
+    const uint32_t* guide;          // second-stage guide table, one entry per light vertex: entry jump_bias + j of a subspace of n vertices = the
+                                    // first place k of its CMF with cmf[k] > (j / n)(1 - 2^-20) -- a lower bound of the bisection's answer for every
+                                    // random number u with (int)(u * n) == j (written by the sampler build next to the CMF)
     const int32_t* jump;
     const int32_t* sampler_counts;  // [0] vertex_count, [1] path_count (device-resident: no host round trip)
     int32_t uniform_lvc;            // != 0: "SPCBPT_eye" draws its light vertices with uniformSample (cuProg.h:283-289) = plain LVC-BDPT

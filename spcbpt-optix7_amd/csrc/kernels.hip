@@ -41,7 +41,20 @@ static constexpr int BLOCK = 256;
 #define SPC_JOINT_FIRST_STAGE 0   // 1 / 2: the first stages of a vertex's connections on one coarse fetch (below: measured, slower)
 #endif
 static constexpr int EYE_BLOCK = SPC_EYE_BLOCK;
+#ifndef SPC_POOL_SLOTS_IN_REGS
+// 1: the LVC slot and the pmf of a lane's three connections cross the traversal pass in the lane's own registers (i.e. in its scratch:
+// six more dwords of parked state) and are handed to the job loop in the xy of the ray slot, whose direction the pass no longer
+// needs -- instead of two 768-B arrays per wave in LDS, which become 96 more hot nodes per block.  Measured (profiles/r05_experiments.md,
+// section 24): the scratch costs +1.4 %, 115 instead of 19 hot nodes give back 0.4 %.
+#define SPC_POOL_SLOTS_IN_REGS 0
+#endif
+#if defined(SPC_EYE_HOT_OVERRIDE)
+static constexpr int EYE_HOT = SPC_EYE_HOT_OVERRIDE;   // (experiments)
+#elif SPC_POOL_SLOTS_IN_REGS
+static constexpr int EYE_HOT = HOT_NODES < 115 || SPC_EYE_BLOCK >= 512 ? HOT_NODES : 115;   // node records [0, EYE_HOT) live in LDS (256 threads: what 40 960 B leave)
+#else
 static constexpr int EYE_HOT = SPC_EYE_BLOCK >= 1024 ? 64 : (SPC_EYE_BLOCK >= 512 ? 38 : 19);   // node records [0, EYE_HOT) live in LDS
+#endif
 static_assert(EYE_HOT <= HOT_NODES, "the builder numbers HOT_NODES nodes first (layout.h)");
 static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
 static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye vertex through the traversal-stack LDS");
@@ -90,8 +103,10 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
     struct alignas(16) WavePool {
         float4 ray[POOL_RAYS];      // shadow ray it * 64 + lane: direction.xyz, length (< 0: none)
         float4 org[64];             // eye vertex of lane l: position.xyz (= origin of its shadow rays), lastNormalProjection
+#if !SPC_POOL_SLOTS_IN_REGS
         int32_t slot[POOL_RAYS];    // LVC slot of connection it * 64 + lane
         float pmf[POOL_RAYS];       // its resampling pmf (path_count * pmf2 * pmf1)
+#endif
         uint8_t job[POOL_RAYS];     // before the pass: slots that hold a ray; after it: the unoccluded connections, compacted
                                     // (the pass answers a shadow ray in the ray's own slot: an occluded pair's length becomes -1 = no ray)
         uint32_t next;              // pool cursor
@@ -106,8 +121,15 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
     // wave_in_block through readfirstlane: the per-wave LDS base below is then a wave-uniform value the compiler keeps in an SGPR
     const uint32_t lane = threadIdx.x & 63, wave_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WavePool* wp = s_pool + wave_in_block;
+#if SPC_POOL_SLOTS_IN_REGS
+    int32_t my_slot[SPCBPT_CONNECTION_N];   // LVC slot of this lane's connection `it` ...
+    float my_pmf[SPCBPT_CONNECTION_N];      // ... and its resampling pmf (path_count * pmf2 * pmf1)
+#pragma unroll
+    for (int it = 0; it < SPCBPT_CONNECTION_N; it++) { my_slot[it] = 0; my_pmf[it] = 1.0f; }
+#else
     int32_t* w_slot = wp->slot;
     float* w_pmf = wp->pmf;
+#endif
     uint8_t* w_job = wp->job;
     uint32_t* w_stack = s_stack + wave_in_block * 64;      // [entry * BLOCK + lane]: free between two traversal passes
     float4* w_ray = wp->ray;
@@ -233,6 +255,9 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                 if (live) {
                     w_job[n_jobs + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)(it * 64 + lane);
                     my_live |= 1u << it;
+#if SPC_POOL_SLOTS_IN_REGS
+                    w_ray[it * 64 + lane] = make_float4(__int_as_float(my_slot[it]), my_pmf[it], 0.0f, 0.0f);   // (the pass is over: the slot's direction is free)
+#endif
                 }
                 n_jobs += (uint32_t)__popcll(m);
             }
@@ -274,13 +299,20 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     const LightVertex* job_lvc = BATCH ? p.frames[ids >> 26].lvc_sorted : p.lvc_sorted;   // (w_slot holds the vertex's place in the sampler's order)
                     a.c.mat = (int)(col[15 * BLOCK] & 0xffffu); a.lsub = (int)(col[15 * BLOCK] >> 16);
                     LightVertex b;
+#if SPC_POOL_SLOTS_IN_REGS
+                    const float4 sp = w_ray[slot];
+                    const float4* src = reinterpret_cast<const float4*>(job_lvc + __float_as_int(sp.x));
+                    const float job_pmf = sp.y;
+#else
                     const float4* src = reinterpret_cast<const float4*>(job_lvc + w_slot[slot]);
+                    const float job_pmf = w_pmf[slot];
+#endif
                     float4* dst = reinterpret_cast<float4*>(&b);
 #pragma unroll
                     for (int q = 0; q < 6; q++) dst[q] = src[q];
                     f3 res = connect_vertices<COUNT, CACHE, ENV>(p, a, b, cn);
                     if (is_invalid(res)) res = mk3(0.0f);
-                    res = res / w_pmf[slot];
+                    res = res / job_pmf;
                     const bool ok = !is_invalid(res);
                     res = res / (float)SPCBPT_CONNECTION_N;
                     w_ray[slot] = make_float4(res.x, res.y, res.z, ok ? 1.0f : 0.0f);
@@ -558,11 +590,19 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                         const int lslot = lslot_[it];
                         float4 rq = make_float4(0.f, 0.f, 0.f, -1.0f);
                         if (lslot >= 0) {
+#if SPC_POOL_SLOTS_IN_REGS
+                            my_slot[it] = lslot;
+#else
                             w_slot[it * 64 + lane] = lslot;
+#endif
                             cn.add(C_CONN);
                             const float4 bq0 = reinterpret_cast<const float4*>(f_lvc + lslot)[0];
                             const float4 bq1 = reinterpret_cast<const float4*>(f_lvc + lslot)[1];
+#if SPC_POOL_SLOTS_IN_REGS
+                            my_pmf[it] = (float)f_path_count * pmf2 * pmf1;
+#else
                             w_pmf[it * 64 + lane] = (float)f_path_count * pmf2 * pmf1;
+#endif
                             // a light vertex that is a DIRECTION of the environment map (only scenes with one pay the flag fetch):
                             // visibilityTest shoots from the eye vertex to eye - 10 r n_b (cuProg.h:489-495)
                             const bool b_dir = ENV && (f_lvc[lslot].pad & SPCBPT_LV_DIRECTION) != 0u;

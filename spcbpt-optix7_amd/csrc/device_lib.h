@@ -1255,12 +1255,15 @@ SPC_DEV void sample_first_stage_n(const float* cmf_gamma2, int eye_subspace, con
 #ifndef SPC_GUIDE
 #define SPC_GUIDE 1
 #endif
+#ifndef SPC_GUIDE_WINDOW
+#define SPC_GUIDE_WINDOW 8   // 4: windows of one 16-B load (fewer values read, more often a second round trip: measured, section 25)
+#endif
 struct GuideScan { int cnt; float lo, hi; };   // entries <= u so far; the largest of them; the smallest entry > u
 // the entries at places [pos, pos + 8) of an array, of which [first, end) take part
 SPC_DEV void guide_window(float4 q0, float4 q1, int pos, int first, int end, float u, GuideScan& s) {
     const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < SPC_GUIDE_WINDOW; i++) {
         const bool in = pos + i >= first && pos + i < end;
         const bool le = in && v[i] <= u, gt = in && !(v[i] <= u);
         s.cnt += le ? 1 : 0;
@@ -1276,9 +1279,9 @@ SPC_DEV int sample_first_stage_guided(const float* cmf_gamma2, const uint16_t* g
     GuideScan s = {c0, -INFINITY, INFINITY};
     int pos = c0 & ~3, windows = 0;
     do {
-        const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = *reinterpret_cast<const float4*>(fine + pos + 4);
+        const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = SPC_GUIDE_WINDOW == 8 ? *reinterpret_cast<const float4*>(fine + pos + 4) : q0;
         guide_window(q0, q1, pos, c0, CMF2_FINE, u, s);
-        pos += 8; windows++;
+        pos += SPC_GUIDE_WINDOW; windows++;
     } while (!(s.hi < INFINITY) && pos < CMF2_FINE);
     l = s.cnt;
     pmf = l == 0 ? s.hi : s.hi - s.lo;
@@ -1298,9 +1301,9 @@ SPC_DEV void sample_first_stage_guided_n(const float* cmf_gamma2, const uint16_t
         int pos = c0 & ~3;
         windows[i] = 0;
         do {
-            const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = *reinterpret_cast<const float4*>(fine + pos + 4);
+            const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = SPC_GUIDE_WINDOW == 8 ? *reinterpret_cast<const float4*>(fine + pos + 4) : q0;
             guide_window(q0, q1, pos, c0, CMF2_FINE, u[i], s);
-            pos += 8; windows[i]++;
+            pos += SPC_GUIDE_WINDOW; windows[i]++;
         } while (!(s.hi < INFINITY) && pos < CMF2_FINE);
         l[i] = s.cnt;
         pmf[i] = s.cnt == 0 ? s.hi : s.hi - s.lo;
@@ -1325,7 +1328,7 @@ SPC_DEV int sample_first_stage(const KParams& p, int eye_subspace, uint32_t& see
 #if SPC_GUIDE
     const int windows = sample_first_stage_guided(p.cmf_gamma2, p.cmf_guide1, eye_subspace, u[0], l[0], pm[0]);
     pmf = pm[0];
-    if (COUNT) cn.add(C_CMF, EXEC ? 1u + 8u * (unsigned)windows : (unsigned)bisection_probes(l[0], SPCBPT_NUM_SUBSPACE));
+    if (COUNT) cn.add(C_CMF, EXEC ? 1u + (unsigned)SPC_GUIDE_WINDOW * (unsigned)windows : (unsigned)bisection_probes(l[0], SPCBPT_NUM_SUBSPACE));
 #else
     sample_first_stage_n<1>(p.cmf_gamma2, eye_subspace, u, l, pm);
     pmf = pm[0];

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                                 pmf1_[it] = pm[it];
                                 if (ss[it].size != 0) { bias_[it] = ss[it].jump_bias; size_[it] = ss[it].size; u2_[it] = u2[it]; }
 #if SPC_GUIDE
-                                if (COUNT) cn.add(C_CMF, CACHE ? 1u + 8u * (unsigned)windows[it] : (unsigned)bisection_probes(l[it], SPCBPT_NUM_SUBSPACE));
+                                if (COUNT) cn.add(C_CMF, CACHE ? 1u + (unsigned)SPC_GUIDE_WINDOW * (unsigned)windows[it] : (unsigned)bisection_probes(l[it], SPCBPT_NUM_SUBSPACE));
 #else
                                 if (COUNT) cn.add(C_CMF, CACHE ? (it == 0 ? 32u : 16u) : (unsigned)bisection_probes(l[it], SPCBPT_NUM_SUBSPACE));
 #endif
@@ -488,10 +488,10 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                         for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                             while (open_[it]) {
                                 const float4 a = *reinterpret_cast<const float4*>(f_cmfs + pos_[it]);
-                                const float4 b = *reinterpret_cast<const float4*>(f_cmfs + pos_[it] + 4);
-                                if (COUNT && CACHE) cn.add(C_CMF, 8);
+                                const float4 b = SPC_GUIDE_WINDOW == 8 ? *reinterpret_cast<const float4*>(f_cmfs + pos_[it] + 4) : a;
+                                if (COUNT && CACHE) cn.add(C_CMF, SPC_GUIDE_WINDOW);
                                 guide_window(a, b, pos_[it], first_[it], bias_[it] + size_[it], u2_[it], s_[it]);
-                                pos_[it] += 8;
+                                pos_[it] += SPC_GUIDE_WINDOW;
                                 open_[it] = !(s_[it].hi < INFINITY) && pos_[it] < bias_[it] + size_[it];
                             }
                         }

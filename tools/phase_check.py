@@ -14,7 +14,7 @@ r.set_light_trace(100000, 52, 1)
 r.set_subspace()
 if "--trained" in sys.argv: r.preprocess(2000000, 2000000, True)
 r.render_frame("SPCBPT_eye", 0)
-r.enable_counters(True); r.reset_counters()
+r.enable_counters(2 if "--executed" in sys.argv else True); r.reset_counters()
 r.launch("SPCBPT_eye", 1)
 r.sync()
 ph = r.phase_clocks()
@@ -33,3 +33,6 @@ if ph["waves"]:
     total = (ph["wave_end_max"] - ph["wave_start_min"]) / 100.0   # microseconds
     mean_end = (ph["wave_end_sum"] / ph["waves"] - ph["wave_start_min"]) / 100.0
     print(f"waves {ph['waves']}: kernel span {total:.0f} us, mean wave end at {mean_end:.0f} us -> the average wave idles {100 * (1 - mean_end / total):.1f} % of the span")
+print("connect job loop: lane utilisation", round(ph["job_lanes"] / max(1, ph["job_slots"]), 3), "jobs per wave-round", ph["job_lanes"] / max(1, ph["job_slots"] // 64),
+      "rounds", ph["job_slots"] // 64, "connections", cnt["connections"])
+print("phase wave-clocks per wave-iteration-ish: shade", ph["shade"], "connect", ph["connect"], "pool", ph["shadow_pool"])

@@ -1104,34 +1104,36 @@ SPC_DEV int tree_label(const float* tree, f3 position, f3 normal, f3 dir, Counts
 // Two independent classifications descended in lock-step: a descent is a chain of dependent fetches (one per level, up to 15
 // levels), and the callers below always need two of them (eye-tree label of a new vertex + light-tree label for its RMIS
 // recursion; the two relabels of a connection).  Interleaving halves the exposed latency; the labels are the same.
-template <bool COUNT>
+// The step is written without branches (selects on `go`): as nested ifs it compiled to ~45 scalar instructions of EXEC bookkeeping per
+// iteration next to its ~45 vector ones, and a vertex's pair of descents -- the wave goes round until its deepest lane is done, ~13
+// times -- was 4.7 % of the megakernel (profiles/r05_experiments.md, sections 27-28).  NODIR: the caller's trees hold no direction
+// nodes (the label-caching kernels: Context::tree_has_direction sends every other tree to the generic instantiations), so the
+// split point is compared with the position or the normal only.
+template <bool COUNT, bool NODIR = false>
 SPC_DEV void tree_label2(const float* treeA, f3 posA, f3 nA, f3 dirA, bool needA, const float* treeB, f3 posB, f3 nB, f3 dirB, bool needB,
                          int& labelA, int& labelB, Counts<COUNT>& cn) {
     int nodeA = 0, nodeB = 0;
     bool goA = needA && treeA != nullptr, goB = needB && treeB != nullptr;
     labelA = 0; labelB = 0;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;   // (a lane that is done keeps its last record: the selects below ignore it)
     while (goA || goB) {
-        float4 a, b;
         if (goA) { a = ldq(treeA, (size_t)nodeA); cn.add(C_TREE); }
         if (goB) { b = ldq(treeB, (size_t)nodeB); cn.add(C_TREE); }
-        if (goA) {
-            const uint32_t meta = __float_as_uint(a.w);
-            if (meta & TREE_LEAF_BIT) { labelA = (int)(meta & ~TREE_LEAF_BIT); goA = false; }
-            else {
-                const uint32_t type = (meta >> 29) & 3u;
-                const f3 p = type == 0 ? posA : (type == 1 ? nA : dirA);
-                nodeA = (int)(meta & 0x1fffffffu) + (p.x > a.x ? 1 : 0) + (p.y > a.y ? 2 : 0) + (p.z > a.z ? 4 : 0);
-            }
+#define SPC_TREE_STEP__(q, pos, nrm, dir, node, label, go)                                                              \
+        {                                                                                                             \
+            const uint32_t meta = __float_as_uint(q.w);                                                               \
+            const bool leaf = (meta & TREE_LEAF_BIT) != 0u;                                                           \
+            const uint32_t type = (meta >> 29) & 3u;                                                                  \
+            const f3 p = NODIR ? mk3(type != 0u ? nrm.x : pos.x, type != 0u ? nrm.y : pos.y, type != 0u ? nrm.z : pos.z)  \
+                               : (type == 0u ? pos : (type == 1u ? nrm : dir));                                       \
+            const int next = (int)(meta & 0x1fffffffu) + (p.x > q.x ? 1 : 0) + (p.y > q.y ? 2 : 0) + (p.z > q.z ? 4 : 0);   \
+            label = (go && leaf) ? (int)(meta & ~TREE_LEAF_BIT) : label;                                              \
+            node = (go && !leaf) ? next : node;                                                                       \
+            go = go && !leaf;                                                                                         \
         }
-        if (goB) {
-            const uint32_t meta = __float_as_uint(b.w);
-            if (meta & TREE_LEAF_BIT) { labelB = (int)(meta & ~TREE_LEAF_BIT); goB = false; }
-            else {
-                const uint32_t type = (meta >> 29) & 3u;
-                const f3 p = type == 0 ? posB : (type == 1 ? nB : dirB);
-                nodeB = (int)(meta & 0x1fffffffu) + (p.x > b.x ? 1 : 0) + (p.y > b.y ? 2 : 0) + (p.z > b.z ? 4 : 0);
-            }
-        }
+        SPC_TREE_STEP__(a, posA, nA, dirA, nodeA, labelA, goA)
+        SPC_TREE_STEP__(b, posB, nB, dirB, nodeB, labelB, goB)
+#undef SPC_TREE_STEP__
     }
 }
 

@@ -41,7 +41,7 @@ SPC_DEV void eye_surface_hit(const KParams& p, const Geom& g, float t_hit, f3 ra
     int light_label;
     mid.lsub = 0;
     if (CACHE) {   // both labels of the NEW vertex (device_lib.h: label caching); the previous vertex brings its own
-        tree_label2(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, g.P, N, inv_dir, last.depth + 1 != 1, mid.sub, mid.lsub, cn);
+        tree_label2<COUNT, true>(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, g.P, N, inv_dir, last.depth + 1 != 1, mid.sub, mid.lsub, cn);
         light_label = last.lsub;
     } else {
         tree_label2(p.eye_tree, g.P, N, inv_dir, true, p.light_tree, last.c.pos, last.c.n, normalize(g.P - last.c.pos),

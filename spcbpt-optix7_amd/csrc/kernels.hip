@@ -928,7 +928,7 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams 
                     uint32_t own_eye_label = 0u;   // device_lib.h: label caching -- the new vertex's own eye-tree label + 1
                     if (CACHE) {
                         int own;
-                        tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, g.P, N, inv_dir, true, new_label, own, cn);
+                        tree_label2<COUNT, true>(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, g.P, N, inv_dir, true, new_label, own, cn);
                         own_eye_label = (uint32_t)own + 1u;
                         eye_label = (int)(last.pad & 0xffffu) - 1;   // the previous vertex's, cached when it was created (unused when it is the origin)
                     } else {

@@ -384,7 +384,7 @@ int spcbpt_set_connection_sampler(spcbpt_ctx* ctx, int mode);
  *   SPCBPT_UNIT_BSDF     in 24: material(base3, metallic, roughness, specular, specular_tint, subsurface, sheen, sheen_tint, clearcoat,
  *                        clearcoat_gloss) N3 V3 L3 seed pad2        out 12: Sample(N,V;seed)3, seed', Eval(N,V,L)3, Pdf(N,V,L), Eval(N,V,Ls)3, Pdf(N,V,Ls)
  *   SPCBPT_UNIT_TREE     in 10: tree(0 eye, 1 light) position3 normal3 direction3                      out 1: label
- *   SPCBPT_UNIT_STAGE1   in 2: eye subspace, seed        out 6: l, pmf, seed' as the kernels sample (counting passes) ; l, pmf, seed' by binary_sample
+ *   SPCBPT_UNIT_STAGE1   in 2: eye subspace, seed        out 6: l, pmf, seed' as the kernels sample (guide table + window) ; l, pmf, seed' by binary_sample
  *   SPCBPT_UNIT_BSEARCH  in 3: offset, size, seed (CMF = aux + offset)                                  out 3: bin, pmf, seed'
  *   SPCBPT_UNIT_STAGE2   in 2: light subspace, seed                                                     out 5: size, bin (-1: empty), LVC slot, pmf, seed'
  *   SPCBPT_UNIT_UNIFORM  in 1: seed                                                                     out 3: LVC slot, pmf, seed'
@@ -415,7 +415,8 @@ int spcbpt_debug_trace_bench(spcbpt_ctx* ctx, const float* rays, int n, int mode
 /* Event counting in the kernels (off for timed runs).  1: the counting instantiations evaluate in the REFERENCE's order and charge
  * its events (two relabels per connection and one per RMIS update, a ten-probe bisection per first sampling stage): the contract's
  * byte table of SURVEY.md 8(d).  2: the instantiations the timed runs use, with counters -- the events that really execute (labels
- * cached per vertex; 16 + 8 + 8 CMF values per first stage): what the roofline fraction is computed from. */
+ * cached per vertex; one guide entry + eight CMF values per window of either resampling stage, one Gamma / Q value per
+ * evaluation): what the roofline fraction is computed from. */
 int spcbpt_enable_counters(spcbpt_ctx* ctx, int enabled);
 
 /* Streams.  A context owns two non-blocking HIP streams: the one returned here (hipStream_t as void*) carries "light trace",

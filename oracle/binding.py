@@ -209,7 +209,7 @@ class Oracle:
 
     def set_count_as_executed(self, on):
         """Test knob, counters only: charge the classification and first-stage-sampling events the product's timed kernels execute
-        (labels cached per vertex, two counting passes per first stage) instead of the reference's."""
+        (labels cached per vertex, guide table + windows per resampling stage, one Gamma / Q read) instead of the reference's."""
         self.l.orc_set_count_as_executed(self.h, int(on))
 
     def enable_counters(self, on):

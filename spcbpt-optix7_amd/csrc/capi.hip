@@ -448,7 +448,7 @@ int Context::launch_light(uint32_t frame) {
     // write the set the eye pass is NOT reading; it was last read by the render launch before the previous one
     lset = (lset + 1) % n_sets;
     select_set(lset);
-    if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[lset], 0));
+    if (ev_render_set[lset]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[render_event_of[lset]], 0));
     // ... and a sampler build or an import copy of the set's previous contents may still be queued on `stream` (a set that was
     // built or imported but never rendered carries no fresh ev_render): the second lane does not run in `stream`'s order
     if (ls != stream) {
@@ -581,10 +581,14 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
     kp.counters = counting ? d_counters : nullptr;
     CompactBatch dst = {};
     int sets[kMaxBatchFrames];
+    int waited_for = -1;
     for (int k = 0; k < n; k++) {   // what launch_light waits for before it rewrites a set, for every set of the batch
         const int s = (lset + 1 + k) % n_sets;
         sets[k] = s;
-        if (ev_render_set[s]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[s], 0));
+        if (ev_render_set[s] && render_event_of[s] != waited_for) {   // (the sets of one batched eye launch share one event)
+            HIP_TRY(this, hipStreamWaitEvent(ls, ev_render[render_event_of[s]], 0));
+            waited_for = render_event_of[s];
+        }
         if (ev_set_touched[s]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_set_stream[s], 0));
         if (ev_exch_set[s]) HIP_TRY(this, hipStreamWaitEvent(ls, ev_exch[s], 0));
         set_bound[s] = -1;
@@ -919,6 +923,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
         launch_spcbpt_no_rmis(kp, rstream);
         time_end();
         HIP_TRY(this, hipGetLastError());
+        render_event_of[eset] = eset;
         HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
         ev_render_set[eset] = true;
         return finish_frame();
@@ -958,6 +963,7 @@ int Context::launch_render(const char* name, bool spcbpt_alg, uint32_t frame, in
     time_end();
     HIP_TRY(this, hipGetLastError());
     if (spcbpt_alg) {
+        render_event_of[eset] = eset;
         HIP_TRY(this, hipEventRecord(ev_render[eset], rstream));
         ev_render_set[eset] = true;
     }
@@ -1047,7 +1053,8 @@ int Context::launch_eye_batch(int n, const uint32_t* subframes, int r0, int r1, 
     launch_spcbpt_batch(kp, max_blocks, rstream);
     time_end();
     HIP_TRY(this, hipGetLastError());
-    for (int k = 0; k < n; k++) { HIP_TRY(this, hipEventRecord(ev_render[sets[k]], rstream)); ev_render_set[sets[k]] = true; }
+    HIP_TRY(this, hipEventRecord(ev_render[sets[n - 1]], rstream));   // ONE event for the sets of the batch (context.h: render_event_of)
+    for (int k = 0; k < n; k++) { render_event_of[sets[k]] = sets[n - 1]; ev_render_set[sets[k]] = true; }
     eset = sets[n - 1];
     // the frames' merges, in frame order, after the previous launch's merge
     if (last_merge_k >= 0 && last_merge_k != rk && rstreams[last_merge_k] != rstream) HIP_TRY(this, hipStreamWaitEvent(rstream, ev_merge[last_merge_k], 0));

@@ -339,8 +339,14 @@ def main():
                 n = max(1, min(batch, state["phase_left"]))
                 light_batch(n); state["lb_left"] = n
                 if comm is not None and xbatch:
-                    # ... and exchanges the n OLDEST pending passes (launched a batch ago) as ONE all-gather + one compaction
-                    comm.exchange_lvc_batch(n)
+                    # ... and exchanges the n OLDEST pending passes (launched a batch ago) as ONE all-gather + one compaction --
+                    # unless that exchange was queued a batch ahead, behind the previous eye launch (build_ahead below)
+                    if state["exchanged"] == n:
+                        state["exchanged"] = 0
+                    elif state["exchanged"] == 0:
+                        comm.exchange_lvc_batch(n)
+                    else:
+                        raise SystemExit(f"bench loop: {state['exchanged']} passes were exchanged ahead for a batch of {n}")
             state["lb_left"] -= 1; state["phase_left"] -= 1
         else:
             if not state["primed"]:
@@ -379,8 +385,18 @@ def main():
     # launched at this batch's first step, a batch ago by the time they are needed -- so that they run under the eye kernel that does
     # not need them instead of between two eye kernels.  Every step still has its one build (of a later frame, like its light pass);
     # spcbpt_launch_eye_batch renders the samplers of the last n builds, in build order, so the frames keep their passes.
-    build_ahead = bbatch and comm is None and ex is None and hasattr(r.lib, "spcbpt_get_pipeline_state") and args.build_ahead != 0
+    # A sharded job does the same with its exchange: the all-gather of the next launch's light passes and the builds over the gathered
+    # caches are queued behind this eye launch (every rank runs this same sequence of calls, so the collectives keep their order).
+    build_ahead = bbatch and ex is None and (comm is None or xbatch) and hasattr(r.lib, "spcbpt_get_pipeline_state") and args.build_ahead != 0
     state["prebuilt"] = 0
+    state["exchanged"] = 0
+
+    def build_next(n):
+        if comm is not None:
+            comm.exchange_lvc_batch(n)
+            state["exchanged"] = n
+        r.build_sampler_batch(n)
+        state["prebuilt"] = n
 
     def flush(isolate=False, ahead_at_end=False):
         if queued:
@@ -403,16 +419,14 @@ def main():
                 pend = r.pipeline_state()["pending_passes"]
                 n_next = min(batch, state["phase_left"]) if state["phase_left"] > 0 else min(batch, pend)
                 if 0 < n_next <= pend:
-                    r.build_sampler_batch(n_next)
-                    state["prebuilt"] = n_next
+                    build_next(n_next)
 
     def prebuild_first_batch(steps):
         """The samplers of a phase's first eye launch, built under the phase before it (its light passes were traced there too)."""
         if build_ahead and state["prebuilt"] == 0 and not queued:
             n = min(batch, steps)
             if 0 < n <= r.pipeline_state()["pending_passes"]:
-                r.build_sampler_batch(n)
-                state["prebuilt"] = n
+                build_next(n)
 
     def barrier():
         if dist is not None:

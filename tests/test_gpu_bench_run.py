@@ -39,3 +39,18 @@ def test_bench_line(gpu, args):
     assert d["config"]["workload"] and d["dtype"] == "f32" and d["data"] == "synthetic"
     ev = d["events_per_eye_path"]
     assert ev["closest_rays"] >= 1.0 and ev["node_visits"] > 1.0
+
+
+def test_forced_exchange_renders_the_same_film_with_and_without_builds_ahead(gpu, tmp_path):
+    """The sharded job's loop (RCCL path at world size 1): exchanging and building a batch ahead changes when the calls are queued,
+    not what any frame is rendered from."""
+    import numpy as np
+    films = []
+    for ahead in ("1", "0"):
+        out = str(tmp_path / f"film_{ahead}.npy")
+        d = _run(["--steps", "20", "--warmup", "5", "--long-steps", "40", "--sync-each-frames", "0", "--force-exchange", "--build-ahead", ahead,
+                  "--write-image", out])
+        assert d["config"]["sampler_builds_ahead"] == (20 if ahead == "1" else 0)
+        films.append(np.load(out))
+    assert films[0].shape == films[1].shape and np.isfinite(films[0]).all() and films[0][..., :3].mean() > 0.01
+    assert np.array_equal(films[0], films[1])

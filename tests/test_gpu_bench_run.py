@@ -28,7 +28,8 @@ def _run(args):
     ["--steps", "33", "--warmup", "3", "--long-steps", "34", "--sync-each-frames", "0", "--build-ahead", "0"],
     ["--steps", "4", "--warmup", "1", "--long-steps", "0", "--sync-each-frames", "0", "--eye-batch", "1"],   # one eye launch per frame
     ["--steps", "6", "--warmup", "2", "--long-steps", "0", "--sync-each-frames", "0", "--force-exchange"],   # the RCCL path at world size 1
-], ids=["driver-form", "all-passes", "uneven-launches", "no-build-ahead", "unbatched", "forced-exchange"])
+    ["--steps", "33", "--warmup", "3", "--long-steps", "40", "--sync-each-frames", "0", "--force-exchange"],  # ... with uneven launches, exchanges a batch ahead
+], ids=["driver-form", "all-passes", "uneven-launches", "no-build-ahead", "unbatched", "forced-exchange", "forced-exchange-uneven"])
 def test_bench_line(gpu, args):
     d = _run(args)
     steps = int(args[args.index("--steps") + 1])

@@ -1261,12 +1261,16 @@ SPC_DEV void sample_first_stage_n(const float* cmf_gamma2, int eye_subspace, con
 #define SPC_GUIDE_WINDOW 8   // 4: windows of one 16-B load (fewer values read, more often a second round trip: measured, section 25)
 #endif
 struct GuideScan { int cnt; float lo, hi; };   // entries <= u so far; the largest of them; the smallest entry > u
-// the entries at places [pos, pos + 8) of an array, of which [first, end) take part
+// the entries at places [pos, pos + 8) of an array, of which [first, end) take part.  first - pos <= 3 (pos is first rounded down to a
+// quad, or a later window), so only the first three entries can lie in front of it.  RANGE = false: every entry takes part (the
+// first stage: a row of its own, padded with 2.0 -- the entries in front of the guide's place are <= u like the one it names, so the
+// caller counts from the window's start instead of masking them).
+template <bool RANGE = true>
 SPC_DEV void guide_window(float4 q0, float4 q1, int pos, int first, int end, float u, GuideScan& s) {
     const float v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
     for (int i = 0; i < SPC_GUIDE_WINDOW; i++) {
-        const bool in = pos + i >= first && pos + i < end;
+        const bool in = !RANGE || ((i >= 3 || pos + i >= first) && pos + i < end);
         const bool le = in && v[i] <= u, gt = in && !(v[i] <= u);
         s.cnt += le ? 1 : 0;
         s.lo = fmaxf(s.lo, le ? v[i] : -INFINITY);
@@ -1278,11 +1282,11 @@ SPC_DEV int sample_first_stage_guided(const float* cmf_gamma2, const uint16_t* g
     const float* fine = cmf_gamma2 + (size_t)eye_subspace * CMF2_ROW + CMF2_COARSE + CMF2_MID;   // 1000 entries, 2.0 up to CMF2_FINE
     const int g = guide1[(size_t)eye_subspace * CMF_GUIDE1 + (int)(u * (float)CMF_GUIDE1)];
     const int c0 = max(g - 1, 0);
-    GuideScan s = {c0, -INFINITY, INFINITY};
     int pos = c0 & ~3, windows = 0;
+    GuideScan s = {pos, -INFINITY, INFINITY};   // (the entries of the first quad in front of c0 are counted with it: all <= u)
     do {
         const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = SPC_GUIDE_WINDOW == 8 ? *reinterpret_cast<const float4*>(fine + pos + 4) : q0;
-        guide_window(q0, q1, pos, c0, CMF2_FINE, u, s);
+        guide_window<false>(q0, q1, pos, c0, CMF2_FINE, u, s);
         pos += SPC_GUIDE_WINDOW; windows++;
     } while (!(s.hi < INFINITY) && pos < CMF2_FINE);
     l = s.cnt;
@@ -1299,12 +1303,12 @@ SPC_DEV void sample_first_stage_guided_n(const float* cmf_gamma2, const uint16_t
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int c0 = max(g[i] - 1, 0);
-        GuideScan s = {c0, -INFINITY, INFINITY};
         int pos = c0 & ~3;
+        GuideScan s = {pos, -INFINITY, INFINITY};
         windows[i] = 0;
         do {
             const float4 q0 = *reinterpret_cast<const float4*>(fine + pos), q1 = SPC_GUIDE_WINDOW == 8 ? *reinterpret_cast<const float4*>(fine + pos + 4) : q0;
-            guide_window(q0, q1, pos, c0, CMF2_FINE, u[i], s);
+            guide_window<false>(q0, q1, pos, c0, CMF2_FINE, u[i], s);
             pos += SPC_GUIDE_WINDOW; windows[i]++;
         } while (!(s.hi < INFINITY) && pos < CMF2_FINE);
         l[i] = s.cnt;

@@ -439,7 +439,8 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                     }
                     }
 #if SPC_GUIDE
-                    if (f_guide) {   // binary_sample (cuProg.h:245-264) of the three through the guide table (device_lib.h: guide_window), side by side
+                    {   // binary_sample (cuProg.h:245-264) of the three through the guide table (device_lib.h: guide_window); every sampler build
+                        // writes one (capi.hip: set_guide is allocated with the CMF), so there is no bisection beside it in this build
                         GuideScan s_[SPCBPT_CONNECTION_N];
                         int pos_[SPCBPT_CONNECTION_N], first_[SPCBPT_CONNECTION_N];
                         bool open_[SPCBPT_CONNECTION_N];
@@ -511,8 +512,8 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                                 if (COUNT && !CACHE) cn.add(C_CMF, (unsigned)bisection_probes(k, size_[it]));
                             }
                         }
-                    } else
-#endif
+                    }
+#else
                     {   // binary_sample (cuProg.h:245-264) of the three, level by level
                         int lo_[SPCBPT_CONNECTION_N], hi_[SPCBPT_CONNECTION_N], mid_[SPCBPT_CONNECTION_N];
 #if SPC_SECOND_STAGE_ARY == 4
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
                             }
                         }
                     }
+#endif
 #pragma unroll
                     for (int it = 0; it < SPCBPT_CONNECTION_N; it++) {
                         const float pmf1 = pmf1_[it], pmf2 = pmf2_[it];

@@ -27,8 +27,8 @@ ARGS = "EEEvNS_7KParamsE"
 # <COUNT, BATCH, CACHE, ENV>: the timed forms (COUNT = false, CACHE = true)
 TIMED = {"single frame, plain scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS, "batched, plain scene (bench.py)": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS,
          "single frame, general scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS, "batched, general scene": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS}
-PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 14696, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13836,
-                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 16693, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 16029}   # profiles/r05g_* (r05h: within 0.2 %)
+PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 14226, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13418,
+                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 16281, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 15613}   # profiles/r05i_*
 
 
 def _traversal_loops(lines, quad=False, fan=False):

@@ -95,11 +95,38 @@ def spawn_ranks(n: int, argv, script: str = None, out=None) -> int:
     return rc
 
 
+def host_cpus():
+    """The CPUs this process can really run on: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU quota
+    (v2 `cpu.max`, v1 `cpu.cfs_quota_us`).  A one-GPU box of the pool shows all 256 hardware threads of its host in os.cpu_count() but
+    is given a 16-CPU share of them: 256 oracle threads then run like 11, and a baseline labelled "256 cores" misleads (round-5 review)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.999)))
+    return max(1, n)
+
+
 def cpu_baseline(pkg, scene, args, tup):
     """The oracle (scalar CPU restatement, `kind: port`) timed on this host's cores on a bounded sample of the same
     workload: the full light pass + sampler build + every `stride`-th band of the eye pass."""
     from oracle import binding as ob
-    threads = os.cpu_count() or 1
+    threads = args.cpu_threads if args.cpu_threads > 0 else host_cpus()
     o = ob.Oracle(scene, nthreads=threads)
     cam = scene.camera
     o.set_camera_lookat(cam["eye"], cam["lookat"], cam["up"], cam["fov"], args.width / args.height)
@@ -119,7 +146,7 @@ def cpu_baseline(pkg, scene, args, tup):
         frames += 1
         dt = time.perf_counter() - t0
     paths = frames * (rows * args.width + args.light_paths)
-    out = {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+    out = {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "host_cpus_visible": os.cpu_count(), "kind": "port",
            "sample": f"{frames} subframe(s): {args.light_paths} light paths + sampler build + eye pass on every {stride}-th 8-row "
                      f"band ({rows * args.width} eye paths) each, {dt:.1f} s with {threads} threads"}
     # (i) of SURVEY 8(d): the same port on ONE thread.  A whole subframe would take minutes, so its two halves are sampled and put
@@ -143,7 +170,29 @@ def cpu_baseline(pkg, scene, args, tup):
         out["single_thread"] = {"value": (args.width * args.height + args.light_paths) / t_frame / 1e6, "unit": "Mpaths/s", "cores": 1, "kind": "port",
                                 "sample": f"eye pass on every {s1}-th band ({rows1 * args.width} eye paths, {t_eye:.1f} s) + 1/{frac} of the light pass's cores with "
                                           f"their sampler build ({t_light:.1f} s), scaled to one whole subframe ({t_frame:.0f} s)"}
+        out["speedup_over_single_thread"] = round(out["value"] / out["single_thread"]["value"], 2)
     return out
+
+
+def fast_math_line(pkg, args):
+    """A SECOND line, never `value`: the same command on the opt-in approximate-arithmetic library (libspcbpt_hip_fast.so: hardware
+    reciprocal / square root like the reference's own --use_fast_math build; image-level bars of its own, tests/test_gpu_fast_build.py),
+    in a child interpreter (two libraries with the same exports cannot share a process), after this process's measurements are done."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+           "--fast-math-line", "0", "--sync-each-frames", "0", "--long-steps", "0", "--scene", args.scene, "--tris", str(args.tris),
+           "--width", str(args.width), "--height", str(args.height), "--light-paths", str(args.light_paths), "--tuple", args.tuple]
+    env = dict(os.environ, SPCBPT_LIB=pkg.api.FAST_LIB_PATH)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "kernel_ms": d["roofline"]["kernel_ms"],
+                "library": "libspcbpt_hip_fast.so", "arithmetic": "approx (v_rcp_f32 / v_sqrt_f32: -fno-hip-fp32-correctly-rounded-divide-sqrt)",
+                "note": "opt-in build, NOT the shipped default and not `value`: function-level parity and the film hashes are the IEEE build's"}
+    except Exception as e:   # the second line is optional: never let it take the contract's line down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def frames_per_launch(steps: int, max_batch: int = 32) -> int:
@@ -170,6 +219,8 @@ def main():
                     help="gltf: write the generated scene as glTF 2.0 and read it back with the C++ reader (default); memory: hand the arrays over directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--long-steps", type=int, default=256, help="steps of the extra steady-state run reported as ms_per_step_long (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = the CPUs this process can really use: host_cpus())")
+    ap.add_argument("--fast-math-line", type=int, default=1, help="1 (default, one GPU): report the same run on the opt-in approximate-arithmetic library as a second line (fast_math_build)")
     ap.add_argument("--sync-each-frames", type=int, default=16, help="frames of the extra pass in the reference's loop form -- one light pass, one build, one eye "
                     "launch and a device sync per frame (optixPathTracer.cpp:791-822) -- reported as ms_per_frame_sync_each (0 = skip)")
     ap.add_argument("--cpu-band-stride", type=int, default=0, help="0 = choose from the host core count (about 10-30 s of CPU work)")
@@ -708,6 +759,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pkg, scene, args, tup)
+        if args.fast_math_line and world == 1 and comm is None and ex is None and not os.environ.get("SPCBPT_LIB") and os.path.exists(pkg.api.FAST_LIB_PATH):
+            out["fast_math_build"] = fast_math_line(pkg, args)
     if comm is not None:
         comm.close()
     if dist is not None:

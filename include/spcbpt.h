@@ -356,6 +356,11 @@ int spcbpt_reset_counters(spcbpt_ctx* ctx);
 int spcbpt_debug_phase_clocks(spcbpt_ctx* ctx, uint64_t out[19]);
 /* Hash of the sources this library was built from (csrc/source_hash.py); the Python mirror refuses a stale library. */
 const char* spcbpt_build_source_hash(void);
+/* The FP32 arithmetic of this library's device code: "ieee" for libspcbpt_hip.so (correctly rounded division and square root,
+ * no contraction -- the oracle's operations; what every function-level parity test and the film hashes assume), "approx" for the
+ * opt-in libspcbpt_hip_fast.so (hardware reciprocal / square root, as the reference's own `--use_fast_math` build,
+ * src/CMakeLists.txt:214; image-level bars only: tests/test_gpu_fast_build.py). */
+const char* spcbpt_build_arithmetic(void);
 /* sizeof of the structs of this header as the library was COMPILED, in declaration order: material, texture, quad_light,
  * scene_desc, tree_node, light_trace_params, light_vertex, subspace, counters, unit_eye_vertex, pretrace_path,
  * pretrace_node, viewer_state.  A binding in another language (ctypes / cgo / JNI) checks its mirrors against these instead of

@@ -144,9 +144,14 @@ int orc_launch(orc_ctx* c, const char* name, unsigned frame, int row_begin, int 
             if (((y / 8) - (row_begin / 8)) % row_step == 0) rows.push_back(y);
         bool spc = alg == "SPCBPT_eye", full_mis = alg == "SPCBPT_no_rmis";
         make_views();
-        parallel_for((int)rows.size(), nthreads, [&](int i, int t) {
-            unsigned y = (unsigned)rows[i];
-            for (unsigned x = 0; x < c->P.width; x++) {
+        // work items of the dynamic queue: 8-pixel-wide pieces of a row (the rows of a band are consecutive in `rows`, so the items of
+        // a band's 8 x 8 tiles are neighbours in the queue).  Whole rows -- 1 080 items for 256 threads -- left the last threads of a
+        // frame idle for a fifth of it; pixels are independent, so the image does not depend on the split (test_thread_count_invariance).
+        const int xt = ((int)c->P.width + 7) / 8;
+        parallel_for((int)rows.size() * xt, nthreads, [&](int i, int t) {
+            const unsigned y = (unsigned)rows[i / xt];
+            const unsigned x0 = (unsigned)(i % xt) * 8u, x1 = std::min(x0 + 8u, c->P.width);
+            for (unsigned x = x0; x < x1; x++) {
                 if (spc) raygen_SPCBPT(tp[t], x, y);
                 else if (full_mis) raygen_SPCBPT_no_rmis(tp[t], x, y);
                 else raygen_pinhole(tp[t], x, y);

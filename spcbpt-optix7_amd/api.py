@@ -21,6 +21,9 @@ CONNECTION_N = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libspcbpt_hip.so")
+# the opt-in approximate-arithmetic build of the same sources (csrc/Makefile: libspcbpt_hip_fast.so; spcbpt_build_arithmetic() == "approx").
+# A process picks it with SPCBPT_LIB=<this path> before the first load_library(); never the default.
+FAST_LIB_PATH = os.path.join(_HERE, "csrc", "libspcbpt_hip_fast.so")
 
 
 class Material(C.Structure):
@@ -474,7 +477,7 @@ def load_library(path: str = LIB_PATH):
         built = lib.spcbpt_build_source_hash().decode()
     except AttributeError:
         built = "none"
-    if path == LIB_PATH and built != source_hash() and not os.environ.get("SPCBPT_ALLOW_STALE_LIB"):
+    if path in (LIB_PATH, FAST_LIB_PATH) and built != source_hash() and not os.environ.get("SPCBPT_ALLOW_STALE_LIB"):
         raise SpcbptError(f"{path} was built from other sources (library {built}, tree {source_hash()}): run `make -C spcbpt-optix7_amd/csrc`")
     vp, i32, u32, f32p = C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_float)
     sig = {
@@ -573,6 +576,7 @@ def load_library(path: str = LIB_PATH):
     lib.spcbpt_viewer_alg_name.restype = C.c_char_p
     lib.spcbpt_last_error.argtypes = [vp]
     lib.spcbpt_last_error.restype = C.c_char_p
+    lib.spcbpt_build_arithmetic.restype = C.c_char_p
     lib.spcbpt_scene_file_warnings.argtypes = [vp]
     lib.spcbpt_scene_file_warnings.restype = C.c_char_p
     _lib = lib
@@ -585,7 +589,7 @@ EXPORTED_SYMBOLS = [
     "spcbpt_lvc_export", "spcbpt_lvc_import", "spcbpt_lvc_set_capacity", "spcbpt_lvc_get_capacity", "spcbpt_set_environment", "spcbpt_get_environment", "spcbpt_hdr_load", "spcbpt_lvc_read", "spcbpt_sampler_read", "spcbpt_read_accum",
     "spcbpt_read_frame", "spcbpt_accum_device_ptr", "spcbpt_clear_accum", "spcbpt_get_counters",
     "spcbpt_reset_counters", "spcbpt_debug_phase_clocks", "spcbpt_debug_spill_arm", "spcbpt_debug_spill_count", "spcbpt_set_connection_sampler", "spcbpt_debug_unit", "spcbpt_debug_trace_bench",
-    "spcbpt_build_source_hash", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_get_pipeline_state", "spcbpt_reuse_sampler", "spcbpt_read_film", "spcbpt_debug_batch_scratch", "spcbpt_debug_read_sampling_tables", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
+    "spcbpt_build_source_hash", "spcbpt_build_arithmetic", "spcbpt_abi_struct_sizes", "spcbpt_lvc_export_on", "spcbpt_lvc_import_gathered", "spcbpt_lvc_export_batch_on", "spcbpt_lvc_import_gathered_batch", "spcbpt_film_pack_bands", "spcbpt_film_unpack_bands", "spcbpt_image_size", "spcbpt_get_light_trace", "spcbpt_enable_counters", "spcbpt_stream", "spcbpt_sync", "spcbpt_sync_light", "spcbpt_launch_deferred", "spcbpt_merge_deferred", "spcbpt_sync_film", "spcbpt_set_light_ahead", "spcbpt_get_pipeline_state", "spcbpt_reuse_sampler", "spcbpt_read_film", "spcbpt_debug_batch_scratch", "spcbpt_debug_read_sampling_tables", "spcbpt_lvc_import_wait", "spcbpt_kernel_time",
     "spcbpt_reset_kernel_time", "spcbpt_enable_kernel_timing", "spcbpt_trace_closest", "spcbpt_trace_any",
     "spcbpt_preprocess", "spcbpt_get_subspace", "spcbpt_scene_info", "spcbpt_set_pretrace", "spcbpt_train_records_count",
     "spcbpt_train_records_read", "spcbpt_train_records_import", "spcbpt_train_records_clear", "spcbpt_preprocess_stage",

@@ -18,6 +18,7 @@
 namespace spc { void launch_repack_nodes_quad2(const float* nodes_q, float* out, int n_nodes, hipStream_t s); }   // quad_trace.hip (declared here: kernels.h is part of the megakernel's source hash)
 #include "lbvh.h"
 #include "env_host.h"
+void spc_viewers_forget_context(spcbpt_ctx* ctx);   // viewer.cpp: called by spcbpt_destroy, so that a viewer outliving its context is safe
 
 using namespace spc;
 
@@ -352,26 +353,48 @@ int Context::probe_lvc_capacity() {
 int Context::ensure_lvc_capacity(size_t n) {
     if (n <= lvc_capacity) return 0;
     if (sync_all()) return SPCBPT_ERR_HIP;
+    // Footprint (round 6, advisor): per buffer set TWO copies of the cache (own order + the sampler's order: 2 x 96 B per vertex),
+    // jump 4 B, CMF 4 B, guide 4 B = 204 B per vertex and set; n_sets = eye_batch * (n_render + 2) + 3 (83 for 20-frame batches).  A
+    // calibrated cache (spcbpt_lvc_calibrate: ~2 x a measured pass, 0.5 M vertices on the bench scene) is 100 MB per set; the
+    // uncalibrated worst case core_count x padding (5.2 M) is 1.06 GB per set -- INTEGRATION.md section 4 tells hosts to calibrate.
+    // The old buffers are gone from here on; if an allocation below fails the context is left EMPTY and consistent (capacity 0, every
+    // pointer null, no sampler): the failed call returns SPCBPT_ERR_HIP, and a later call with a size the device can hold succeeds.
     dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_weights);
     dev_free(d_wsorted); dev_free(d_prefix);
-    for (int s = 0; s < n_sets; s++) {   // what the eye pass reads exists once per frame in flight (see context.h)
-        dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_guide[s]);
-        HIP_TRY(this, dev_alloc(&set_lvc[s], n)); HIP_TRY(this, dev_alloc(&set_lvc_sorted[s], n)); HIP_TRY(this, dev_alloc(&set_vals2[s], n));
-        HIP_TRY(this, dev_alloc(&set_cmfs[s], n + 8));   // (the eye kernel reads a CMF in aligned windows of eight: kernels.hip guide_window)
-        HIP_TRY(this, dev_alloc(&set_guide[s], n));
-    }
+    for (int s = 0; s < n_sets; s++) { dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_guide[s]); }
     for (int s2 = 0; s2 < kMaxSets; s2++) { set_count_host[s2] = -1; light_counts_valid[s2] = false; set_bound[s2] = -1; ev_exch_set[s2] = false; }   // the sets are empty again
     pending.clear();
     built_sets.clear();   // samplers built in the old allocations went with them
     free_batch_build_scratch();
-    select_set(lset);
-    HIP_TRY(this, dev_alloc(&d_keys, n)); HIP_TRY(this, dev_alloc(&d_keys2, n));
-    HIP_TRY(this, dev_alloc(&d_vals, n));
-    HIP_TRY(this, dev_alloc(&d_weights, n));
-    HIP_TRY(this, dev_alloc(&d_wsorted, n)); HIP_TRY(this, dev_alloc(&d_prefix, n));
-    lvc_capacity = n;
+    sbb_refused_bytes = 0;   // (a new capacity is a new question to the allocator)
+    lvc_capacity = 0;
     lvc_count = 0;
     have_sampler = false;
+    hipError_t e = hipSuccess;
+    for (int s = 0; s < n_sets && e == hipSuccess; s++) {   // what the eye pass reads exists once per frame in flight (see context.h)
+        e = dev_alloc(&set_lvc[s], n);
+        if (e == hipSuccess) e = dev_alloc(&set_lvc_sorted[s], n);
+        if (e == hipSuccess) e = dev_alloc(&set_vals2[s], n);
+        if (e == hipSuccess) e = dev_alloc(&set_cmfs[s], n + 8);   // (the eye kernel reads a CMF in aligned windows of eight: kernels.hip guide_window)
+        if (e == hipSuccess) e = dev_alloc(&set_guide[s], n);
+    }
+    if (e == hipSuccess) e = dev_alloc(&d_keys, n);
+    if (e == hipSuccess) e = dev_alloc(&d_keys2, n);
+    if (e == hipSuccess) e = dev_alloc(&d_vals, n);
+    if (e == hipSuccess) e = dev_alloc(&d_weights, n);
+    if (e == hipSuccess) e = dev_alloc(&d_wsorted, n);
+    if (e == hipSuccess) e = dev_alloc(&d_prefix, n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dev_free(d_keys); dev_free(d_keys2); dev_free(d_vals); dev_free(d_weights); dev_free(d_wsorted); dev_free(d_prefix);
+        for (int s = 0; s < n_sets; s++) { dev_free(set_lvc[s]); dev_free(set_lvc_sorted[s]); dev_free(set_vals2[s]); dev_free(set_cmfs[s]); dev_free(set_guide[s]); }
+        select_set(lset);
+        error = std::string("light-vertex cache of ") + std::to_string(n) + " vertices x " + std::to_string(n_sets) + " buffer sets: " + hipGetErrorString(e) +
+                " (the context now holds NO cache: call spcbpt_lvc_set_capacity / spcbpt_lvc_calibrate with a size the device can hold)";
+        return SPCBPT_ERR_HIP;
+    }
+    select_set(lset);
+    lvc_capacity = n;
     return 0;
 }
 
@@ -563,7 +586,9 @@ int Context::launch_light_batch(uint32_t first_frame, int n) {
         // which the light pass that shares its CUs is slower: with 24 blocks the batch for the NEXT eye launch took 101-113 ms beside an eye
         // launch of 116 (tools/timeline_long.sh), so that its sampler build -- 1.3 ms -- ran in the gap between two eye kernels instead of
         // under the first.  Steady-state ms per step, 24 / 32 / 40 / 48 / 64 blocks: 3.706 / 3.661 / 3.70-3.77 / 3.75 / 3.87)
-        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, std::ceil(640.0 * ratio)));
+        // (round 6, advisor: 640 x 0.048225 = 30.9 -> ceil gave 31, a grid no sweep had covered; the product is now rounded up to a
+        // multiple of 8 blocks -- one per XCD -- which IS the swept 32 on the bench scene)
+        grid_cap = (int)std::max(kp.row_step > 1 ? 48.0 : 16.0, std::min(256.0, 8.0 * std::ceil(80.0 * ratio)));
     }
     // (cores that trace many paths one after the other -- the reference's geometry -- are long jobs: never two of them per lane)
     if (lt.m_per_core >= 8) grid_cap = std::max(grid_cap, (int)(((long long)n * lt.core_count + 255) / 256));
@@ -766,24 +791,36 @@ int Context::build_sampler_batch(int n) {
     }
     stride = (stride + 4095) / 4096 * 4096;
     if (!sbb_keys || sbb_frames < n || sbb_capacity < stride) {
-        if (sync_all()) return SPCBPT_ERR_HIP;
         const int frames = std::max(n, sbb_frames);
         const size_t cap = std::max(stride, sbb_capacity);
-        free_batch_build_scratch();
         const size_t limit = sbb_debug_limit();   // tests: pretend the device refuses more than this many bytes of batch scratch
         const size_t bytes = (size_t)frames * cap * (sizeof(uint32_t) + sizeof(float) + sizeof(double));
-        bool ok = bytes <= limit;
-        ok = ok && dev_alloc(&sbb_keys, (size_t)frames * cap) == hipSuccess;
-        ok = ok && dev_alloc(&sbb_weights, (size_t)frames * cap) == hipSuccess;
-        ok = ok && dev_alloc(&sbb_wsorted, (size_t)frames * cap) == hipSuccess;
-        ok = ok && dev_alloc(&sbb_hist, (size_t)frames * sampler_build_hist_ints()) == hipSuccess;
+        // (round 6, advisor) A size the device has refused is not asked for again until the capacity or the mode changes -- every call used
+        // to repeat the device-wide wait, four hipMallocs and the failure path -- and the scratch that exists is kept while the larger one
+        // is tried: a later, smaller batch still fits it.  The first refusal is reported once on stderr; spcbpt_get_pipeline_state's
+        // callers see the count in spcbpt_debug_get("sbb_fallbacks").
+        bool ok = bytes <= limit && (sbb_refused_bytes == 0 || bytes < sbb_refused_bytes);
+        uint32_t* nk = nullptr; float* nw = nullptr; double* ns = nullptr; int* nh = nullptr;
+        if (ok) {
+            if (sync_all()) return SPCBPT_ERR_HIP;
+            ok = dev_alloc(&nk, (size_t)frames * cap) == hipSuccess;
+            ok = ok && dev_alloc(&nw, (size_t)frames * cap) == hipSuccess;
+            ok = ok && dev_alloc(&ns, (size_t)frames * cap) == hipSuccess;
+            ok = ok && dev_alloc(&nh, (size_t)frames * sampler_build_hist_ints()) == hipSuccess;
+            if (!ok) { (void)hipGetLastError(); dev_free(nk); dev_free(nw); dev_free(ns); dev_free(nh); }   // (an allocation failure is sticky in hipGetLastError only)
+        }
         if (!ok) {
-            (void)hipGetLastError();   // (an allocation failure is sticky in hipGetLastError only)
-            free_batch_build_scratch();
+            if (sbb_refused_bytes == 0 || bytes < sbb_refused_bytes) {
+                if (sbb_refused_bytes == 0)
+                    fprintf(stderr, "spcbpt: no room for %zu bytes of batched sampler-build scratch (%d frames x %zu vertices): building one by one\n", bytes, frames, cap);
+                sbb_refused_bytes = bytes;
+            }
             sbb_fallbacks++;
             for (int k = 0; k < n; k++) { const int rc = build_sampler(); if (rc) return rc; }
             return 0;
         }
+        free_batch_build_scratch();
+        sbb_keys = nk; sbb_weights = nw; sbb_wsorted = ns; sbb_hist = nh;
         sbb_frames = frames; sbb_capacity = cap;
     }
     SamplerBuildBatch B = {};
@@ -1367,10 +1404,19 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
 
 int spcbpt_destroy(spcbpt_ctx* c) {
     if (!c) return SPCBPT_ERR_INVALID_ARG;
+    spc_viewers_forget_context(c);   // viewers of this context live on as state machines without one (viewer.cpp)
     (void)hipSetDevice(c->device);
     (void)c->sync_all();
     delete c;
     return SPCBPT_OK;
+}
+
+const char* spcbpt_build_arithmetic(void) {
+#if defined(SPCBPT_FAST_MATH_BUILD)
+    return "approx";
+#else
+    return "ieee";
+#endif
 }
 
 const char* spcbpt_last_error(const spcbpt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
@@ -1458,6 +1504,7 @@ int spcbpt_lvc_set_capacity(spcbpt_ctx* c, int vertices) {
     if (vertices < 0) { c->error = "lvc_set_capacity: negative capacity"; return SPCBPT_ERR_INVALID_ARG; }
     c->lvc_fixed = (size_t)vertices;
     if (c->sbb_keys) { if (c->sync_all()) return SPCBPT_ERR_HIP; c->free_batch_build_scratch(); }   // sized for the old capacity's builds
+    c->sbb_refused_bytes = 0;
     if (vertices == 0) { c->lvc_probe_needed = true; return SPCBPT_OK; }   // back to the probe pass (the sets only ever grow)
     c->lvc_probe_needed = false;
     return c->ensure_lvc_capacity((size_t)vertices);
@@ -1753,7 +1800,7 @@ int spcbpt_set_light_ahead(spcbpt_ctx* c, int on) {
     const bool was = c->light_ahead;
     c->light_ahead = on != 0;
     c->pending.clear();
-    if (was && !c->light_ahead) c->free_batch_build_scratch();   // only loops with passes ahead build in batches
+    if (was && !c->light_ahead) { c->free_batch_build_scratch(); c->sbb_refused_bytes = 0; }   // only loops with passes ahead build in batches
     return SPCBPT_OK;
 }
 

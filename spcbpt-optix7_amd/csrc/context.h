@@ -221,6 +221,7 @@ struct Context {
     uint32_t* sbb_keys = nullptr; float* sbb_weights = nullptr; double* sbb_wsorted = nullptr; int* sbb_hist = nullptr;   // its scratch: per frame what d_keys .. d_hist are
     int sbb_frames = 0; size_t sbb_capacity = 0;   // frames x items per frame it holds
     int sbb_fallbacks = 0;                          // batches built one by one because the scratch could not be allocated
+    size_t sbb_refused_bytes = 0;                   // the smallest scratch size the device has refused (0: none): not asked for again until the capacity or the mode changes
     void free_batch_build_scratch();
     size_t sbb_debug_limit() const;
     // the tables of the last sampler build are still what that build left (no later pass, import or re-allocation took the set)

@@ -223,6 +223,12 @@ static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_TRI_BATCH
 #define SPC_TRI_BATCH 8   // trace_pool: N > 1 = lanes on a leaf wait until N of them are (or nobody is on an internal node) before the triangle step
 #endif
+#ifndef SPC_PROBE_DROP_TAIL
+#define SPC_PROBE_DROP_TAIL 0
+#endif
+#ifndef SPC_PROBE_TRI_PAIRS
+#define SPC_PROBE_TRI_PAIRS 0
+#endif
 #ifndef SPC_ROOT_AHEAD
 #define SPC_ROOT_AHEAD 1  // trace_pool: a lane that is about to draw a ray requests the root with the other lanes' next records
 #endif
@@ -691,6 +697,13 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
         if (live__ == 0ull) break;
         // The pool is dry (some lane found it empty; the cursor only grows) and at most 16 rays are still in flight: the rest of the
         // pass is the tail that used to run these iterations at a fifth of the lanes.  Hand each ray to FOUR lanes (quad tail below).
+#if SPC_PROBE_DROP_TAIL
+        // TIMING PROBES (images invalid; profiles/r06_experiments.md): what the end of the pass costs -- the upper bound of anything that
+        // would carry its unfinished shadow rays into the next pass.  1: the rays the quad tail would take over are dropped (left
+        // unoccluded) when no closest-hit ray is among them; 2: every shadow ray still in flight once the pool is dry and the
+        // closest-hit rays are done.
+        if (__any(done) && !__any(node != kTravDone && closest) && (SPC_PROBE_DROP_TAIL == 2 || __popcll(live__) <= 16)) break;
+#endif
         if (SPC_QUAD_TAIL && S.nodes_q && __popcll(live__) <= 16 && __any(done)) { quad_live = live__; break; }
         const bool tail = COUNT && __any(done);   // (counting build) some lane found the pool empty: what follows is the pass's tail
         bool finished = false, occluded = false;
@@ -731,8 +744,10 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                         occluded = true; finished = true; node = kTravDone;                                           \
                     } else {                                                                                          \
                         if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                \
-                        node -= 1;  /* ~(tri + 1) */                                                                  \
-                        leaf_count -= 1;                                                                              \
+                        /* SPC_PROBE_TRI_PAIRS (timing probe, images invalid): a step answers for two triangles of the leaf */ \
+                        const int adv__ = (SPC_PROBE_TRI_PAIRS && leaf_count >= 2) ? 2 : 1;                           \
+                        node -= adv__;  /* ~(tri + 1) */                                                              \
+                        leaf_count -= adv__;                                                                          \
                         if (leaf_count == 0) { SPC_TRAV_POP_(POP); finished = node == kTravDone; }                    \
                     }                                                                                                 \
                 }                                                                                                     \

@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <utility>
+#include <vector>
 
 #include "../../include/spcbpt.h"
 
@@ -152,6 +154,24 @@ void spcbpt_viewer::revalidate() {
     if (sampler_ready && !intact) { sampler_ready = false; lt_launch_frame--; }
 }
 
+// Live viewers, so that a context that is destroyed FIRST can tell them (round 6, advisor: spcbpt_viewer_destroy calls into the
+// context; with `Renderer.close()` before `Viewer.close()` that was a use-after-free).  spcbpt_destroy calls
+// spc_viewers_forget_context (not part of the C ABI: exports.map keeps it local to the library); a forgotten viewer is the
+// state-machine-only viewer of `ctx == NULL`, which every entry point already supports.
+namespace {
+std::mutex g_viewers_mutex;
+std::vector<spcbpt_viewer*> g_viewers;
+}  // namespace
+
+void spc_viewers_forget_context(spcbpt_ctx* ctx) {
+    std::lock_guard<std::mutex> lock(g_viewers_mutex);
+    for (spcbpt_viewer* v : g_viewers) {
+        if (v->ctx != ctx) continue;
+        v->ctx = nullptr;
+        v->light_pending = v->sampler_ready = v->spec_in_flight = false;
+    }
+}
+
 extern "C" {
 
 int spcbpt_viewer_create(spcbpt_ctx* ctx, const float eye[3], const float lookat[3], const float up[3], float fov_y, int width,
@@ -176,6 +196,10 @@ int spcbpt_viewer_create(spcbpt_ctx* ctx, const float eye[3], const float lookat
         if (!rc) rc = spcbpt_set_light_ahead(ctx, 1);
         if (rc) { delete v; return rc; }
     }
+    {
+        std::lock_guard<std::mutex> lock(g_viewers_mutex);
+        g_viewers.push_back(v);
+    }
     *out = v;
     return SPCBPT_OK;
 }
@@ -189,6 +213,10 @@ void spcbpt_viewer_destroy(spcbpt_viewer* v) {
         int deferred = 0;
         if (!spcbpt_get_pipeline_state(v->ctx, nullptr, nullptr, nullptr, &deferred) && deferred) (void)spcbpt_merge_deferred(v->ctx, 0);
         (void)spcbpt_set_light_ahead(v->ctx, v->ctx_light_ahead_at_create);   // (waits for what is queued; clears the pending passes)
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_viewers_mutex);
+        g_viewers.erase(std::remove(g_viewers.begin(), g_viewers.end(), v), g_viewers.end());
     }
     delete v;
 }

@@ -42,12 +42,16 @@ def hip_lib(pkg):
     if not os.path.exists(pkg.api.LIB_PATH) or not os.path.exists(pkg.dist.MGPU_LIB_PATH):
         _make(csrc)
     try:
-        return pkg.load_library()      # refuses a library whose embedded source hash differs from the tree's (api.source_hash)
+        lib = pkg.load_library()       # refuses a library whose embedded source hash differs from the tree's (api.source_hash)
     except pkg.SpcbptError as e:
         if "built from other sources" not in str(e):
             raise
         _make(csrc)                    # stale binary: rebuild (hipcc cross-compiles here and compiles on the GPU box), then load
-        return pkg.load_library()
+        lib = pkg.load_library()
+    want = os.environ.get("SPCBPT_EXPECT_ARITHMETIC")   # the child run of tests/test_gpu_fast_build.py: prove which build is under test
+    if want:
+        assert lib.spcbpt_build_arithmetic().decode() == want, (lib.spcbpt_build_arithmetic(), want)
+    return lib
 
 
 def gpu_available():

@@ -126,13 +126,17 @@ int main(int argc, char** argv) {
                 parent[ref] = node; area[ref] = e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
             }
         }
+        // (round 6, advisor) areas are read from the 8-bit boxes, which are rounded outward on the PARENT's grid: a child's stored area
+        // may exceed by a grid cell per axis (~1 %) what its parent measures in the grandparent's grid, so the largest-first pop order
+        // of the builder is monotone only up to that slack.  The structural property (a hot node's parent is hot and precedes it) is exact.
+        const float slack = 1.02f;
         const int hot = std::min(n_nodes, (int)HOT_NODES);
         for (int i = 1; i < hot; i++) {
             if (parent[i] < 0 || parent[i] >= i) { c.ok = false; printf("hot node %d: parent %d\n", i, parent[i]); }
-            if (i > 1 && area[i] > area[i - 1] * 1.0001f) { c.ok = false; printf("hot node %d: area %g after %g\n", i, area[i], area[i - 1]); }
+            if (i > 1 && area[i] > area[i - 1] * slack) { c.ok = false; printf("hot node %d: area %g after %g\n", i, area[i], area[i - 1]); }
         }
         for (int i = hot; i < n_nodes && hot > 1; i++)
-            if (parent[i] >= 0 && parent[i] < hot && area[i] > area[hot - 1] * 1.0001f) { c.ok = false; printf("node %d (area %g) should be in the crown (last %g)\n", i, area[i], area[hot - 1]); break; }
+            if (parent[i] >= 0 && parent[i] < hot && area[i] > area[hot - 1] * slack) { c.ok = false; printf("node %d (area %g) should be in the crown (last %g)\n", i, area[i], area[hot - 1]); break; }
     }
     printf("%s n=%d nodes=%lld leaves=%lld depth=%d sah=%.1f build=%.3fs\n", c.ok ? "OK" : "FAIL", n, c.nodes, c.leaves, out.depth, c.sah, sec);
     return c.ok ? 0 : 1;

@@ -508,7 +508,8 @@ def test_c5_full_size_hallway_equal_time_variance_against_plain_bdpt_and_pt(gpu,
 
 def test_c2_cornell_1024_trained_tuple_properties_and_oracle_parity(gpu, pkg, ob):
     """BASELINE config 2 "with the minimal valid subspace tuple AND with the trained Gamma" (SURVEY 8(d) C2): the trained half.
-    Cornell box 1024 x 1024, M = 100 000 light paths, a tuple trained on the device; 16 spp of "SPCBPT_eye": every pixel written
+    Cornell box 1024 x 1024, M = 100 000 light paths, a tuple trained on the device; the configuration's own 64 spp of "SPCBPT_eye"
+    (and 64 of "pt"): every pixel written
     and finite, mean = PT's within 1 %, the running mean is the running mean (a frame rendered again on a converged buffer of
     itself leaves it unchanged).  Then the SAME trained tuple on both sides at 128 x 128: image parity against the oracle."""
     scene = pkg.scenes.cornell_box()
@@ -518,12 +519,12 @@ def test_c2_cornell_1024_trained_tuple_properties_and_oracle_parity(gpu, pkg, ob
     tup = r.get_subspace()
     et, lt, q, cmf = tup
     assert len(set(et["label"][et["leaf"] == 1].tolist())) > 300 and len(set(lt["label"][lt["leaf"] == 1].tolist())) > 100
-    for f in range(16):
+    for f in range(64):
         r.render_frame("SPCBPT_eye", f)
     sp = r.read_accum()
     assert (sp[..., 3] == 1.0).all() and np.isfinite(sp).all()
     r.clear_accum()
-    for f in range(16):
+    for f in range(64):
         r.launch("pt", f)
     pt = r.read_accum()
     assert (pt[..., 3] == 1.0).all() and np.isfinite(pt).all()

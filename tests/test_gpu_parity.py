@@ -678,3 +678,20 @@ def test_batched_build_scratch_is_sized_by_the_batch_and_falls_back_when_it_cann
     assert all(np.array_equal(x, y) for x, y in zip(got[:3], want[:3]))
     r.launch_eye_batch([0, 1, 2]); r.sync()
     assert np.array_equal(r.read_accum(), film)
+    # a refused size is remembered (no device-wide wait and four hipMallocs per call), until the mode or the capacity changes
+    monkeypatch.delenv("SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT")
+    r.launch_light_batch(1, 3); r.build_sampler_batch(3)
+    assert r.batch_scratch() == {"bytes": 0, "frames": 0, "fallbacks": 2}
+    r.launch_eye_batch([0, 1, 2]); r.sync()
+    r.set_light_ahead(False); r.set_light_ahead(True)
+    r.launch_light_batch(1, 2); r.build_sampler_batch(2)
+    small = r.batch_scratch()
+    assert small["frames"] == 2 and small["bytes"] > 0 and small["fallbacks"] == 2
+    r.launch_eye_batch([0, 1]); r.sync()
+    # a grow attempt that fails keeps the scratch that exists: the next 2-frame batch still runs batched
+    monkeypatch.setenv("SPCBPT_DEBUG_BATCH_SCRATCH_LIMIT", "4096")
+    r.launch_light_batch(1, 3); r.build_sampler_batch(3)
+    assert r.batch_scratch() == {"bytes": small["bytes"], "frames": 2, "fallbacks": 3}
+    r.launch_eye_batch([0, 1, 2]); r.sync()
+    r.launch_light_batch(1, 2); r.build_sampler_batch(2)
+    assert r.batch_scratch() == {"bytes": small["bytes"], "frames": 2, "fallbacks": 3}

@@ -251,6 +251,28 @@ def test_destroying_the_viewer_hands_the_context_back_as_it_was_found(gpu, pkg):
 
 
 @pytest.mark.gpu
+def test_context_destroyed_before_its_viewer(gpu, pkg):
+    """The host tears down in the "wrong" order (Renderer.close(), then Viewer.close() -- or the garbage collector does): the
+    library forgets the context in its live viewers at spcbpt_destroy, the viewer goes on as the state machine of a null context
+    (events and frames still advance its state, nothing is launched) and its destruction touches no freed context."""
+    r, cam = _small_renderer(pkg)
+    v = pkg.api.Viewer(r, cam["eye"], cam["lookat"], cam["up"], cam["fov"], 64, 64)
+    for _ in range(3):
+        v.frame()
+    assert r.pipeline_state()["deferred"] == 1          # a frame traced ahead and a light pass are queued on the context
+    r.close()                                           # waits for what is queued, then frees the context
+    before = v.state()["subframe_index"]
+    v.mouse_button("left", 1, 10, 10); v.cursor_pos(20, 14); v.mouse_button("left", 0, 20, 14)
+    v.frame()                                           # state machine only: camera changed -> subframe restarts at 0, then counts
+    assert v.state()["subframe_index"] == 1 and before == 3
+    v.close()
+    # and the usual order still works on a fresh context
+    r2, cam = _small_renderer(pkg)
+    v2 = pkg.api.Viewer(r2, cam["eye"], cam["lookat"], cam["up"], cam["fov"], 64, 64)
+    v2.frame(); v2.close(); r2.close()
+
+
+@pytest.mark.gpu
 def test_moving_camera_does_not_speculate_and_read_film_shows_the_frame(gpu, pkg):
     """Mode 2 speculates from a steady view only: during a drag (every call sees a camera change) no frame is queued to be dropped
     -- the context holds no deferred frame after such a call -- and the first steady calls trace ahead again.  The frames are the

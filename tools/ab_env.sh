@@ -6,7 +6,7 @@ sw=$1; shift
 for k in 1 2; do
   for v in A B; do
     if [ $v = A ]; then export $sw=1; else unset $sw; fi
-    python bench.py --no-cpu-baseline "$@" 2>gpurun_out/ab_err_$v.log | python -c "
+    python bench.py --no-cpu-baseline --fast-math-line 0 "$@" 2>gpurun_out/ab_err_$v.log | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], 'Mpaths/s', d['ms_per_step'], 'ms/step, kernel', d['roofline']['kernel_ms'], 'viewer', d.get('ms_per_frame_viewer'))" || tail -5 gpurun_out/ab_err_$v.log
   done
 done

@@ -486,8 +486,14 @@ int Context::launch_light(uint32_t frame) {
     kp.work_counter = d_work_counter + kMaxRender + lane;
     HIP_TRY(this, hipMemsetAsync(kp.work_counter, 0, sizeof(uint32_t), ls));
     if (light_blocks < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS"); light_blocks = lb ? std::max(1, atoi(lb)) : std::max(1, num_cus); }
+    // Thin or wide (round 6).  One block per CU is right for a pass that runs BESIDE eye kernels (light-ahead mode: few long-lived blocks
+    // take least from them).  In the reference's loop form -- light pass, build, eye launch, sync, strictly in turn
+    // (optixPathTracer.cpp:791-822) -- nothing else is on the GPU while the pass runs, and one wave per SIMD leaves it a chain of
+    // dependent fetches: there the pass gets a lane per core (100 000 paths: 391 blocks; four per CU at most), SPCBPT_LIGHT_BLOCKS_WIDE.
+    if (light_blocks_wide < 0) { const char* lb = getenv("SPCBPT_LIGHT_BLOCKS_WIDE"); light_blocks_wide = lb ? std::max(1, atoi(lb)) : std::max(1, 4 * num_cus); }
+    const int light_grid = (!light_ahead && lane == 0) ? std::max(light_blocks, light_blocks_wide) : light_blocks;
     time_begin("light_trace", ls);
-    launch_light_trace(kp, kernel_variant(), light_blocks, ls);   // direction trees: the generic instantiation (no label caching)
+    launch_light_trace(kp, kernel_variant(), light_grid, ls);   // direction trees: the generic instantiation (no label caching)
     time_end();
     HIP_TRY(this, hipGetLastError());
     // compaction: exclusive scan of per-core counts (+1 sentinel gives the total) -> offsets

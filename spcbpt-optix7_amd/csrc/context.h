@@ -192,6 +192,7 @@ struct Context {
     int num_cus = 0, blocks_per_cu[3] = {0, 0, 0};   // per kernel variant (single-frame launches), of the instantiation launched
     int blocks_per_cu_batch = 0;                       // the batched timed kernel's
     int grid_percent = 0;              // persistent grid as a share of the resident block slots; 0 = 94 with several render streams, else 100 (launch_render)
+    int light_blocks_wide = -1;        // ... of a pass that has the GPU to itself (no passes ahead): a lane per core, at most four blocks per CU (SPCBPT_LIGHT_BLOCKS_WIDE)
     int light_blocks = -1;             // persistent grid of the light pass (SPCBPT_LIGHT_BLOCKS; default: one block per CU)
     int light_batch_blocks = -1;       // ... of a batched light pass (SPCBPT_LIGHT_BATCH_BLOCKS; 0 = in proportion to the light paths per pixel, >= 16: launch_light_batch)
     int tiles_per_wave = 1;            // lower bound of 8x8 tiles per persistent wave (SPCBPT_TILES_PER_WAVE)

@@ -144,10 +144,14 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     c->n_triangles = mesh.n_triangles; c->n_nodes = (int)(bvh.nodes.size() / 16); c->bvh_depth = bvh.depth;
     c->n_lights = (int)lights.size(); c->n_mats = (int)mats.size();
 
-    // nodes and triangles in ONE allocation, the triangle records right behind the node records (both 64 B): the pooled traversal
-    // step fetches "the record of its next step" through one base pointer (device_lib.h: SPC_FETCH_STEP__)
-    CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size() + bvh.tris.size()));
-    c->d_tris = c->d_nodes + bvh.nodes.size();
+    // nodes and the PAIR records of the triangles (lbvh.h: Lbvh::pairs, one 64-B slot per triangle) in ONE allocation, the pair records
+    // right behind the node records: the pooled traversal step fetches "the record of its next step" through one base pointer
+    // (dev_traversal.h: SPC_FETCH_STEP__).  The per-triangle records (corners + UVs + material: what the tails, the one-ray-per-lane
+    // loop and the shading read) live in an allocation of their own.
+    CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size() + bvh.pairs.size()));
+    CREATE_TRY(dev_alloc(&c->d_tris, bvh.tris.size()));
+    CREATE_TRY(hipMemcpy(c->d_nodes + bvh.nodes.size(), bvh.pairs.data(), bvh.pairs.size() * 4, hipMemcpyHostToDevice));
+    c->n_paired = bvh.n_paired;
     CREATE_TRY(dev_alloc(&c->d_tri_orig, bvh.tri_orig.size()));
     CREATE_TRY(dev_alloc(&c->d_mats, mats.size()));
     CREATE_TRY(dev_alloc(&c->d_lights, lights.size()));

@@ -118,6 +118,7 @@ struct Context {
     float* d_nodes_q = nullptr;            // the same nodes in the quad-lane layout (quad_trace.hip), built on first use
     float* d_nodes_q2 = nullptr;           // ... with the scale exponents as signed bytes (the lean quad kernel)
     float* d_tris = nullptr;
+    int n_paired = 0;                      // triangles that are half of a fan pair (lbvh.h): what the pooled pass tests two at a time
     int32_t* d_tri_orig = nullptr;
     DMaterial* d_mats = nullptr;
     DLight* d_lights = nullptr;

@@ -429,7 +429,7 @@ int Context::install_minimal_tuple() {
 Context::~Context() {
     resolve_spans();
     free_preprocess();
-    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_nodes_q2); /* d_tris lives in d_nodes' allocation */ dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
+    dev_free(d_nodes); dev_free(d_nodes_q); dev_free(d_nodes_q2); dev_free(d_tris); dev_free(d_tri_orig); dev_free(d_mats); dev_free(d_lights); dev_free(d_tex);
     for (auto p : d_tex_data) (void)hipFree(p);
     dev_free(d_env_tex); dev_free(d_env_cmf); dev_free(d_accum); dev_free(d_frame); dev_free(d_eye_tree); dev_free(d_light_tree); dev_free(d_Q); dev_free(d_gamma); dev_free(d_gamma2); dev_free(d_guide1); dev_free(d_gamma_q);
     dev_free(d_scratch); dev_free(d_core_counts); dev_free(d_core_offsets); dev_free(d_keys); dev_free(d_keys2);

@@ -150,6 +150,9 @@ static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_PROBE_DROP_TAIL
 #define SPC_PROBE_DROP_TAIL 0
 #endif
+#ifndef SPC_TRI_PAIRS
+#define SPC_TRI_PAIRS 1   // trace_pool: a lane's triangle step tests both halves of a fan pair (lbvh.h: Lbvh::pairs); 0 = one triangle per step (the slot's first three corners)
+#endif
 #ifndef SPC_PROBE_TRI_PAIRS
 #define SPC_PROBE_TRI_PAIRS 0
 #endif
@@ -509,7 +512,10 @@ static constexpr int POOL_RAYS = 64 * SPCBPT_CONNECTION_N;
 #ifndef SPC_POOL_BUCKETS
 #define SPC_POOL_BUCKETS 4
 #endif
-SPC_DEV uint32_t pool_ray_list(const float4* s_ray, uint8_t* s_list) {
+#ifndef SPC_PROBE_HALVE_LONG
+#define SPC_PROBE_HALVE_LONG 0   // TIMING PROBE (images invalid): the rays of the longest class end at half their length -- what splitting them in two could save at most
+#endif
+SPC_DEV uint32_t pool_ray_list(const float4* s_ray, uint8_t* s_list, float* s_mean = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t n = 0u;
     float len[SPCBPT_CONNECTION_N];
@@ -534,6 +540,7 @@ SPC_DEV uint32_t pool_ray_list(const float4* s_ray, uint8_t* s_list) {
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     if (cnt == 0u) return 0u;
     const float mean = sum / (float)cnt;
+    if (SPC_PROBE_HALVE_LONG && s_mean && lane == 0) *s_mean = mean;
     // class 0 = longest.  SPC_POOL_BUCKETS = 2: [mean, inf), [0, mean); 4: [2 mean, inf), [mean, 2 mean), [mean / 2, mean), [0, mean / 2)
     int cls[SPCBPT_CONNECTION_N];
 #pragma unroll
@@ -610,6 +617,7 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
             o = mk3(oq.x, oq.y, oq.z); d = mk3(rq.x, rq.y, rq.z);
             inv = safe_inv(d); ood = o * inv;
             best_t = rq.w - kEps;
+            if (SPC_PROBE_HALVE_LONG && rq.w >= 2.0f * __uint_as_float(s_next[1])) best_t = 0.5f * rq.w;
             node = 0; st.sp = 0;
             cn.add(C_SHADOW);
 #if SPC_ONE_FETCH
@@ -661,15 +669,26 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                     const int tri = ~node;                                                                            \
                     cn.add(C_TRI);                                                                                    \
                     SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)                                                      \
-                    const bool cull = closest && (__float_as_uint(R3.w) & 0x80000000u) != 0;  /* single-sided emitters */ \
+                    /* the slot of a FAN PAIR (lbvh.h: R0 .. R2 = A's corners, R3.xyz = B's third corner, B = (A.P0, A.P2, R3)): this step */ \
+                    /* tests both, A first and B against what A left of the interval -- the operations and the order of two steps */ \
+                    const uint32_t fl__ = __float_as_uint(R3.w);                                                      \
+                    const bool pair__ = SPC_TRI_PAIRS && (fl__ & 1u) != 0;                                            \
+                    const bool cull = closest && (fl__ & 0x80000000u) != 0;  /* single-sided emitters */              \
                     float t, u, v;                                                                                    \
-                    const bool h = tri_test(R0, R1, R2, o, d, kEps, best_t, cull, t, u, v);                           \
+                    bool h = tri_test(R0, R1, R2, o, d, kEps, best_t, cull, t, u, v);                                 \
+                    if (h && closest) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                         \
+                    if (pair__ && !(h && !closest)) {                                                                 \
+                        cn.add(C_TRI);                                                                                \
+                        if (COUNT) cn.add(C_U_TRI_LANES);                                                             \
+                        const bool hb__ = tri_test(R0, R2, R3, o, d, kEps, best_t, closest && (fl__ & 0x40000000u) != 0, t, u, v); \
+                        if (hb__ && closest) { best_t = t; best_tri = tri + 1; best_u = u; best_v = v; }              \
+                        h = h || hb__;                                                                                \
+                    }                                                                                                 \
                     if (h && !closest) {                                                                              \
                         occluded = true; finished = true; node = kTravDone;                                           \
                     } else {                                                                                          \
-                        if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                \
                         /* SPC_PROBE_TRI_PAIRS (timing probe, images invalid): a step answers for two triangles of the leaf */ \
-                        const int adv__ = (SPC_PROBE_TRI_PAIRS && leaf_count >= 2) ? 2 : 1;                           \
+                        const int adv__ = (pair__ || (SPC_PROBE_TRI_PAIRS && leaf_count >= 2)) ? 2 : 1;               \
                         node -= adv__;  /* ~(tri + 1) */                                                              \
                         leaf_count -= adv__;                                                                          \
                         if (leaf_count == 0) { SPC_TRAV_POP_(POP); finished = node == kTravDone; }                    \

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(EYE_BLOCK, SPC_EYE_WAVES) void k_spcbpt(const KPara
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the slots that hold a shadow ray, compacted (w_job is free here: the connect phase below rebuilds it after the pass)
-        const uint32_t n_rays = pool_ray_list(w_ray, w_job);
+        const uint32_t n_rays = pool_ray_list(w_ray, w_job, reinterpret_cast<float*>(w_next + 1));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // the vertex's five small integers cross the pass in two registers (the pass needs every register it can get: the kernel spills)

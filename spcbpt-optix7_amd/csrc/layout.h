@@ -20,7 +20,10 @@ namespace spc {
 // (count 1..LEAF_MAX).  An empty slot has ref 0x80000000 (a leaf of zero triangles) and the inverted box qlo = 255, qhi = 0,
 // which the sign-aware slab test of device_lib.h cannot hit.  Quantisation rounds lo down and hi up, so a child box only
 // grows: the nearest hit found is unchanged.
-static const int LEAF_MAX = 4;
+#ifndef SPC_LEAF_MAX
+#define SPC_LEAF_MAX 4   // (experiments: smaller leaves trade triangle steps for node steps -- profiles/r06_experiments.md)
+#endif
+static const int LEAF_MAX = SPC_LEAF_MAX;
 static const int NODE_QUADS = 4;
 static const int HOT_NODES = 64;   // lbvh.cpp numbers the nodes of largest surface area 0 .. HOT_NODES - 1 (largest first; node 0 is the root)
 static const uint32_t NODE_EMPTY = 0x80000000u;  // decodes to a leaf of zero triangles: harmless even if a ray "hits" the slot
@@ -116,7 +119,7 @@ struct DeviceScene {
     int32_t n_mats;
     int32_t general;         // != 0: the scene has an environment map or a material with `brdf` set -> the timed kernels' ENV = true forms
     int32_t fan_tail;        // != 0: the shadow rays of the quad tail fan out over the idle quads (device_lib.h: fan_tail)
-    int32_t tri_base;        // the triangle records follow the node records in one allocation: record n_nodes + t of `nodes` is triangle t
+    int32_t tri_base;        // the PAIR records (lbvh.h: Lbvh::pairs) follow the node records in one allocation: record n_nodes + t of `nodes` is the slot of triangle t
     int32_t pad_tri_base;
     DEnv env;
 };

@@ -547,6 +547,68 @@ void hot_nodes_first(std::vector<float>& nodes, int K) {
 }
 }  // namespace
 
+// ---- fan pairs (round 6) -------------------------------------------------------------------------------------------------
+// Inside every leaf the triangles are reordered so that the halves of a quad sit next to each other, A first (B.P0 == A.P0 and
+// B.P1 == A.P2, compared as bits: B is then (v0, v2, v3) of the fan (v0, v1, v2, v3), and testing B from the pair record runs the
+// very operations its own record would).  A leaf's box and its set of triangles do not change; the order in which its triangles are
+// tested does (a tie in t between two triangles of one leaf goes to the one tested first, as before).
+static void make_fan_pairs(Lbvh& out) {
+    const size_t n = out.tri_orig.size();
+    out.pairs.assign(16 * n, 0.0f);
+    out.n_paired = 0;
+    std::vector<uint8_t> is_a(n, 0);
+    auto same3 = [](const float* a, const float* b) { return memcmp(a, b, 12) == 0; };
+    auto fan = [&](const float* A, const float* B) { return same3(A, B) && same3(A + 8, B + 4); };   // records of 16 floats: P0 at 0, P1 at 4, P2 at 8
+    const size_t n_nodes = out.nodes.size() / 16;
+    for (size_t nd = 0; nd < n_nodes; nd++) {
+        for (int c = 0; c < 4; c++) {
+            uint32_t ref; memcpy(&ref, &out.nodes[nd * 16 + 10 + c], 4);
+            if (!(ref & 0x80000000u)) continue;
+            const size_t first = (ref & 0x7fffffffu) >> 3;
+            const int cnt = (int)(ref & 7u);
+            if (cnt < 2) continue;
+            // greedy matching in the leaf's own order (stable: unmatched triangles keep their relative order)
+            float rec[LEAF_MAX > 0 ? LEAF_MAX : 1][16]; int32_t orig[LEAF_MAX > 0 ? LEAF_MAX : 1];
+            for (int i = 0; i < cnt; i++) { memcpy(rec[i], &out.tris[(first + i) * 16], 64); orig[i] = out.tri_orig[first + i]; }
+            int used[8] = {0, 0, 0, 0, 0, 0, 0, 0}, seq[8], a_flag[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m = 0;
+            for (int i = 0; i < cnt; i++) {
+                if (used[i]) continue;
+                int partner = -1, as_b = 0;
+                for (int j = 0; j < cnt && partner < 0; j++) {
+                    if (j == i || used[j]) continue;
+                    if (fan(rec[i], rec[j])) { partner = j; as_b = 0; }
+                    else if (fan(rec[j], rec[i])) { partner = j; as_b = 1; }
+                }
+                used[i] = 1;
+                if (partner < 0) { seq[m++] = i; continue; }
+                used[partner] = 1;
+                a_flag[m] = 1;
+                seq[m++] = as_b ? partner : i;
+                seq[m++] = as_b ? i : partner;
+            }
+            for (int i = 0; i < cnt; i++) {
+                memcpy(&out.tris[(first + i) * 16], rec[seq[i]], 64);
+                out.tri_orig[first + i] = orig[seq[i]];
+                if (a_flag[i]) { is_a[first + i] = 1; out.n_paired += 2; }
+            }
+        }
+    }
+    for (size_t i = 0; i < n; i++) {
+        const float* t = &out.tris[i * 16];
+        float* q = &out.pairs[i * 16];
+        uint32_t meta; memcpy(&meta, t + 15, 4);
+        uint32_t flags = meta & 0x80000000u;
+        for (int v = 0; v < 3; v++) { q[4 * v] = t[4 * v]; q[4 * v + 1] = t[4 * v + 1]; q[4 * v + 2] = t[4 * v + 2]; }
+        if (is_a[i]) {
+            const float* b = &out.tris[(i + 1) * 16];
+            uint32_t mb; memcpy(&mb, b + 15, 4);
+            q[12] = b[8]; q[13] = b[9]; q[14] = b[10];   // B.P2 = v3
+            flags |= 1u | ((mb & 0x80000000u) >> 1);
+        }
+        memcpy(q + 15, &flags, 4);
+    }
+}
+
 void build_lbvh(const HostMesh& mesh, Lbvh& out) {
     Builder b(mesh, out);
     b.run();
@@ -560,6 +622,7 @@ void build_lbvh(const HostMesh& mesh, Lbvh& out) {
     int hot = HOT_NODES;
     if (const char* e = getenv("SPCBPT_BVH_HOT_NODES")) hot = std::max(0, atoi(e));   // developer knob (0 = depth-first order throughout)
     hot_nodes_first(out.nodes, hot);
+    make_fan_pairs(out);
 }
 
 }  // namespace spc

@@ -153,6 +153,9 @@ static constexpr int kTravDone = 0x7fffffff;
 #ifndef SPC_TRI_PAIRS
 #define SPC_TRI_PAIRS 1   // trace_pool: a lane's triangle step tests both halves of a fan pair (lbvh.h: Lbvh::pairs); 0 = one triangle per step (the slot's first three corners)
 #endif
+#ifndef SPC_TRI_PAIRS_LANE
+#define SPC_TRI_PAIRS_LANE 1   // traverse<> (one ray per lane to its end: "pt", the light pass, the pre-trace): the same pair step
+#endif
 #ifndef SPC_PROBE_TRI_PAIRS
 #define SPC_PROBE_TRI_PAIRS 0
 #endif
@@ -287,23 +290,43 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
             SPC_TRAV_POP_(POP);  /* an empty slot's zero-triangle leaf (only reachable through rounding): nothing to test */ \
         } else if (node < 0) {                                                                                        \
             const int tri = ~node;                                                                                    \
-            const size_t base = (size_t)tri * 4;                                                                      \
-            const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);                 \
             cn.add(C_TRI);                                                                                            \
             SPC_UTIL_COUNT(C_U_TRI_LANES, C_U_TRI_SLOTS)                                                              \
-            bool cull = false;                                                                                        \
-            if (!ANY) {                                                                                               \
-                /* emitter flag lives in quad 3; only fetched for closest-hit rays (single-sided emitters, q16) */     \
-                cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;                                 \
-            }                                                                                                         \
+            bool h;                                                                                                   \
+            int adv__ = 1;                                                                                            \
             float t, u, v;                                                                                            \
-            const bool h = tri_test(a, b, c, o, d, tmin, best_t, cull, t, u, v);                                      \
-            if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                            \
+            if (SPC_TRI_PAIRS_LANE) {                                                                                 \
+                /* the triangle's PAIR slot (lbvh.h; behind the node records): both halves of a quad in one step, A first */ \
+                const size_t base = ((size_t)(uint32_t)S.tri_base + (size_t)tri) * 4;                                 \
+                const float4 a = ldq(S.nodes, base), b = ldq(S.nodes, base + 1), c = ldq(S.nodes, base + 2), e = ldq(S.nodes, base + 3); \
+                const uint32_t fl__ = __float_as_uint(e.w);                                                           \
+                h = tri_test(a, b, c, o, d, tmin, best_t, !ANY && (fl__ & 0x80000000u) != 0, t, u, v);                \
+                if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                        \
+                if ((fl__ & 1u) != 0) {                                                                               \
+                    adv__ = 2;                                                                                        \
+                    if (!(ANY && h)) {                                                                                \
+                        cn.add(C_TRI);                                                                                \
+                        const bool hb__ = tri_test(a, c, e, o, d, tmin, best_t, !ANY && (fl__ & 0x40000000u) != 0, t, u, v); \
+                        if (hb__) { best_t = t; best_tri = tri + 1; best_u = u; best_v = v; }                         \
+                        h = h || hb__;                                                                                \
+                    }                                                                                                 \
+                }                                                                                                     \
+            } else {                                                                                                  \
+                const size_t base = (size_t)tri * 4;                                                                  \
+                const float4 a = ldq(S.tris, base), b = ldq(S.tris, base + 1), c = ldq(S.tris, base + 2);             \
+                bool cull = false;                                                                                    \
+                if (!ANY) {                                                                                           \
+                    /* emitter flag lives in quad 3; only fetched for closest-hit rays (single-sided emitters, q16) */ \
+                    cull = (__float_as_uint(ldq(S.tris, base + 3).w) & 0x80000000u) != 0;                             \
+                }                                                                                                     \
+                h = tri_test(a, b, c, o, d, tmin, best_t, cull, t, u, v);                                             \
+                if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                        \
+            }                                                                                                         \
             if (ANY && h) {                                                                                           \
                 node = kTravDone;                                                                                     \
             } else {                                                                                                  \
-                node -= 1;  /* ~(tri + 1) */                                                                          \
-                leaf_count -= 1;                                                                                      \
+                node -= adv__;  /* ~(tri + 1) */                                                                      \
+                leaf_count -= adv__;                                                                                  \
                 if (leaf_count == 0) SPC_TRAV_POP_(POP);                                                              \
             }                                                                                                         \
         }                                                                                                             \

@@ -82,14 +82,22 @@ int main(int argc, char** argv) {
     std::mt19937 rng(seed);
     std::uniform_real_distribution<float> U(0.0f, 1.0f);
     std::vector<float> V; std::vector<uint32_t> I; std::vector<int32_t> M; std::vector<uint8_t> E;
+    int n_quads = 0;
     for (int t = 0; t < n; t++) {
         // clustered small triangles plus a few large ones and exact duplicates (coincident centroids)
         float c[3] = {U(rng) * 10, U(rng) * 3, U(rng) * 10};
         float s = (t % 97 == 0) ? 3.0f : 0.05f;
         if (t % 50 == 1 && t > 0) { for (int k = 0; k < 9; k++) V.push_back(V[V.size() - 9]); }
+        else if (t % 5 == 2 && t > 0) {   // the second half of a quad: (P0, P2 of the triangle before, a new corner) -- a fan pair (lbvh.h)
+            const size_t a = V.size() - 9;
+            for (int k = 0; k < 3; k++) V.push_back(V[a + k]);
+            for (int k = 0; k < 3; k++) V.push_back(V[a + 6 + k]);
+            for (int k = 0; k < 3; k++) V.push_back(V[a + k] + V[a + 6 + k] - V[a + 3 + k]);
+            n_quads++;
+        }
         else for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) V.push_back(c[k] + s * (U(rng) - 0.5f));
         for (int v = 0; v < 3; v++) I.push_back(3 * t + v);
-        M.push_back(0); E.push_back(0);
+        M.push_back(0); E.push_back((uint8_t)(t % 5 == 2 || t % 5 == 1 ? (t / 5) % 2 : 0));
     }
     HostMesh m; m.vertices = V.data(); m.indices = I.data(); m.tri_material = M.data(); m.tri_emitter = E.data();
     m.n_vertices = 3 * n; m.n_triangles = n;
@@ -104,6 +112,46 @@ int main(int argc, char** argv) {
     std::vector<int> perm(out.tri_orig.begin(), out.tri_orig.end());
     std::sort(perm.begin(), perm.end());
     for (int i = 0; i < n; i++) if (perm[i] != i) c.ok = false;
+    // the triangle records still belong to the triangles tri_orig names (make_fan_pairs reorders inside leaves) ...
+    for (int i = 0; i < n; i++) {
+        const float* tr = &out.tris[(size_t)i * 16];
+        const float* src = &V[(size_t)9 * out.tri_orig[i]];
+        for (int v = 0; v < 3; v++) if (memcmp(tr + 4 * v, src + 3 * v, 12) != 0) { c.ok = false; printf("record %d is not triangle %d\n", i, out.tri_orig[i]); break; }
+    }
+    // ... and the pair slots (lbvh.h: Lbvh::pairs): a slot flagged "pair" holds (A.P0, A.P1, A.P2, B.P2) of triangles i, i + 1 of ONE
+    // leaf with B = (A.P0, A.P2, B.P2) bit for bit and both culling flags; every other slot holds its own triangle
+    {
+        std::vector<int> leaf_of((size_t)n, -1);
+        int leaf_id = 0;
+        for (size_t nd = 0; nd < out.nodes.size() / 16; nd++)
+            for (int k = 0; k < 4; k++) {
+                uint32_t ref; memcpy(&ref, &out.nodes[nd * 16 + 10 + k], 4);
+                if (!(ref & 0x80000000u)) continue;
+                for (uint32_t t = (ref & 0x7fffffffu) >> 3, e = t + (ref & 7u); t < e && t < (uint32_t)n; t++) leaf_of[t] = leaf_id;
+                leaf_id++;
+            }
+        int pairs = 0;
+        if ((int)out.pairs.size() != 16 * n) { c.ok = false; printf("pair slots: %zu floats for %d triangles\n", out.pairs.size(), n); }
+        for (int i = 0; c.ok && i < n; i++) {
+            const float* q = &out.pairs[(size_t)i * 16];
+            const float* a = &out.tris[(size_t)i * 16];
+            uint32_t fl, ma; memcpy(&fl, q + 15, 4); memcpy(&ma, a + 15, 4);
+            bool good = memcmp(q, a, 12) == 0 && memcmp(q + 4, a + 4, 12) == 0 && memcmp(q + 8, a + 8, 12) == 0 && ((fl ^ ma) & 0x80000000u) == 0;
+            if (fl & 1u) {
+                pairs++;
+                if (i + 1 >= n || leaf_of[i + 1] != leaf_of[i] || (i > 0 && (([&] { uint32_t p; memcpy(&p, &out.pairs[(size_t)(i - 1) * 16 + 15], 4); return p & 1u; })()))) good = false;
+                else {
+                    const float* b = &out.tris[(size_t)(i + 1) * 16];
+                    uint32_t mb; memcpy(&mb, b + 15, 4);
+                    good = good && memcmp(b, a, 12) == 0 && memcmp(b + 4, a + 8, 12) == 0 && memcmp(q + 12, b + 8, 12) == 0 && ((fl >> 30) & 1u) == (mb >> 31);
+                }
+            } else good = good && (fl & 0x7fffffffu) == 0;
+            if (!good) { c.ok = false; printf("pair slot %d is wrong (flags %08x)\n", i, fl); }
+        }
+        if (out.n_paired != 2 * pairs) { c.ok = false; printf("n_paired %d, slots flagged %d\n", out.n_paired, pairs); }
+        // the halves of a quad share a bounding box, so the builder rarely separates them: most of the quads made above end up paired
+        if (n >= 700 && pairs * 2 < n_quads) { c.ok = false; printf("only %d of %d quads paired\n", pairs, n_quads); }
+    }
     // every node is reachable exactly once (the walk counts them), and the first HOT_NODES records are the hottest-first crown of the
     // tree (lbvh.cpp: hot_nodes_first): node 0 is the root, the parent of a hot node is hot and comes before it, and no node outside
     // the crown has a larger box than the crown's last (the crown is the top of the area order, ties aside)

@@ -27,8 +27,8 @@ ARGS = "EEEvNS_7KParamsE"
 # <COUNT, BATCH, CACHE, ENV>: the timed forms (COUNT = false, CACHE = true)
 TIMED = {"single frame, plain scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS, "batched, plain scene (bench.py)": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS,
          "single frame, general scene": "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS, "batched, general scene": "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS}
-PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 14226, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13418,
-                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 16281, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 15613}   # profiles/r05i_*
+PROFILED_INSTRUCTIONS = {"_ZN3spc8k_spcbptILb0ELb0ELb1ELb0" + ARGS: 14431, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb0" + ARGS: 13624,
+                         "_ZN3spc8k_spcbptILb0ELb0ELb1ELb1" + ARGS: 16484, "_ZN3spc8k_spcbptILb0ELb1ELb1ELb1" + ARGS: 15818}   # profiles/r06* (round 5: 14 226 / 13 418 / 16 281 / 15 613; + the pair half of the triangle step)
 
 
 def _traversal_loops(lines, quad=False, fan=False):
@@ -129,7 +129,7 @@ def test_timed_megakernel_resources(code_object, form):
     size, stores, loads = loops[0]
     assert stores == 0, report                                       # nothing is spilled inside the loop ...
     assert loads <= 6, report                                        # ... and the only reloads are the HBM stack area's base in the (rare) sp >= 16 path
-    assert 1000 <= size <= 1250, report                              # 1 110-1 130 instructions: the step twice (LDS-only stack operations / with the HBM part), ~560 executed per iteration
+    assert 1000 <= size <= 1500, report                              # ~1 400 instructions: the step twice (LDS-only stack operations / with the HBM part), each with the two triangle tests of a fan pair (round 6; 1 110-1 130 with one test per step)
     # ... and the quad tail's loop (four lanes per ray: the loop around a DPP quad_perm and a single node-record fetch) spills nothing either
     tail = d["quad_tail_loop"]
     assert tail and tail[0][1] == 0 and tail[0][2] == 0 and tail[0][0] <= 500, report   # 441-457 instructions (node + leaf step of up to 16 rays)

@@ -26,8 +26,9 @@ static float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 static V3 norm(V3 a) { float l = std::sqrt(dot(a, a)); return a * (1.0f / l); }
 
+static uint64_t g_depth_ray[64], g_depth_step[64];   // stack depth: per ray its maximum, per step (node visit) the entries held -- what an N-entry LDS stack would have to spill
 static std::vector<uint64_t> g_visits;   // per node: how often it was visited (top-of-tree share, printed at the end)
-struct Stats { double nodes = 0, tris = 0, leaves = 0, rays = 0, hits = 0, leaves_exact = 0, tris_exact = 0; };   // *_exact: leaf visits / tests left if the leaf's child box were the exact bounds of its triangles
+struct Stats { double nodes = 0, tris = 0, leaves = 0, rays = 0, hits = 0, leaves_exact = 0, tris_exact = 0, tri_steps = 0; };   // tri_steps: triangle steps of a lane when a fan pair is one step (Lbvh::pairs)   // *_exact: leaf visits / tests left if the leaf's child box were the exact bounds of its triangles
 
 static bool tri_hit(const float* q, V3 o, V3 d, float tmin, float tmax, float& t) {
     V3 v0{q[0], q[1], q[2]}, v1{q[4], q[5], q[6]}, v2{q[8], q[9], q[10]};
@@ -54,7 +55,10 @@ static bool traverse(const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any
     const float inv[3] = {1.0f / (std::fabs(d.x) > 1e-20f ? d.x : 1e-20f), 1.0f / (std::fabs(d.y) > 1e-20f ? d.y : 1e-20f), 1.0f / (std::fabs(d.z) > 1e-20f ? d.z : 1e-20f)};
     const float oo[3] = {o.x, o.y, o.z};
     st.rays++;
+    int sp_max = 0;
+    struct DepthNote { int& m; ~DepthNote() { g_depth_ray[std::min(m, 63)]++; } } note{sp_max};
     while (true) {
+        sp_max = std::max(sp_max, sp);
         if (cur & 0x80000000u) {
             if (cur != 0x80000000u) {
                 const int first = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
@@ -70,6 +74,9 @@ static bool traverse(const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any
                 }
                 for (int t = first; t < first + cnt; t++) {
                     st.tris++;
+                    uint32_t fl = 0, flp = 0;
+                    if (!B.pairs.empty()) { memcpy(&fl, &B.pairs[(size_t)t * 16 + 15], 4); if (t > first) memcpy(&flp, &B.pairs[(size_t)(t - 1) * 16 + 15], 4); }
+                    if (!(flp & 1u)) st.tri_steps++;   // the second half of a pair rides on its first half's step
                     float th;
                     if (tri_hit(&B.tris[(size_t)t * 16], o, d, tmin, best, th)) { best = th; hit = true; if (any) { st.hits++; return true; } }
                 }
@@ -79,6 +86,7 @@ static bool traverse(const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any
             continue;
         }
         st.nodes++;
+        g_depth_step[std::min(sp, 63)]++;
         if (!g_visits.empty()) g_visits[cur]++;
         uint32_t w[16];
         memcpy(w, &B.nodes[(size_t)cur * 16], sizeof(w));
@@ -163,6 +171,7 @@ int main(int argc, char** argv) {
         if (len > 1e-4f) traverse(B, P, dv * (1.0f / len), 1e-3f, len - 1e-3f, true, ss);
     }
     printf("nodes %zu  depth %d  build %.2f s\n", B.nodes.size() / 16, B.depth, build_s);
+    printf("steps per ray (node visits + triangle steps, a fan pair = one step): closest %.2f  shadow %.2f\n", (sc.nodes + sc.tri_steps) / sc.rays, (ss.nodes + ss.tri_steps) / ss.rays);
     printf("closest: node visits %.2f  leaf visits %.2f  triangle tests %.2f  hit rate %.3f   with exact leaf boxes: leaf visits %.2f  tests <= %.2f\n", sc.nodes / sc.rays, sc.leaves / sc.rays, sc.tris / sc.rays, sc.hits / sc.rays, sc.leaves_exact / sc.rays, sc.tris_exact / sc.rays);
     printf("shadow : node visits %.2f  leaf visits %.2f  triangle tests %.2f  occluded %.3f   with exact leaf boxes: leaf visits %.2f  tests <= %.2f\n", ss.nodes / ss.rays, ss.leaves / ss.rays, ss.tris / ss.rays, ss.hits / ss.rays, ss.leaves_exact / ss.rays, ss.tris_exact / ss.rays);
     {   // how concentrated the visits are: share of all node visits that go to the K most visited nodes (what a K-node LDS copy would
@@ -177,6 +186,17 @@ int main(int argc, char** argv) {
             double hot = 0, first = 0;
             for (int i = 0; i < K && i < (int)v.size(); i++) { hot += (double)sorted[i]; first += (double)v[i]; }
             printf("  K=%d %.3f/%.3f", K, hot / total, first / total);
+        }
+        printf("\n");
+    }
+    {   // traversal-stack depth (entries held): cumulative share of the rays whose maximum / of the node visits made at depth <= N
+        double rays = 0, steps = 0;
+        for (int i = 0; i < 64; i++) { rays += (double)g_depth_ray[i]; steps += (double)g_depth_step[i]; }
+        printf("stack depth <= N: rays (their maximum) / node visits:");
+        double cr = 0, cs = 0;
+        for (int i = 0; i < 64; i++) {
+            cr += (double)g_depth_ray[i]; cs += (double)g_depth_step[i];
+            if (i == 3 || i == 5 || i == 7 || i == 9 || i == 11 || i == 13 || i == 15 || i == 19) printf("  N=%d %.4f/%.4f", i, cr / rays, cs / steps);
         }
         printf("\n");
     }

@@ -621,6 +621,9 @@ typedef struct spcbpt_viewer_state {
 } spcbpt_viewer_state;
 int spcbpt_viewer_create(spcbpt_ctx* ctx, const float eye[3], const float lookat[3], const float up[3], float fov_y,
                          int width, int height, spcbpt_viewer** out);
+/* Either order of tear-down is safe (round 6): spcbpt_destroy(ctx) tells the context's live viewers, which go on as state machines
+ * without a context (events and frames still advance their state, nothing is launched); destroying the viewer first hands the
+ * context back as spcbpt_viewer_create found it. */
 void spcbpt_viewer_destroy(spcbpt_viewer* v);
 int spcbpt_viewer_mouse_button(spcbpt_viewer* v, int button, int action, double x, double y);
 int spcbpt_viewer_cursor_pos(spcbpt_viewer* v, double x, double y);

@@ -150,6 +150,10 @@ int spcbpt_create(const spcbpt_scene_desc* sc, int device, spcbpt_ctx** out) {
     // loop and the shading read) live in an allocation of their own.
     CREATE_TRY(dev_alloc(&c->d_nodes, bvh.nodes.size() + bvh.pairs.size()));
     CREATE_TRY(dev_alloc(&c->d_tris, bvh.tris.size()));
+    if (getenv("SPCBPT_NO_TRI_PAIRS")) {   // test switch: every slot a single triangle (the same device code, one test per step): films must not change
+        for (size_t i = 0; i < bvh.pairs.size() / 16; i++) { uint32_t fl; memcpy(&fl, &bvh.pairs[i * 16 + 15], 4); fl &= 0x80000000u; memcpy(&bvh.pairs[i * 16 + 15], &fl, 4); }
+        bvh.n_paired = 0;
+    }
     CREATE_TRY(hipMemcpy(c->d_nodes + bvh.nodes.size(), bvh.pairs.data(), bvh.pairs.size() * 4, hipMemcpyHostToDevice));
     c->n_paired = bvh.n_paired;
     CREATE_TRY(dev_alloc(&c->d_tri_orig, bvh.tri_orig.size()));

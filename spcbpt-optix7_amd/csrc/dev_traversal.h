@@ -116,9 +116,11 @@ SPC_DEV bool slab(float4 lo, float4 hi, f3 o, f3 inv, float tmin, float tmax, fl
 SPC_DEV f3 cross_fma(f3 a, f3 b) {
     return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
+// EDGES = true: q1, q2 hold the edges P1 - P0, P2 - P0 already (the pair slots of lbvh.h: the same FP32 differences, taken on the host)
+template <bool EDGES = false>
 SPC_DEV bool tri_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float tmin, float tmax, bool cull, float& ot, float& ou, float& ov) {
     const f3 v0 = mk3(q0.x, q0.y, q0.z);
-    const f3 e1 = mk3(q1.x, q1.y, q1.z) - v0, e2 = mk3(q2.x, q2.y, q2.z) - v0;
+    const f3 e1 = EDGES ? mk3(q1.x, q1.y, q1.z) : mk3(q1.x, q1.y, q1.z) - v0, e2 = EDGES ? mk3(q2.x, q2.y, q2.z) : mk3(q2.x, q2.y, q2.z) - v0;
     const f3 p = cross_fma(d, e2);
     const float det = dot(e1, p);
     if (det == 0.0f || (cull && det < 0.0f)) return false;
@@ -300,13 +302,13 @@ SPC_DEV bool traverse(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, f3 
                 const size_t base = ((size_t)(uint32_t)S.tri_base + (size_t)tri) * 4;                                 \
                 const float4 a = ldq(S.nodes, base), b = ldq(S.nodes, base + 1), c = ldq(S.nodes, base + 2), e = ldq(S.nodes, base + 3); \
                 const uint32_t fl__ = __float_as_uint(e.w);                                                           \
-                h = tri_test(a, b, c, o, d, tmin, best_t, !ANY && (fl__ & 0x80000000u) != 0, t, u, v);                \
+                h = tri_test<true>(a, b, c, o, d, tmin, best_t, !ANY && (fl__ & 0x80000000u) != 0, t, u, v);                \
                 if (h) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                                        \
                 if ((fl__ & 1u) != 0) {                                                                               \
                     adv__ = 2;                                                                                        \
                     if (!(ANY && h)) {                                                                                \
                         cn.add(C_TRI);                                                                                \
-                        const bool hb__ = tri_test(a, c, e, o, d, tmin, best_t, !ANY && (fl__ & 0x40000000u) != 0, t, u, v); \
+                        const bool hb__ = tri_test<true>(a, c, e, o, d, tmin, best_t, !ANY && (fl__ & 0x40000000u) != 0, t, u, v); \
                         if (hb__) { best_t = t; best_tri = tri + 1; best_u = u; best_v = v; }                         \
                         h = h || hb__;                                                                                \
                     }                                                                                                 \
@@ -698,12 +700,12 @@ SPC_DEV void trace_pool(const DeviceScene& S, TravStack<BLOCK, STACK_LDS>& st, b
                     const bool pair__ = SPC_TRI_PAIRS && (fl__ & 1u) != 0;                                            \
                     const bool cull = closest && (fl__ & 0x80000000u) != 0;  /* single-sided emitters */              \
                     float t, u, v;                                                                                    \
-                    bool h = tri_test(R0, R1, R2, o, d, kEps, best_t, cull, t, u, v);                                 \
+                    bool h = tri_test<true>(R0, R1, R2, o, d, kEps, best_t, cull, t, u, v);                                 \
                     if (h && closest) { best_t = t; best_tri = tri; best_u = u; best_v = v; }                         \
                     if (pair__ && !(h && !closest)) {                                                                 \
                         cn.add(C_TRI);                                                                                \
                         if (COUNT) cn.add(C_U_TRI_LANES);                                                             \
-                        const bool hb__ = tri_test(R0, R2, R3, o, d, kEps, best_t, closest && (fl__ & 0x40000000u) != 0, t, u, v); \
+                        const bool hb__ = tri_test<true>(R0, R2, R3, o, d, kEps, best_t, closest && (fl__ & 0x40000000u) != 0, t, u, v); \
                         if (hb__ && closest) { best_t = t; best_tri = tri + 1; best_u = u; best_v = v; }              \
                         h = h || hb__;                                                                                \
                     }                                                                                                 \

@@ -9,11 +9,11 @@
 
 #include "device_lib.h"
 #include "eye_walk.h"
+#include "kernel_config.h"
 #include "kernels.h"
 
 namespace spc {
 
-static constexpr int BLOCK = 256;
 // The eye megakernel's block.  Its waves share nothing but the LDS copy of the hottest BVH nodes (s_hot below), and a CU holds 16 of
 // them whatever the block size (4 per SIMD at 128 VGPRs; 16 x (4 KB of stack + a 5 840-B pool record) = 155 KB of its 160 KB of
 // LDS): the larger the block, the fewer copies of that table share what is left -- 19 nodes in each of four 256-thread blocks, 38
@@ -34,9 +34,6 @@ static constexpr int BLOCK = 256;
 #ifndef SPC_PRIO_SHADE
 #define SPC_PRIO_SHADE 0
 #endif
-#ifndef SPC_PRIO_LIGHT
-#define SPC_PRIO_LIGHT 0   // ... of the light pass's waves (they share CUs with the eye megakernel when passes run ahead)
-#endif
 #ifndef SPC_JOINT_FIRST_STAGE
 #define SPC_JOINT_FIRST_STAGE 0   // 1 / 2: the first stages of a vertex's connections on one coarse fetch (below: measured, slower)
 #endif
@@ -56,15 +53,7 @@ static constexpr int EYE_HOT = HOT_NODES < 115 || SPC_EYE_BLOCK >= 512 ? HOT_NOD
 static constexpr int EYE_HOT = SPC_EYE_BLOCK >= 1024 ? 64 : (SPC_EYE_BLOCK >= 512 ? 38 : 19);   // node records [0, EYE_HOT) live in LDS
 #endif
 static_assert(EYE_HOT <= HOT_NODES, "the builder numbers HOT_NODES nodes first (layout.h)");
-static constexpr int STACK_LDS = kStackLds;  // LDS stack entries per lane; deeper entries spill (TravStack)
 static_assert(STACK_LDS >= 16, "the pooled connections publish 16 dwords per eye vertex through the traversal-stack LDS");
-#ifndef SPC_WAVES
-// minimum waves per SIMD requested from the register allocator for the other kernels of this file.  4 like the eye kernel, and for
-// its sake: with three 128-VGPR eye blocks resident on a CU, 128 registers per lane are what is left -- a light-pass block that
-// wants 154 would only fit on CUs holding two eye blocks or fewer and starve next to a persistent eye kernel (measured: the step
-// got SLOWER with the faster eye kernel until the light pass was compiled to fit)
-#define SPC_WAVES 4
-#endif
 #ifndef SPC_EYE_WAVES
 // ... and for the eye megakernel.  Measured on MI355X (bedroom 1080p, ms per frame).  With the pooled if-if traversal, one frame
 // per launch: 2 (241 VGPR, no scratch) -> 12.86, 3 (168 VGPR, 252 B scratch) -> 10.72, 4 (128 VGPR, 452 B) -> 11.01,
@@ -758,913 +747,6 @@ __global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_pt(const KParams p) {
     cn.flush(p.counters);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Light pass.  A core walks m_per_core light paths and fills its own padded slot range, exactly the launch geometry of
-// LightTraceParams; the MI355X default is num_core = M, m_per_core = 1 (one path per core).  Persistent waves with per-lane
-// regeneration, like the eye pass: a lane whose core is finished takes the next core of a global queue at once (one atomic
-// per wave and refill), and every iteration of the wave advances all live paths by one segment.  Light paths end after 2.6
-// vertices on average but may run for 50, so one core per lane for the whole launch kept a wave resident for its longest
-// path with 1-2 live lanes; regenerating waves do the same work with a quarter of the resident blocks, which matters because
-// the pass shares the GPU with persistent eye kernels that never yield a block slot.  What a core computes and where it
-// stores it does not depend on the lane that runs it: seeds come from the global core index, slots from the core's range.
-template <bool COUNT, bool CACHE>
-__global__ __launch_bounds__(BLOCK, SPC_WAVES) void k_light_trace(const KParams p) {
-    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    if (SPC_PRIO_LIGHT) __builtin_amdgcn_s_setprio(SPC_PRIO_LIGHT);
-    const DeviceScene& S = p.scene;
-    const uint32_t lane = threadIdx.x & 63;
-    Counts<COUNT> cn;
-    cn.clear();
-    TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)blockIdx.x * BLOCK + threadIdx.x, p.diag);
-    int paths_started = 0;
-    // per-core state
-    bool has_core = false, exhausted = false;
-    int local_core = 0, nverts = 0, npaths = 0, origins = 0;
-    uint32_t seed = 0, pseed = 0;
-    LightVertex* slots = nullptr;
-    const bool batched = p.n_lframes > 0;   // several frames' passes in one queue (each lane then counts its cores' paths with one atomic per core)
-    const uint32_t queue_len = batched ? (uint32_t)p.core_count * (uint32_t)p.n_lframes : (uint32_t)p.core_count;
-    int fk = 0;   // frame of the lane's core within a batched pass
-    // per-path state
-    bool in_path = false;
-    f3 origin = mk3(0.0f), dir = mk3(0.0f), next_flux = mk3(0.0f);
-    float next_single_pdf = 0.0f;
-    int depth = 0;
-    uint32_t path_id = 0;
-    LightVertex last;
-    uint32_t pool_base = 0;
-    int pool_left = 0;
-    auto store = [&](const LightVertex& v) {
-        float4* dst = reinterpret_cast<float4*>(slots + nverts);
-        const float4* src = reinterpret_cast<const float4*>(&v);
-#pragma unroll
-        for (int q = 0; q < 6; q++) dst[q] = src[q];
-        nverts++;
-        cn.add(C_LVCW);
-    };
-    auto core_done = [&]() {   // the lane's core is complete: its vertex count, and the paths it started
-        if (batched) {
-            p.core_counts[(size_t)fk * (p.core_count + 1) + local_core] = nverts;
-            atomicAdd(p.path_counter + fk, origins);
-        } else { p.core_counts[local_core] = nverts; paths_started += origins; }
-    };
-    while (true) {
-        // ---- regeneration: cores of the queue to lanes without one
-        unsigned long long idle = __ballot(!has_core);
-        while (idle != 0ull && !exhausted) {
-            if (pool_left == 0) {
-                uint32_t t = 0;
-                if (lane == (uint32_t)__ffsll((long long)idle) - 1u) t = atomicAdd(p.work_counter, 64u);
-                t = __shfl(t, __ffsll((long long)idle) - 1, 64);
-                if (t >= queue_len) { exhausted = true; break; }
-                pool_base = t;
-                pool_left = min(64, (int)(queue_len - t));
-            }
-            const int n_idle = __popcll(idle);
-            const int take = n_idle < pool_left ? n_idle : pool_left;
-            const int my_rank = __popcll(idle & ((1ull << lane) - 1ull));
-            if (!has_core && my_rank < take) {
-                local_core = (int)pool_base + my_rank;
-                has_core = true;
-                uint32_t launch_frame = p.launch_frame;
-                LightVertex* scratch = p.lvc_scratch;
-                if (batched) {   // the queue spans the passes of n_lframes frames (layout.h: n_lframes)
-                    fk = local_core / p.core_count;
-                    local_core -= fk * p.core_count;
-                    launch_frame += (uint32_t)fk;
-                    scratch += (size_t)fk * p.core_count * p.core_padding;
-                }
-                const int core = p.core_begin + local_core;
-                seed = tea4((uint32_t)core, launch_frame);  // light sampling stream
-                // payload.seed: BSDF stream; the reference starts it equal to `seed`
-                pseed = p.lt_decorrelate ? tea4((uint32_t)core ^ 0x80000000u, launch_frame) : seed;
-                slots = scratch + (size_t)local_core * p.core_padding;
-                nverts = 0; npaths = 0; origins = 0;
-                in_path = false;
-            }
-            pool_base += (uint32_t)take;
-            pool_left -= take;
-            idle = __ballot(!has_core);
-        }
-        if (!__any(has_core)) break;   // queue exhausted and every core of the wave finished
-        // ---- a core without a running path starts its next one: light sample + origin vertex (raygen.cu:620-668)
-        if (has_core && !in_path) {
-            const int lid = pick_light(S, seed);
-            const DLight& L = S.lights[lid];
-            LightSampleD ls;
-            float dir_pdf;
-            uint32_t origin_flags = 0u;
-            if (L.type == 1) {   // the environment map: a sky direction, the sub-path starts on the sky disk and runs against it
-                ls = env_light_sample(S, seed, dir_pdf);
-                dir = ls.normal;
-                origin_flags = SPCBPT_LV_DIRECTION;
-            } else {
-                const float r1 = rnd(seed), r2 = rnd(seed);
-                ls = light_reverse_sample(S, L, r1, r2);
-                const float d1 = rnd(seed), d2 = rnd(seed);  // traceMode
-                const Onb onb(ls.normal);
-                dir = onb.to_world(cosine_sample_hemisphere(d1, d2));
-                dir_pdf = fabsf(dot(dir, ls.normal)) * kInvPi;
-            }
-            origin = ls.position;
-            path_id = (uint32_t)(p.core_begin + local_core) * (uint32_t)p.m_per_core + (uint32_t)npaths;
-            cn.add(C_LIGHT);
-            // origin vertex (init_vertex_from_lightSample raygen.cu:172-195)
-            LightVertex v;
-            v.position[0] = ls.position.x; v.position[1] = ls.position.y; v.position[2] = ls.position.z; v.pdf = ls.pdf;
-            v.normal[0] = ls.normal.x; v.normal[1] = ls.normal.y; v.normal[2] = ls.normal.z; v.single_pdf = ls.pdf;
-            v.flux[0] = ls.emission.x; v.flux[1] = ls.emission.y; v.flux[2] = ls.emission.z; v.rmis_pointer = 1.0f;
-            v.color[0] = v.color[1] = v.color[2] = 0.0f; v.last_lum = 0.0f;
-            v.last_position[0] = v.last_position[1] = v.last_position[2] = 0.0f; v.last_normal_projection = 0.0f;
-            v.material_id = (int16_t)L.id; v.subspace_id = (int16_t)ls.subspace; v.depth = 0; v.last_zone_id = 0;
-            v.path_id = path_id; v.pad = origin_flags;
-            store(v);
-            origins++;
-            last = v;
-            next_flux = mk3(0.0f);
-            next_single_pdf = dir_pdf;
-            depth = 0;
-            in_path = nverts < p.core_padding;   // a full slot range ends the core right after the origin vertex
-            if (!in_path) { core_done(); has_core = false; }
-        }
-        // ---- one segment of every running path (hit_program.cu:341-438)
-        const bool tracing = has_core && in_path;
-        HitRec h;
-        h.tri = -1;
-        if (tracing) {
-            cn.add(C_CLOSEST);
-            traverse<false, COUNT>(S, st, origin, dir, kEps, 1e16f, h, cn);
-        }
-        if (tracing) {
-            bool done = false, full = false;
-            if (h.tri < 0) { done = true; }
-            else {
-                const Geom g = local_geometry(S, h);
-                if (g.emitter) { done = true; }  // __closesthit__lightSource_subpath
-                else {
-                    Pbr pbr = load_pbr(S, g.mat);
-                    color_tex_sample(S, g, pbr, cn);
-                    f3 N = g.N;
-                    if (dot(N, dir) > 0.f) N = -N;
-                    const f3 inv_dir = -dir;
-                    const f3 new_dir = bsdf_sample(pbr, N, inv_dir, pseed);
-                    const float pdf = bsdf_pdf(pbr, N, inv_dir, new_dir);
-                    if (!(pdf > 0.0f)) done = true;
-                    const f3 last_n = ld3(last.normal), last_flux = ld3(last.flux);
-                    const bool last_dir = (last.pad & SPCBPT_LV_DIRECTION) != 0u;   // LastVertex.is_DIRECTION(): parallel rays from the sky, no 1 / t^2 (hit_program.cu:372-375)
-                    const float pdf_G = last_dir ? fabsf(dot(N, dir) * dot(last_n, dir)) : fabsf(dot(N, dir) * dot(last_n, dir)) / (h.t * h.t);
-                    const f3 flux = last.depth == 0 ? last_flux * pdf_G : next_flux * last_flux * pdf_G;
-                    LightVertex m;
-                    m.position[0] = g.P.x; m.position[1] = g.P.y; m.position[2] = g.P.z;
-                    m.normal[0] = N.x; m.normal[1] = N.y; m.normal[2] = N.z;
-                    m.flux[0] = flux.x; m.flux[1] = flux.y; m.flux[2] = flux.z;
-                    m.color[0] = pbr.base.x; m.color[1] = pbr.base.y; m.color[2] = pbr.base.z;
-                    m.last_position[0] = last.position[0]; m.last_position[1] = last.position[1]; m.last_position[2] = last.position[2];
-                    if (last_dir) { const f3 lp = g.P - dir; m.last_position[0] = lp.x; m.last_position[1] = lp.y; m.last_position[2] = lp.z; }   // hit_program.cu:386-389
-                    m.last_normal_projection = fabsf(dot(last_n, dir));
-                    m.material_id = (int16_t)g.mat;
-                    // light-tree label of the new vertex and eye-tree relabel of the previous one (tracing_weight_light) in lock-step
-                    int new_label, eye_label;
-                    const f3 last_pos = ld3(last.position);
-                    uint32_t own_eye_label = 0u;   // device_lib.h: label caching -- the new vertex's own eye-tree label + 1
-                    if (CACHE) {
-                        int own;
-                        tree_label2<COUNT, true>(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, g.P, N, inv_dir, true, new_label, own, cn);
-                        own_eye_label = (uint32_t)own + 1u;
-                        eye_label = (int)(last.pad & 0xffffu) - 1;   // the previous vertex's, cached when it was created (unused when it is the origin)
-                    } else {
-                        tree_label2(p.light_tree, g.P, N, inv_dir, true, p.eye_tree, last_pos, last_n, normalize(g.P - last_pos), last.depth != 0,
-                                    new_label, eye_label, cn);
-                    }
-                    m.subspace_id = (int16_t)new_label;
-                    m.last_zone_id = last.subspace_id;
-                    m.depth = (int16_t)(last.depth + 1);
-                    m.single_pdf = next_single_pdf * pdf_G / fabsf(dot(last_n, dir));
-                    m.pdf = last.pdf * m.single_pdf;
-                    m.last_lum = sum3(last_flux / last.pdf);
-                    m.path_id = path_id; m.pad = own_eye_label | (last_dir ? SPCBPT_LV_LAST_DIRECTION : 0u);   // isLastVertex_direction (hit_program.cu:412: the predecessor is the origin)
-                    if (last.depth == 0) {
-                        m.rmis_pointer = last.rmis_pointer / last.single_pdf;  // tracing_init_light
-                    } else {  // tracing_update_light (rmis.h:80-94)
-                        const VCore lc = core_of(last);
-                        const Pbr mat_last = load_pbr_colored(S, lc.mat, lc.color);
-                        const f3 in_dir = normalize(g.P - lc.pos);
-                        const float LL_pdf = rmis_last_pdf(mat_last, lc, in_dir);
-                        const float wgt = rmis_weight_light_l(p, last.last_zone_id, last.last_lum, eye_label, cn);
-                        m.rmis_pointer = (last.rmis_pointer * LL_pdf + wgt) / last.single_pdf;
-                    }
-                    cn.add(C_VERTEX);
-                    next_flux = brdf_div(pbr, bsdf_eval(pbr, N, inv_dir, new_dir), N, new_dir);   // hit_program.cu:384
-                    next_single_pdf = pdf;
-                    origin = g.P;
-                    dir = new_dir;
-                    const float r = rnd(pseed);
-                    const float rr = rr_of(pbr.base);
-                    if (r > rr) done = true;
-                    else next_single_pdf *= rr;
-                    store(m);
-                    last = m;
-                    if (!(nverts < p.core_padding)) full = true;
-                }
-            }
-            // the walk loop's exit tests (raygen.cu:646-676): slot range full -> the core ends; path done or too deep -> next path
-            bool path_over = full;
-            if (!full) {
-                if (done || depth > 50) path_over = true;
-                else depth += 1;
-            }
-            if (path_over) {
-                in_path = false;
-                bool core_over = full;
-                if (!full) {
-                    npaths++;
-                    if (npaths >= p.m_per_core || !(nverts < p.core_padding)) core_over = true;
-                }
-                if (core_over) { core_done(); has_core = false; }
-            }
-        }
-    }
-    // path_count of the sampler (#depth-0 vertices, device_thrust.cu:324-326): one atomic per wave
-    for (int o = 32; o > 0; o >>= 1) paths_started += __shfl_down(paths_started, o, 64);
-    if (lane == 0 && paths_started) atomicAdd(p.path_counter, paths_started);
-    cn.flush(p.counters);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Sampler build on device (LVC_Process).  Input: padded scratch + per-core counts.  Steps:
-//   1. exclusive scan of core_counts (hipcub)                       -> core_offsets, vertex_count
-//   2. k_lvc_compact: copy to the compact LVC in (core, slot) order, emit key = subspace id, weight, path starts
-//   3. stable radix sort of (subspace id -> compact index) (hipcub)  -> jump_buffer
-//   4. k_subspace_ranges: first/last position of each subspace in the sorted keys -> jump_bias, size
-//   5. inclusive scan (double) of the weights in sorted order (hipcub), k_cmf: per-subspace normalised CMF
-__global__ void k_lvc_compact(const LightVertex* __restrict__ scratch, const int* __restrict__ core_counts,
-                              const int* __restrict__ core_offsets, int core_count, int core_padding, LightVertex* __restrict__ lvc,
-                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, float* __restrict__ weights,
-                              int* __restrict__ sampler_counts, int capacity, uint32_t* __restrict__ overflow) {
-    // one thread per padded slot; only the filled slots (slot < count of its core) copy their 96-B record.  The compact cache holds
-    // `capacity` vertices (sized from a measured pass with slack, not from the padded worst case: context.h); a pass that outgrows
-    // it is cut off at the capacity and reported through *overflow (SPCBPT_ERR_CAPACITY at the next sync), never written past the end.
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0 && core_offsets[core_count] > capacity) { sampler_counts[0] = capacity; *overflow = 1u; }
-    if (t < (long long)core_count * core_padding) {
-        const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
-        if (slot < core_counts[core] && core_offsets[core] + slot < capacity) {
-            const int dst_i = core_offsets[core] + slot;
-            const float4* src = reinterpret_cast<const float4*>(scratch + t);
-            float4* dst = reinterpret_cast<float4*>(lvc + dst_i);
-            float4 q[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) q[k] = src[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) dst[k] = q[k];
-            const LightVertex& v = *reinterpret_cast<const LightVertex*>(q);
-            float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;  // LVCSubspaceInfoCopy device_thrust.cu:191-212
-            if (isinf(w) || isnan(w)) w = 0.0f;
-            keys[dst_i] = (uint32_t)v.subspace_id;
-            vals[dst_i] = (uint32_t)dst_i;
-            weights[dst_i] = w;
-        }
-    }
-}
-
-// Compaction of a batched light pass: grid.y = frame of the batch.  core_offsets is ONE exclusive scan over the n * (core_count + 1)
-// counts (each frame's segment ends in a zero sentinel), so frame k's offsets are relative to its first entry and its total is the
-// sentinel's offset minus that.  Keys are left to the sampler build (k_fill_keys_from_lvc), which also counts the paths again.
-__global__ void k_lvc_compact_batch(const LightVertex* __restrict__ scratch, const int* __restrict__ core_counts, const int* __restrict__ core_offsets,
-                                    const int* __restrict__ path_counts, int core_count, int core_padding, CompactBatch dst, int capacity,
-                                    uint32_t* __restrict__ overflow) {
-    const int k = blockIdx.y;
-    const int* counts = core_counts + (size_t)k * (core_count + 1);
-    const int* offs = core_offsets + (size_t)k * (core_count + 1);
-    const int base = offs[0];
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) {
-        const int total = offs[core_count] - base;
-        if (total > capacity) *overflow = 1u;   // k_lvc_compact: cut off at the set's capacity and reported
-        dst.counts[k][0] = min(total, capacity); dst.counts[k][1] = path_counts[k];
-    }
-    if (t < (long long)core_count * core_padding) {
-        const int core = (int)(t / core_padding), slot = (int)(t % core_padding);
-        if (slot < counts[core] && offs[core] - base + slot < capacity) {
-            const float4* src = reinterpret_cast<const float4*>(scratch + (size_t)k * core_count * core_padding + t);
-            float4* out = reinterpret_cast<float4*>(dst.lvc[k] + (offs[core] - base + slot));
-            float4 q[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++) q[j] = src[j];
-#pragma unroll
-            for (int j = 0; j < 6; j++) out[j] = q[j];
-        }
-    }
-}
-
-__global__ void k_fill_keys_from_lvc(const LightVertex* __restrict__ lvc, int n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                     float* __restrict__ weights, int* __restrict__ sampler_counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int start = 0;
-    if (i < n) {
-        const LightVertex& v = lvc[i];
-        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;
-        if (isinf(w) || isnan(w)) w = 0.0f;
-        keys[i] = (uint32_t)v.subspace_id;
-        vals[i] = (uint32_t)i;
-        weights[i] = w;
-        start = v.depth == 0 ? 1 : 0;
-    }
-    for (int o = 32; o > 0; o >>= 1) start += __shfl_down(start, o, 64);
-    if ((threadIdx.x & 63) == 0 && start) atomicAdd(&sampler_counts[1], start);
-}
-
-// The same with the item count on the DEVICE (sampler_counts[0]) and a host-known upper bound `bound` as the grid: slots beyond the
-// count get the pad key 1023 (no subspace id reaches it: ids are < 1000) and weight 0, so a 10-bit radix sort over `bound` items
-// leaves the real items sorted in front.  sampler_counts[1] (path count) is left as the caller set it.
-__global__ void k_fill_keys_devcount(const LightVertex* __restrict__ lvc, int bound, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                     float* __restrict__ weights, const int* __restrict__ sampler_counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= bound) return;
-    const int n = sampler_counts[0];
-    if (i < n) {
-        const LightVertex& v = lvc[i];
-        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;
-        if (isinf(w) || isnan(w)) w = 0.0f;
-        keys[i] = (uint32_t)v.subspace_id;
-        weights[i] = w;
-    } else {
-        keys[i] = 1023u;
-        weights[i] = 0.0f;
-    }
-    vals[i] = (uint32_t)i;
-}
-
-// Exchange 1 of a sharded job, receiving side: `gathered` holds `world` shards of `cap` slots each (the all-gather of every rank's
-// compact shard, padded to the agreed capacity), counts_all[2 r] / [2 r + 1] the vertex / path count of rank r.  The shards are
-// concatenated in rank order = global (path, depth) order into the set's LVC; the totals go to sampler_counts (device-resident:
-// the sampler build sizes itself from them, no host round trip).  A shard that did not fit `cap` raises *overflow.
-// Batched form (one exchange per light batch): grid.y = frame k of `nf`; rank q's block of the all-gather holds its nf shards one
-// after the other, so frame k of rank q sits at (q nf + k) cap and its counts at 2 (q nf + k); every frame goes to its own set (dst).
-__global__ void k_gather_compact(const LightVertex* __restrict__ gathered, const int* __restrict__ counts_all, int world, int cap, int lvc_capacity,
-                                 CompactBatch dst, int nf, int* __restrict__ overflow) {
-    const int chunks = (cap + 255) / 256;
-    const int r = blockIdx.x / chunks, c = blockIdx.x % chunks, k = blockIdx.y;
-    LightVertex* __restrict__ lvc = dst.lvc[k];
-    int* __restrict__ sampler_counts = dst.counts[k];
-    int base = 0, total = 0, paths = 0;
-    bool over = false;
-    for (int q = 0; q < world; q++) {
-        const int n = counts_all[2 * (q * nf + k)];
-        if (n > cap) over = true;
-        if (q < r) base += min(n, cap);
-        total += min(n, cap);
-        paths += counts_all[2 * (q * nf + k) + 1];
-    }
-    if (total > lvc_capacity) over = true;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        sampler_counts[0] = min(total, lvc_capacity);
-        sampler_counts[1] = paths;
-        if (over) *overflow = 1;
-    }
-    const int n_r = min(counts_all[2 * (r * nf + k)], cap);
-    const int i = c * 256 + (int)threadIdx.x;
-    if (i >= n_r || base + i >= lvc_capacity) return;
-    const float4* src = reinterpret_cast<const float4*>(gathered + ((size_t)r * nf + k) * cap + i);
-    float4* dst_q = reinterpret_cast<float4*>(lvc + base + i);
-    float4 q[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) q[j] = src[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) dst_q[j] = q[j];
-}
-// Sending side of the batched exchange: the first min(count, cap) vertices of nf sets and their count pairs into one contiguous
-// send buffer of nf x cap vertices (grid.y = frame).  The padding behind a shard is not copied (nobody reads it).
-__global__ void k_pack_shards(CompactBatch src, int cap, LightVertex* __restrict__ send, int* __restrict__ send_counts) {
-    const int k = blockIdx.y;
-    const int n = src.counts[k][0];
-    const int i = blockIdx.x * 256 + (int)threadIdx.x;
-    if (i == 0) { send_counts[2 * k] = n; send_counts[2 * k + 1] = src.counts[k][1]; }
-    if (i >= min(n, cap)) return;
-    const float4* in = reinterpret_cast<const float4*>(src.lvc[k] + i);
-    float4* out = reinterpret_cast<float4*>(send + (size_t)k * cap + i);
-    float4 q[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) q[j] = in[j];
-#pragma unroll
-    for (int j = 0; j < 6; j++) out[j] = q[j];
-}
-
-// film exchange of a sharded job: the 8-row bands of rank `rank` (band b with b % world == rank) packed contiguously / unpacked
-__global__ void k_pack_bands(const float4* __restrict__ accum, int width, int height, int rank, int world, float4* __restrict__ packed, int unpack_all) {
-    // unpack_all == 0: accum -> packed (own bands, band-major); != 0: packed (world x bands_per_rank x 8 x width) -> accum (every band)
-    const int bands = (height + 7) / 8, per_rank = (bands + world - 1) / world;
-    const size_t band_px = (size_t)8 * width;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (!unpack_all) {
-        if (t >= (size_t)per_rank * band_px) return;
-        const int k = (int)(t / band_px), b = rank + k * world;
-        const size_t in_band = t % band_px;
-        const int y = b * 8 + (int)(in_band / width), x = (int)(in_band % width);
-        packed[t] = (b < bands && y < height) ? accum[(size_t)y * width + x] : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-        if (t >= (size_t)world * per_rank * band_px) return;
-        const int r = (int)(t / ((size_t)per_rank * band_px));
-        const size_t tr = t % ((size_t)per_rank * band_px);
-        const int k = (int)(tr / band_px), b = r + k * world;
-        const size_t in_band = tr % band_px;
-        const int y = b * 8 + (int)(in_band / width), x = (int)(in_band % width);
-        if (b < bands && y < height) reinterpret_cast<float4*>(const_cast<float4*>(accum))[(size_t)y * width + x] = packed[t];
-    }
-}
-
-__global__ void k_subspace_ranges(const uint32_t* __restrict__ sorted_keys, const int* __restrict__ sampler_counts, DSubspace* __restrict__ sub) {
-    const int n = sampler_counts[0];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = sorted_keys[i];
-    if (i == 0 || sorted_keys[i - 1] != k) sub[k].jump_bias = i;
-    if (i == n - 1 || sorted_keys[i + 1] != k) sub[k].size = i + 1;  // temporarily the END position; fixed in k_finish_ranges
-}
-__global__ void k_finish_ranges(DSubspace* __restrict__ sub) {
-    // one block of 1024 threads: empty subspaces get jump_bias = end of the last non-empty one before them, like the
-    // running offset of the reference's host loop (device_thrust.cu:301-309) -> inclusive max-scan of the END positions
-    __shared__ int ends[1024];
-    const int s = threadIdx.x;
-    const int end = s < SPCBPT_NUM_SUBSPACE ? sub[s].size : 0;  // END position written by k_subspace_ranges, 0 if empty
-    ends[s] = end;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = s >= off ? ends[s - off] : 0;
-        __syncthreads();
-        ends[s] = max(ends[s], v);
-        __syncthreads();
-    }
-    if (s < SPCBPT_NUM_SUBSPACE) {
-        if (end > 0) sub[s].size = end - sub[s].jump_bias;
-        else { sub[s].jump_bias = s > 0 ? ends[s - 1] : 0; sub[s].size = 0; }
-    }
-}
-__global__ void k_gather_weights(const float* __restrict__ weights, const uint32_t* __restrict__ sorted_vals, const int* __restrict__ sampler_counts,
-                                 double* __restrict__ out) {
-    const int n = sampler_counts[0];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (double)weights[sorted_vals[i]];
-}
-__global__ void k_cmf(const double* __restrict__ prefix, const uint32_t* __restrict__ sorted_keys, const int* __restrict__ sampler_counts,
-                      DSubspace* __restrict__ sub, float* __restrict__ cmfs) {
-    const int n = sampler_counts[0];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = sorted_keys[i];
-    const int b = sub[k].jump_bias, e = b + sub[k].size;
-    const double base = b > 0 ? prefix[b - 1] : 0.0;
-    const double total = prefix[e - 1] - base;
-    const bool last = i == e - 1;
-    // sum_pmf == 0 gives NaN CMFs in the reference; guarded here: zero-weight subspaces sample uniformly
-    float c = total > 0.0 ? (float)((prefix[i] - base) / total) : (float)(i - b + 1) / (float)(e - b);
-    if (last) { c = 1.0f; sub[k].sum_pmf = (float)total; }
-    cmfs[i] = c;
-}
-
-// ---- sampler build in four launches ------------------------------------------------------------------------------------------
-// The build above is ~14 dependent launches (hipcub's radix sort and scan are five and two of them): 0.3 ms of launch latency
-// however few vertices it sorts, and a batched eye launch waits for up to 16 of them.  Subspace ids are 10-bit keys, so one stable
-// counting sort does: SB_BLOCKS single-wave blocks each own a contiguous chunk of the cache,
-//   k_sb_hist     per-block histogram of the ids (LDS), keys + weights (+ the path count) on the way
-//   k_sb_scan     one block: per-id running offsets over the blocks, exclusive scan over the ids -> jump_bias / size
-//   k_sb_scatter  each block places its chunk in order (rank among equal ids inside a wave from ten ballots) -> jump buffer,
-//                 weights in sorted order
-//   k_sb_cmf      one block per subspace: double-precision scan of its weights -> CMF, sum_pmf
-// Same tables as the sort: the order inside a subspace is the cache order (stable), empty subspaces carry the running offset.
-// The CMF sums a subspace's weights by themselves (the scan above takes differences of a global prefix): equal to 1e-16 relative.
-static constexpr int SB_BLOCKS = 512;
-// (blockIdx.y = frame of a batched build: SamplerBuildBatch, kernels.h; a single build is a batch of one)
-__global__ __launch_bounds__(64) void k_sb_hist(const SamplerBuildBatch B) {
-    const int f = blockIdx.y;
-    const LightVertex* __restrict__ lvc = B.lvc[f];
-    const int n_host = B.n_host[f];
-    const int* __restrict__ n_dev = B.n_dev[f];
-    uint32_t* __restrict__ keys = B.keys + (size_t)f * B.item_stride;
-    float* __restrict__ weights = B.weights + (size_t)f * B.item_stride;
-    int* __restrict__ hist = B.hist + (size_t)f * (SB_BLOCKS + 1) * 1024;
-    int* __restrict__ path_count = B.path_count[f];
-    __shared__ uint32_t h[1024];
-    const int lane = threadIdx.x, b = blockIdx.x;
-#pragma unroll
-    for (int t = 0; t < 16; t++) h[t * 64 + lane] = 0u;
-    __syncthreads();
-    const int n = n_dev ? n_dev[0] : n_host;
-    const int chunk = (n + SB_BLOCKS - 1) / SB_BLOCKS, i0 = b * chunk, i1 = min(n, i0 + chunk);
-    int starts = 0;
-    for (int i = i0 + lane; i < i1; i += 64) {
-        const LightVertex& v = lvc[i];
-        float w = (v.flux[0] + v.flux[1] + v.flux[2]) / v.pdf;   // LVCSubspaceInfoCopy device_thrust.cu:191-212
-        if (isinf(w) || isnan(w)) w = 0.0f;
-        const uint32_t k = (uint32_t)v.subspace_id & 1023u;
-        keys[i] = k;
-        weights[i] = w;
-        atomicAdd(&h[k], 1u);
-        starts += v.depth == 0 ? 1 : 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 16; t++) hist[(size_t)b * 1024 + t * 64 + lane] = (int)h[t * 64 + lane];
-    if (path_count) {
-        for (int o = 32; o > 0; o >>= 1) starts += __shfl_down(starts, o, 64);
-        if (lane == 0 && starts) atomicAdd(path_count, starts);
-    }
-}
-__global__ __launch_bounds__(1024) void k_sb_scan(const SamplerBuildBatch B) {
-    int* __restrict__ hist = B.hist + (size_t)blockIdx.y * (SB_BLOCKS + 1) * 1024;
-    DSubspace* __restrict__ sub = B.sub[blockIdx.y];
-    // thread = subspace id.  hist[b][id] becomes the number of items with that id in the blocks before b; row SB_BLOCKS receives the
-    // position of the id's first item = items with smaller ids: for an empty subspace the end of the last non-empty one before it,
-    // the running offset of the reference's host loop (device_thrust.cu:301-309)
-    __shared__ int tot[1024];
-    const int k = threadIdx.x;
-    int run = 0;
-#pragma unroll 8
-    for (int b = 0; b < SB_BLOCKS; b++) {
-        const int c = hist[(size_t)b * 1024 + k];
-        hist[(size_t)b * 1024 + k] = run;
-        run += c;
-    }
-    tot[k] = run;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = k >= off ? tot[k - off] : 0;
-        __syncthreads();
-        tot[k] += v;
-        __syncthreads();
-    }
-    const int base = tot[k] - run;   // exclusive
-    hist[(size_t)SB_BLOCKS * 1024 + k] = base;
-    if (k < SPCBPT_NUM_SUBSPACE) { sub[k].jump_bias = base; sub[k].size = run; sub[k].sum_pmf = 0.0f; sub[k].pad = 0; }
-}
-__global__ __launch_bounds__(64) void k_sb_scatter(const SamplerBuildBatch B) {
-    const int f = blockIdx.y;
-    const uint32_t* __restrict__ keys = B.keys + (size_t)f * B.item_stride;
-    const float* __restrict__ weights = B.weights + (size_t)f * B.item_stride;
-    const int n_host = B.n_host[f];
-    const int* __restrict__ n_dev = B.n_dev[f];
-    const int* __restrict__ hist = B.hist + (size_t)f * (SB_BLOCKS + 1) * 1024;
-    uint32_t* __restrict__ jump = B.jump[f];
-    double* __restrict__ wsorted = B.wsorted + (size_t)f * B.item_stride;
-    __shared__ uint32_t next[1024];   // where this block's next item of each id goes
-    const int lane = threadIdx.x, b = blockIdx.x;
-#pragma unroll
-    for (int t = 0; t < 16; t++) next[t * 64 + lane] = (uint32_t)(hist[(size_t)SB_BLOCKS * 1024 + t * 64 + lane] + hist[(size_t)b * 1024 + t * 64 + lane]);
-    __syncthreads();
-    const int n = n_dev ? n_dev[0] : n_host;
-    const int chunk = (n + SB_BLOCKS - 1) / SB_BLOCKS, i0 = b * chunk, i1 = min(n, i0 + chunk);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = i0; base < i1; base += 64) {   // wave-uniform bounds: every lane takes part in the ballots
-        const int i = base + lane;
-        const bool valid = i < i1;
-        const uint32_t k = valid ? keys[i] : 0u;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 10; bit++) {
-            const unsigned long long m = __ballot((k >> bit) & 1u);
-            peers &= ((k >> bit) & 1u) ? m : ~m;
-        }
-        uint32_t pos = 0u;
-        if (valid) pos = next[k];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lt) == 0ull) next[k] = pos + (uint32_t)__popcll(peers);   // the first lane of each id moves the cursor on
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const uint32_t dst = pos + (uint32_t)__popcll(peers & lt);
-            jump[dst] = (uint32_t)i;
-            wsorted[dst] = (double)weights[i];
-        }
-    }
-}
-// the cache in the sampler's order: record i = lvc[jump[i]], one lane per QUAD (six consecutive lanes read one 96-B vertex and write
-// its six quads next to each other: the stores of a wave are contiguous, the loads are whole records)
-__global__ __launch_bounds__(256) void k_sb_copy(const SamplerBuildBatch B) {
-    const int f = blockIdx.y;
-    float4* __restrict__ dst = reinterpret_cast<float4*>(B.lvc_sorted[f]);
-    if (!dst) return;
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(B.lvc[f]);
-    const uint32_t* __restrict__ jump = B.jump[f];
-    const int* __restrict__ n_dev = B.n_dev[f];
-    const long long n = n_dev ? n_dev[0] : B.n_host[f];
-    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n * 6; t += (long long)gridDim.x * 256) {
-        const long long i = t / 6;
-        const int q = (int)(t - i * 6);
-        dst[t] = src[(size_t)jump[i] * 6 + q];
-    }
-}
-// KParams::guide of one subspace: entry j = the first place k with cmf[k] > (j / n)(1 - 2^-20).  A random number u of bucket j --
-// (int)(u * (float)n) == j, the product rounded to FP32 -- is at least (j / n)(1 - 2^-24), so no entry before that place is above u.
-SPC_DEV void build_guide(const float* cmf, int n, uint32_t* guide, int t, int stride) {
-    for (int j = t; j < n; j += stride) {
-        const double tj = (double)j / (double)n * (1.0 - 1.0 / 1048576.0);
-        int lo = 0, hi = n - 1;   // (the last entry is 1)
-        while (lo < hi) {
-            const int m = (lo + hi) >> 1;
-            if ((double)cmf[m] > tj) hi = m; else lo = m + 1;
-        }
-        guide[j] = (uint32_t)lo;
-    }
-}
-__global__ __launch_bounds__(256) void k_sb_cmf(const SamplerBuildBatch B) {
-    DSubspace* __restrict__ sub = B.sub[blockIdx.y];
-    const double* __restrict__ wsorted = B.wsorted + (size_t)blockIdx.y * B.item_stride;
-    float* cmfs = B.cmfs[blockIdx.y];   // (read back for the guide table below: not __restrict__)
-    __shared__ double sh[256];
-    const int k = blockIdx.x, t = threadIdx.x;
-    const int b = sub[k].jump_bias, sz = sub[k].size;
-    if (sz <= 0) return;
-    double acc = 0.0;
-    for (int j = t; j < sz; j += 256) acc += wsorted[b + j];
-    sh[t] = acc;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if (t < off) sh[t] += sh[t + off]; __syncthreads(); }
-    const double total = sh[0];
-    __syncthreads();
-    double carry = 0.0;
-    for (int j0 = 0; j0 < sz; j0 += 256) {
-        const int j = j0 + t;
-        const double w = j < sz ? wsorted[b + j] : 0.0;
-        sh[t] = w;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const double v = t >= off ? sh[t - off] : 0.0;
-            __syncthreads();
-            sh[t] += v;
-            __syncthreads();
-        }
-        if (j < sz) {
-            // sum_pmf == 0 gives NaN CMFs in the reference; guarded here: zero-weight subspaces sample uniformly
-            float c = total > 0.0 ? (float)((carry + sh[t]) / total) : (float)(j + 1) / (float)sz;
-            if (j == sz - 1) c = 1.0f;
-            cmfs[b + j] = c;
-        }
-        carry += sh[255];
-        __syncthreads();
-    }
-    if (t == 0) sub[k].sum_pmf = (float)total;
-    if (B.guide[blockIdx.y]) build_guide(cmfs + b, sz, B.guide[blockIdx.y] + b, t, 256);   // (the loop above ends on a barrier: the block's CMF is written)
-}
-// the second-stage guide table next to a CMF that another path has written (the radix-sort build)
-__global__ __launch_bounds__(256) void k_sb_guide(const DSubspace* __restrict__ sub, const float* cmfs, uint32_t* __restrict__ guide) {
-    const int b = sub[blockIdx.x].jump_bias, sz = sub[blockIdx.x].size;
-    if (sz > 0) build_guide(cmfs + b, sz, guide + b, threadIdx.x, 256);
-}
-void launch_sampler_guide(const DSubspace* sub, const float* cmfs, uint32_t* guide, hipStream_t s) {
-    if (guide) hipLaunchKernelGGL(k_sb_guide, dim3(SPCBPT_NUM_SUBSPACE), dim3(256), 0, s, sub, cmfs, guide);
-}
-size_t sampler_build_hist_ints() { return (size_t)(SB_BLOCKS + 1) * 1024; }
-void launch_sampler_build_batch(const SamplerBuildBatch& b, int frames, hipStream_t s) {
-    if (frames <= 0) return;
-    hipLaunchKernelGGL(k_sb_hist, dim3(SB_BLOCKS, frames), dim3(64), 0, s, b);
-    hipLaunchKernelGGL(k_sb_scan, dim3(1, frames), dim3(1024), 0, s, b);
-    hipLaunchKernelGGL(k_sb_scatter, dim3(SB_BLOCKS, frames), dim3(64), 0, s, b);
-    hipLaunchKernelGGL(k_sb_cmf, dim3(SPCBPT_NUM_SUBSPACE, frames), dim3(256), 0, s, b);
-    hipLaunchKernelGGL(k_sb_copy, dim3(256, frames), dim3(256), 0, s, b);
-}
-__global__ __launch_bounds__(256) void k_lvc_sorted_copy(const LightVertex* __restrict__ lvc, const uint32_t* __restrict__ jump, const int* __restrict__ counts,
-                                                        LightVertex* __restrict__ out, int capacity) {
-    const int n = min(counts[0], capacity);
-    const float4* src = reinterpret_cast<const float4*>(lvc);
-    float4* dst = reinterpret_cast<float4*>(out);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const size_t from = jump[i];
-#pragma unroll
-        for (int q = 0; q < 6; q++) dst[(size_t)i * 6 + q] = src[from * 6 + q];
-    }
-}
-void launch_lvc_sorted_copy(const LightVertex* lvc, const uint32_t* jump, const int* sampler_counts, LightVertex* lvc_sorted, int capacity, hipStream_t s) {
-    if (capacity <= 0 || !lvc_sorted) return;
-    hipLaunchKernelGGL(k_lvc_sorted_copy, dim3(512), dim3(256), 0, s, lvc, jump, sampler_counts, lvc_sorted, capacity);
-}
-void launch_sampler_build(const LightVertex* lvc, int n_host, const int* n_dev, uint32_t* keys, float* weights, int* hist, int* path_count, DSubspace* sub,
-                          uint32_t* jump, double* wsorted, float* cmfs, LightVertex* lvc_sorted, uint32_t* guide, hipStream_t s) {
-    SamplerBuildBatch b = {};
-    b.guide[0] = guide;
-    b.lvc[0] = lvc; b.n_host[0] = n_host; b.n_dev[0] = n_dev; b.path_count[0] = path_count; b.sub[0] = sub; b.jump[0] = jump; b.cmfs[0] = cmfs;
-    b.lvc_sorted[0] = lvc_sorted;
-    b.keys = keys; b.weights = weights; b.hist = hist; b.wsorted = wsorted; b.item_stride = 0;
-    launch_sampler_build_batch(b, 1, s);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Standalone traversal kernels (parity of the software LBVH against the oracle's BVH)
-__global__ __launch_bounds__(BLOCK) void k_trace_closest(const KParams p, const float* __restrict__ rays, int n, float* __restrict__ out_t,
-                                                        int* __restrict__ out_tri, float* __restrict__ out_uv) {
-    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)i, p.diag);
-    const float* r = rays + (size_t)i * 8;
-    Counts<false> cn;
-    HitRec h;
-    traverse<false, false>(p.scene, st, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], h, cn);
-    out_t[i] = h.t;
-    out_tri[i] = h.tri >= 0 ? p.scene.tri_orig[h.tri] : -1;
-    out_uv[2 * i] = h.u; out_uv[2 * i + 1] = h.v;
-}
-__global__ __launch_bounds__(BLOCK) void k_trace_any(const KParams p, const float* __restrict__ rays, int n, int* __restrict__ out_visible) {
-    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)i, p.diag);
-    const float* r = rays + (size_t)i * 8;
-    Counts<false> cn;
-    HitRec h;
-    out_visible[i] = traverse<true, false>(p.scene, st, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], h, cn) ? 0 : 1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// "pretrace": one PT+NEE eye path per lane producing the training records of the sampling-matrix optimisation
-// (__raygen__TrainData raygen.cu:751-868, PreTrace_buildPathInfo 708-740, TrainData::nVertex_device cuProg.h:1128-1292).
-struct NVertex {  // TrainData::nVertex, the live fields
-    f3 position, dir, normal, weight, color;
-    float pdf;
-    int materialId, label_id, depth;  // materialId < 0: area light source
-};
-SPC_DEV NVertex nv_from_eye(const EyeVertex& a) {  // nVertex(const BDPTVertex&, eye_side = true)
-    NVertex v;
-    v.position = a.c.pos; v.normal = a.c.n; v.color = a.c.color; v.materialId = a.c.mat; v.pdf = a.pdf; v.label_id = a.sub;
-    v.depth = a.depth;
-    v.dir = a.depth == 0 ? mk3(0.0f) : normalize(a.c.lastPos - a.c.pos);
-    v.weight = mk3(a.pdf);
-    return v;
-}
-SPC_DEV NVertex nv_from_light(const LightSampleD& ls) {  // nVertex(light BDPTVertex, eye_side = false), depth 0, QUAD
-    NVertex v;
-    v.position = ls.position; v.normal = ls.normal; v.color = mk3(0.0f); v.materialId = -1; v.pdf = ls.pdf; v.label_id = ls.subspace;
-    v.depth = 0; v.dir = mk3(0.0f); v.weight = ls.emission;
-    return v;
-}
-SPC_DEV Pbr nv_mat(const DeviceScene& S, const NVertex& v) { return load_pbr_colored(S, v.materialId, v.color); }
-SPC_DEV f3 nv_forward_eye(const DeviceScene& S, const NVertex& self, const NVertex& b) {  // cuProg.h:1220-1243
-    const f3 vec = b.position - self.position;
-    const f3 c_dir = normalize(vec);
-    const float g = fabsf(dot(c_dir, b.normal)) / dot(vec, vec);
-    const float d_pdf = bsdf_pdf(nv_mat(S, self), self.normal, self.dir, c_dir);
-    return self.weight * d_pdf * rr_of(self.color) * g;
-}
-SPC_DEV f3 nv_forward_light(const DeviceScene& S, const NVertex& self, const NVertex& b) {  // cuProg.h:1245-1282
-    const f3 vec = b.position - self.position;
-    const f3 c_dir = normalize(vec);
-    const float g = fabsf(dot(c_dir, b.normal)) * fabsf(dot(c_dir, self.normal)) / dot(vec, vec);
-    if (self.materialId < 0) return self.weight * g;
-    return self.weight * g * bsdf_eval(nv_mat(S, self), self.normal, self.dir, c_dir);
-}
-SPC_DEV float nv_forward_light_pdf(const DeviceScene& S, const NVertex& self, const NVertex& b) {  // cuProg.h:1193-1218
-    const f3 vec = b.position - self.position;
-    const f3 c_dir = normalize(vec);
-    float g = fabsf(dot(c_dir, b.normal)) / dot(vec, vec);
-    if (self.materialId < 0) {
-        g *= fabsf(dot(self.normal, c_dir));
-        return self.pdf * g * kInvPi;
-    }
-    const float d_pdf = bsdf_pdf(nv_mat(S, self), self.normal, self.dir, c_dir);
-    return self.pdf * d_pdf * rr_of(self.color) * g;
-}
-// nVertex_device(a, b, eye_side): the vertex a seen as the next vertex after b
-SPC_DEV NVertex nv_extend(const DeviceScene& S, const NVertex& a, const NVertex& b, bool eye_side) {
-    NVertex v;
-    v.position = a.position;
-    v.dir = normalize(b.position - a.position);
-    v.normal = a.normal;
-    v.weight = eye_side ? nv_forward_eye(S, b, a) : nv_forward_light(S, b, a);
-    v.pdf = eye_side ? v.weight.x : nv_forward_light_pdf(S, b, a);
-    v.color = a.color; v.materialId = a.materialId; v.label_id = a.label_id; v.depth = b.depth + 1;
-    return v;
-}
-static constexpr int PRETRACE_MAX = 10;  // PRETRACE_CONN_PADDING
-
-SPC_DEV void pretrace_build_path(const DeviceScene& S, const EyeVertex* buffer, int buffer_size, NVertex light,
-                                 spcbpt_pretrace_path& path, spcbpt_pretrace_node* conn) {
-    path.valid = 1;
-    path.begin_ind = 0;
-    path.end_ind = buffer_size - 1;
-    int e = buffer_size - 1;
-    NVertex n_eye = nv_from_eye(buffer[e]);
-    const NVertex n_next_eye = nv_extend(S, light, n_eye, true);
-    const f3 vec = light.position - n_eye.position;
-    const f3 seg_contri = bsdf_eval(nv_mat(S, n_eye), n_eye.normal, n_eye.dir, normalize(vec));  // local_contri
-    path.sample_pdf = n_next_eye.pdf + n_eye.pdf * light.pdf;
-    path.fix_pdf = n_next_eye.pdf;
-    f3 contri = buffer[e].flux * nv_forward_light(S, light, n_eye) * seg_contri;
-    for (int i = 0; i < path.end_ind; i++) {
-        spcbpt_pretrace_node& nd = conn[path.end_ind - i - 1];  // pathInfo_node(n_eye, light)
-        nd.a_position[0] = n_eye.position.x; nd.a_position[1] = n_eye.position.y; nd.a_position[2] = n_eye.position.z;
-        nd.b_position[0] = light.position.x; nd.b_position[1] = light.position.y; nd.b_position[2] = light.position.z;
-        nd.a_dir[0] = n_eye.dir.x; nd.a_dir[1] = n_eye.dir.y; nd.a_dir[2] = n_eye.dir.z;
-        nd.b_dir[0] = light.dir.x; nd.b_dir[1] = light.dir.y; nd.b_dir[2] = light.dir.z;
-        nd.a_normal[0] = n_eye.normal.x; nd.a_normal[1] = n_eye.normal.y; nd.a_normal[2] = n_eye.normal.z;
-        nd.b_normal[0] = light.normal.x; nd.b_normal[1] = light.normal.y; nd.b_normal[2] = light.normal.z;
-        nd.peak_pdf = n_eye.weight.x * sum3(light.weight);
-        nd.path_id = 0;
-        nd.label_a = n_eye.depth;  // set_eye_depth
-        nd.label_b = light.label_id;
-        nd.valid = 1;
-        nd.light_source = light.materialId < 0 ? 1 : 0;
-        e--;
-        light = nv_extend(S, n_eye, light, false);
-        n_eye = nv_from_eye(buffer[e]);
-    }
-    const float wgt = sum3(contri) / path.sample_pdf;
-    if (isnan(wgt) || isinf(wgt)) contri = mk3(0.0f);
-    path.contri[0] = contri.x; path.contri[1] = contri.y; path.contri[2] = contri.z;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_pretrace(const KParams p, uint32_t iteration, int num_core, int padding,
-                                                    spcbpt_pretrace_path* __restrict__ paths, spcbpt_pretrace_node* __restrict__ nodes) {
-    __shared__ uint32_t s_stack[BLOCK * STACK_LDS];
-    const int launch_index = blockIdx.x * BLOCK + threadIdx.x;
-    if (launch_index >= num_core) return;
-    const DeviceScene& S = p.scene;
-    Counts<false> cn;
-    TravStack<BLOCK, STACK_LDS> st;
-    st.init(s_stack, p.spill, p.spill_entries, (size_t)launch_index, p.diag);
-    WalkState w;
-    w.seed = tea4((uint32_t)launch_index, iteration);
-    const float jx = rnd(w.seed), jy = rnd(w.seed);
-    w.dir = normalize((2.0f * jx - 1.0f) * ld3(p.U) + (2.0f * jy - 1.0f) * ld3(p.V) + ld3(p.W));
-    w.origin = ld3(p.eye);
-    w.done = false; w.next_flux = mk3(0.0f); w.next_single_pdf = 1.0f;
-    EyeVertex buffer[PRETRACE_MAX];
-    EyeVertex& cam = buffer[0];
-    cam.c.pos = w.origin; cam.c.n = w.dir; cam.c.color = mk3(0.0f); cam.c.lastPos = w.origin; cam.c.lnp = 0.0f; cam.c.mat = 0; cam.c.lld = false;
-    cam.flux = mk3(1.0f); cam.R3 = mk3(0.0f); cam.pdf = 1.0f; cam.singlePdf = 1.0f; cam.sub = 0; cam.lastZone = 0; cam.depth = 0;
-    int buffer_size = 1, resample_number = 0, depth = 0;
-    spcbpt_pretrace_path path;
-    path.valid = 0; path.begin_ind = path.end_ind = 0; path.choice_id = 0; path.sample_pdf = path.fix_pdf = 0.0f;
-    path.contri[0] = path.contri[1] = path.contri[2] = 0.0f; path.pad = 0;
-    spcbpt_pretrace_node* conn = nodes + (size_t)launch_index * padding;
-    while (true) {
-        HitRec h;
-        if (!traverse<false, false>(S, st, w.origin, w.dir, kEps, 1e16f, h, cn)) break;
-        const Geom g = local_geometry(S, h);
-        const EyeVertex& last = buffer[buffer_size - 1];
-        const f3 ray_dir = w.dir;
-        if (g.emitter) {
-            const Pbr lm = load_pbr(S, g.mat);
-            const DLight& L = S.lights[lm.light_id];
-            if (dot(ray_dir, ld3(L.normal)) > 0) break;                       // back of the emitter: no vertex
-            if (buffer_size + 1 > 2) {                                        // payload.path.size > 2
-                const float r = rnd(w.seed);                                  // rr_acc_accept
-                if (1.0f / (resample_number + 1) > r) {
-                    const LightSampleD ls = light_reverse_sample(S, L, g.u, g.v);
-                    pretrace_build_path(S, buffer, buffer_size, nv_from_light(ls), path, conn);
-                    resample_number++;
-                }
-            }
-            break;
-        }
-        if (buffer_size >= PRETRACE_MAX) break;  // cannot happen: the padding check below stops the walk first
-        EyeVertex mid;
-        eye_surface_hit(p, g, h.t, ray_dir, last.depth == 0, last, w, mid, cn);
-        buffer[buffer_size] = mid;
-        buffer_size++;
-        // next-event candidate
-        // QUAD lights only: upstream picks among all lights here too (raygen.cu:820-823) and then reads the sample's position, which
-        // the ENV branch never sets -- undefined, so the sky is left out of the training pass's next-event candidates
-        const int n_quads = S.n_lights - (S.env.valid ? 1 : 0);
-        const int lid = min(max((int)floorf(rnd(w.seed) * n_quads), 0), n_quads - 1);
-        const float r1 = rnd(w.seed), r2 = rnd(w.seed);
-        const LightSampleD ls = light_reverse_sample(S, S.lights[lid], r1, r2);
-        const f3 vis_vec = ls.position - mid.c.pos;
-        const float len = sqrtf(dot(vis_vec, vis_vec));
-        HitRec sh;
-        if (!traverse<true, false>(S, st, mid.c.pos, vis_vec / len, kEps, len - kEps, sh, cn)) {
-            const float r = rnd(w.seed);
-            if (1.0f / (resample_number + 1) > r) {
-                if (dot(vis_vec, ls.normal) < 0) {
-                    pretrace_build_path(S, buffer, buffer_size, nv_from_light(ls), path, conn);
-                    resample_number++;
-                }
-            }
-        }
-        if (w.done || depth > 50) break;
-        if (buffer_size >= padding) break;  // PRETRACER_PADDING_VERTICES_CHECK
-        depth += 1;
-    }
-    int begin_index = 0;
-    if (path.valid) begin_index += path.end_ind - path.begin_ind;
-    for (int i = begin_index; i < padding; i++) { conn[i].valid = 0; }
-    path.sample_pdf = path.sample_pdf / (float)resample_number;
-    const int bias = launch_index * padding;
-    path.begin_ind += bias;
-    path.end_ind += bias;
-    path.pixel_id[0] = (int)((float)p.width * jx);
-    path.pixel_id[1] = (int)((float)p.height * jy);
-    if (path.begin_ind == path.end_ind && path.valid) path.valid = 0;
-    paths[launch_index] = path;
-}
-void launch_pretrace(const KParams& p, uint32_t iteration, int num_core, int padding, spcbpt_pretrace_path* paths,
-                     spcbpt_pretrace_node* nodes, hipStream_t s) {
-    if (num_core <= 0) return;
-    hipLaunchKernelGGL(k_pretrace, dim3((num_core + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p, iteration, num_core, padding, paths, nodes);
-}
-
 // ---- host-callable launchers ---------------------------------------------------------------------
 static inline int render_blocks(const KParams& p) {
     const int tiles_x = ((int)p.width + 7) / 8;
@@ -1790,79 +872,6 @@ void launch_pt(const KParams& p, bool count, hipStream_t s) {
     if (blocks <= 0) return;
     if (count) hipLaunchKernelGGL(k_pt<true>, dim3(blocks), dim3(BLOCK), 0, s, p);
     else hipLaunchKernelGGL(k_pt<false>, dim3(blocks), dim3(BLOCK), 0, s, p);
-}
-int light_trace_blocks(const KParams& p, int max_blocks) {
-    const long long cores = (long long)p.core_count * (p.n_lframes > 0 ? p.n_lframes : 1);
-    long long blocks = (cores + BLOCK - 1) / BLOCK;
-    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
-    return (int)blocks;
-}
-void launch_light_trace(const KParams& p, int variant, int max_blocks, hipStream_t s) {   // variants as launch_spcbpt
-    const int blocks = light_trace_blocks(p, max_blocks);   // p.work_counter (the core queue head) must have been zeroed on `s`
-    if (blocks <= 0) return;
-    if (variant == 1) {   // (the reference's own evaluation of Gamma / Q, counted as such: launch_spcbpt)
-        KParams q = p;
-        q.gamma_q = nullptr;
-        hipLaunchKernelGGL((k_light_trace<true, false>), dim3(blocks), dim3(BLOCK), 0, s, q);
-    }
-    else if (variant == 2) hipLaunchKernelGGL((k_light_trace<true, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else hipLaunchKernelGGL((k_light_trace<false, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-}
-void launch_lvc_compact(const LightVertex* scratch, const int* core_counts, const int* core_offsets, int core_count, int core_padding,
-                        LightVertex* lvc, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, int capacity, uint32_t* overflow,
-                        hipStream_t s) {
-    const long long total = (long long)core_count * core_padding;
-    const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(k_lvc_compact, dim3(blocks), dim3(256), 0, s, scratch, core_counts, core_offsets, core_count,
-                       core_padding, lvc, keys, vals, weights, sampler_counts, capacity, overflow);
-}
-void launch_lvc_compact_batch(const LightVertex* scratch, const int* core_counts, const int* core_offsets, const int* path_counts, int core_count,
-                              int core_padding, int n, const CompactBatch& dst, int capacity, uint32_t* overflow, hipStream_t s) {
-    const long long total = (long long)core_count * core_padding;
-    hipLaunchKernelGGL(k_lvc_compact_batch, dim3((unsigned)((total + 255) / 256), (unsigned)n), dim3(256), 0, s, scratch, core_counts, core_offsets,
-                       path_counts, core_count, core_padding, dst, capacity, overflow);
-}
-void launch_fill_keys(const LightVertex* lvc, int n, uint32_t* keys, uint32_t* vals, float* weights, int* sampler_counts, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_fill_keys_from_lvc, dim3((n + 255) / 256), dim3(256), 0, s, lvc, n, keys, vals, weights, sampler_counts);
-}
-void launch_fill_keys_devcount(const LightVertex* lvc, int bound, uint32_t* keys, uint32_t* vals, float* weights, const int* sampler_counts, hipStream_t s) {
-    if (bound <= 0) return;
-    hipLaunchKernelGGL(k_fill_keys_devcount, dim3((bound + 255) / 256), dim3(256), 0, s, lvc, bound, keys, vals, weights, sampler_counts);
-}
-void launch_gather_compact(const LightVertex* gathered, const int* counts_all, int world, int cap, int lvc_capacity, const CompactBatch& dst, int nf,
-                           int* overflow, hipStream_t s) {
-    const int chunks = (cap + 255) / 256;
-    hipLaunchKernelGGL(k_gather_compact, dim3((unsigned)(world * chunks), (unsigned)nf), dim3(256), 0, s, gathered, counts_all, world, cap, lvc_capacity, dst,
-                       nf, overflow);
-}
-void launch_pack_shards(const CompactBatch& src, int nf, int cap, LightVertex* send, int* send_counts, hipStream_t s) {
-    hipLaunchKernelGGL(k_pack_shards, dim3((unsigned)((cap + 255) / 256), (unsigned)nf), dim3(256), 0, s, src, cap, send, send_counts);
-}
-void launch_pack_bands(float* accum, int width, int height, int rank, int world, float* packed, bool unpack_all, hipStream_t s) {
-    const int bands = (height + 7) / 8, per_rank = (bands + world - 1) / world;
-    const size_t n = (size_t)(unpack_all ? world : 1) * per_rank * 8 * width;
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_pack_bands, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(accum), width, height, rank, world,
-                       reinterpret_cast<float4*>(packed), unpack_all ? 1 : 0);
-}
-void launch_subspace_ranges(const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, int capacity, hipStream_t s) {
-    hipLaunchKernelGGL(k_subspace_ranges, dim3((capacity + 255) / 256), dim3(256), 0, s, sorted_keys, sampler_counts, sub);
-    hipLaunchKernelGGL(k_finish_ranges, dim3(1), dim3(1024), 0, s, sub);
-}
-void launch_gather_weights(const float* weights, const uint32_t* sorted_vals, const int* sampler_counts, double* out, int capacity, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_weights, dim3((capacity + 255) / 256), dim3(256), 0, s, weights, sorted_vals, sampler_counts, out);
-}
-void launch_cmf(const double* prefix, const uint32_t* sorted_keys, const int* sampler_counts, DSubspace* sub, float* cmfs, int capacity, hipStream_t s) {
-    hipLaunchKernelGGL(k_cmf, dim3((capacity + 255) / 256), dim3(256), 0, s, prefix, sorted_keys, sampler_counts, sub, cmfs);
-}
-void launch_trace_closest(const KParams& p, const float* rays, int n, float* t, int* tri, float* uv, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_trace_closest, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p, rays, n, t, tri, uv);
-}
-void launch_trace_any(const KParams& p, const float* rays, int n, int* vis, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_trace_any, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, p, rays, n, vis);
 }
 
 }  // namespace spc

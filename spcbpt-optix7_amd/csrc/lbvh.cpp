@@ -598,11 +598,13 @@ static void make_fan_pairs(Lbvh& out) {
         float* q = &out.pairs[i * 16];
         uint32_t meta; memcpy(&meta, t + 15, 4);
         uint32_t flags = meta & 0x80000000u;
-        for (int v = 0; v < 3; v++) { q[4 * v] = t[4 * v]; q[4 * v + 1] = t[4 * v + 1]; q[4 * v + 2] = t[4 * v + 2]; }
+        // P0 and the EDGES P1 - P0, P2 - P0 (, B.P2 - P0): the FP32 differences the triangle test starts with, taken here once (the
+        // same IEEE subtractions the device would do per test: bit-identical operands)
+        for (int k = 0; k < 3; k++) { q[k] = t[k]; q[4 + k] = t[4 + k] - t[k]; q[8 + k] = t[8 + k] - t[k]; }
         if (is_a[i]) {
             const float* b = &out.tris[(i + 1) * 16];
             uint32_t mb; memcpy(&mb, b + 15, 4);
-            q[12] = b[8]; q[13] = b[9]; q[14] = b[10];   // B.P2 = v3
+            for (int k = 0; k < 3; k++) q[12 + k] = b[8 + k] - t[k];   // B.P2 - P0 (B.P0 = A.P0, B.P1 = A.P2: B's first edge is A's second)
             flags |= 1u | ((mb & 0x80000000u) >> 1);
         }
         memcpy(q + 15, &flags, 4);

@@ -19,7 +19,7 @@ def source_hash(d=None):
     return h.hexdigest()[:16]
 
 
-KERNEL_SOURCES = ("kernels.hip", "kernels.h", "device_lib.h", "dev_traversal.h", "dev_bsdf.h", "dev_sampling.h", "dev_rmis.h", "eye_walk.h", "layout.h", "Makefile")
+KERNEL_SOURCES = ("kernels.hip", "kernels.h", "kernel_config.h", "device_lib.h", "dev_traversal.h", "dev_bsdf.h", "dev_sampling.h", "dev_rmis.h", "eye_walk.h", "layout.h", "Makefile")
 
 
 def kernel_hash(d=None):

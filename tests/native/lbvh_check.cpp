@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
         const float* src = &V[(size_t)9 * out.tri_orig[i]];
         for (int v = 0; v < 3; v++) if (memcmp(tr + 4 * v, src + 3 * v, 12) != 0) { c.ok = false; printf("record %d is not triangle %d\n", i, out.tri_orig[i]); break; }
     }
-    // ... and the pair slots (lbvh.h: Lbvh::pairs): a slot flagged "pair" holds (A.P0, A.P1, A.P2, B.P2) of triangles i, i + 1 of ONE
+    // ... and the pair slots (lbvh.h: Lbvh::pairs): a slot flagged "pair" holds (A.P0, A.P1 - A.P0, A.P2 - A.P0, B.P2 - A.P0) of triangles i, i + 1 of ONE
     // leaf with B = (A.P0, A.P2, B.P2) bit for bit and both culling flags; every other slot holds its own triangle
     {
         std::vector<int> leaf_of((size_t)n, -1);
@@ -136,14 +136,19 @@ int main(int argc, char** argv) {
             const float* q = &out.pairs[(size_t)i * 16];
             const float* a = &out.tris[(size_t)i * 16];
             uint32_t fl, ma; memcpy(&fl, q + 15, 4); memcpy(&ma, a + 15, 4);
-            bool good = memcmp(q, a, 12) == 0 && memcmp(q + 4, a + 4, 12) == 0 && memcmp(q + 8, a + 8, 12) == 0 && ((fl ^ ma) & 0x80000000u) == 0;
+            // (the slot holds the corner P0 and the EDGES P1 - P0, P2 - P0 as FP32 differences)
+            float e1[3], e2[3];
+            for (int k = 0; k < 3; k++) { e1[k] = a[4 + k] - a[k]; e2[k] = a[8 + k] - a[k]; }
+            bool good = memcmp(q, a, 12) == 0 && memcmp(q + 4, e1, 12) == 0 && memcmp(q + 8, e2, 12) == 0 && ((fl ^ ma) & 0x80000000u) == 0;
             if (fl & 1u) {
                 pairs++;
                 if (i + 1 >= n || leaf_of[i + 1] != leaf_of[i] || (i > 0 && (([&] { uint32_t p; memcpy(&p, &out.pairs[(size_t)(i - 1) * 16 + 15], 4); return p & 1u; })()))) good = false;
                 else {
                     const float* b = &out.tris[(size_t)(i + 1) * 16];
                     uint32_t mb; memcpy(&mb, b + 15, 4);
-                    good = good && memcmp(b, a, 12) == 0 && memcmp(b + 4, a + 8, 12) == 0 && memcmp(q + 12, b + 8, 12) == 0 && ((fl >> 30) & 1u) == (mb >> 31);
+                    float e3[3];
+                    for (int k = 0; k < 3; k++) e3[k] = b[8 + k] - a[k];
+                    good = good && memcmp(b, a, 12) == 0 && memcmp(b + 4, a + 8, 12) == 0 && memcmp(q + 12, e3, 12) == 0 && ((fl >> 30) & 1u) == (mb >> 31);
                 }
             } else good = good && (fl & 0x7fffffffu) == 0;
             if (!good) { c.ok = false; printf("pair slot %d is wrong (flags %08x)\n", i, fl); }

@@ -38,5 +38,8 @@ def test_offline_bvh_evaluator_builds_and_traverses(tmp_path, pkg):
     r = subprocess.run([exe, str(mesh), "20000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
-    closest = dict(zip(("visits", "leaves", "tris", "hit"), [float(x) for x in __import__("re").findall(r"[-+]?\d*\.\d+", lines[1])]))
+    line = next(l for l in lines if l.startswith("closest:"))
+    closest = dict(zip(("visits", "leaves", "tris", "hit"), [float(x) for x in __import__("re").findall(r"[-+]?\d*\.\d+", line)]))
+    steps = [float(x) for x in __import__("re").findall(r"[-+]?\d*\.\d+", next(l for l in lines if l.startswith("steps per ray")))]
+    assert steps[0] <= closest["visits"] + closest["tris"] + 1e-6 and steps[0] >= closest["visits"]   # a fan pair is ONE triangle step (round 6)
     assert 3 < closest["visits"] < 40 and closest["tris"] < 10 and closest["hit"] > 0.4, r.stdout

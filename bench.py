@@ -721,7 +721,9 @@ def main():
                                    f"{ncore} cores x {mpc} paths x {pad} slots ({args.light_geometry})",
                        "preprocess_s": round(t_pre, 2), "frames_in_flight": streams * batch, "frames_per_eye_launch": batch, "light_passes_ahead": (batch if lbatch else depth) if ahead else 0, "light_passes_per_launch": batch if lbatch else 1, "sampler_builds_ahead": batch if build_ahead else 0, "parallelism": "1 GPU" if world == 1 and comm is None else f"{world} GPUs: interleaved 8-row bands, LVC all-gather + film band gather over RCCL ({'C++ host libspcbpt_mgpu: ' + comm_transport + ' transport, ' + str(comm_world) + ' ranks seen by the communicator' if comm is not None else 'torch.distributed harness (--exchange python)'}" + (f", shard capacity {comm.shard_capacity} vertices, {'one exchange per light batch' if xbatch else 'one exchange per frame'}" if comm is not None else "") + ")",
                        "host": "single context" if dist is None else ("libspcbpt_mgpu" if comm is not None else "torch.distributed harness"), "rccl_ranks": comm_world if comm is not None else (world if dist is not None else 0)},
-            "roofline": {"bound": "latency" if nearest else "hbm",
+            # `bound` names the contract's roofline (north_star: the HBM-read roofline; the path has no MFMA work); what really limits the
+            # kernel is in `limiter` -- no unit is saturated, the waves' issue slots and their waits for gathers are
+            "roofline": {"bound": "hbm", "limiter": "latency / VALU issue of partly filled waves (no unit saturated)" if nearest else None,
                          "bound_note": ("contract roofline = algorithmic HBM bytes / kernel time / 8 TB/s (frac); the kernel is NOT HBM-bound: "
                                         "hbm_measured_frac is the memory-side counters over the same kernel time, unit_busy the direct counters -- "
                                         f"nearest saturation: {nearest} = {saturating[nearest]}" if nearest else

@@ -566,7 +566,7 @@ static void make_fan_pairs(Lbvh& out) {
             if (!(ref & 0x80000000u)) continue;
             const size_t first = (ref & 0x7fffffffu) >> 3;
             const int cnt = (int)(ref & 7u);
-            if (cnt < 2) continue;
+            if (cnt < 2 || cnt > LEAF_MAX) continue;   // (a leaf never holds more than LEAF_MAX triangles: the arrays below are sized for that)
             // greedy matching in the leaf's own order (stable: unmatched triangles keep their relative order)
             float rec[LEAF_MAX > 0 ? LEAF_MAX : 1][16]; int32_t orig[LEAF_MAX > 0 ? LEAF_MAX : 1];
             for (int i = 0; i < cnt; i++) { memcpy(rec[i], &out.tris[(first + i) * 16], 64); orig[i] = out.tri_orig[first + i]; }

@@ -330,6 +330,9 @@ int Context::ensure_lvc_capacity(size_t n) {
     lvc_count = 0;
     have_sampler = false;
     hipError_t e = hipSuccess;
+    if (const char* lim = getenv("SPCBPT_DEBUG_LVC_LIMIT")) {   // tests: pretend the device refuses a cache of more than this many vertices per set
+        if (n > (size_t)strtoull(lim, nullptr, 10)) e = hipErrorOutOfMemory;
+    }
     for (int s = 0; s < n_sets && e == hipSuccess; s++) {   // what the eye pass reads exists once per frame in flight (see context.h)
         e = dev_alloc(&set_lvc[s], n);
         if (e == hipSuccess) e = dev_alloc(&set_lvc_sorted[s], n);

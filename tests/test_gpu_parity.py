@@ -695,3 +695,33 @@ def test_batched_build_scratch_is_sized_by_the_batch_and_falls_back_when_it_cann
     r.launch_eye_batch([0, 1, 2]); r.sync()
     r.launch_light_batch(1, 2); r.build_sampler_batch(2)
     assert r.batch_scratch() == {"bytes": small["bytes"], "frames": 2, "fallbacks": 3}
+
+
+@pytest.mark.gpu
+def test_a_cache_the_device_cannot_hold_leaves_an_empty_consistent_context(gpu, pkg, ob, monkeypatch):
+    """Round 6 (advisor): if an allocation of the buffer-set ring fails half-way, the context is left WITHOUT a cache and says so --
+    not with half of its sets allocated and the old pointers freed.  The refusal is simulated (SPCBPT_DEBUG_LVC_LIMIT); afterwards a
+    capacity the device can hold works, and the frames are the frames of a context that never saw the failure."""
+    scene = pkg.scenes.cornell_box()
+    r, o = _pair(pkg, ob, scene, 64, 64)
+    r2, _ = _pair(pkg, ob, scene, 64, 64)
+    for x in (r, r2):
+        x.set_subspace()
+    r.launch("light trace", 1); r.build_sampler(); r.launch("SPCBPT_eye", 0); r.sync()
+    cap, sets = r.lvc_capacity()
+    assert cap > 0 and sets > 0
+    monkeypatch.setenv("SPCBPT_DEBUG_LVC_LIMIT", str(cap))
+    with pytest.raises(pkg.SpcbptError, match="NO cache"):
+        r.lvc_set_capacity(4 * cap)
+    assert r.lvc_capacity()[0] == 0                                   # empty, not half-allocated
+    with pytest.raises(pkg.SpcbptError):                                # nothing renders from a cache that is not there
+        r.build_sampler()
+    monkeypatch.delenv("SPCBPT_DEBUG_LVC_LIMIT")
+    r.lvc_set_capacity(cap)                                             # a size the device can hold: the context works again
+    assert r.lvc_capacity()[0] == cap
+    for x in (r, r2):
+        x.clear_accum()
+        for f in range(2):
+            x.render_frame("SPCBPT_eye", f, launch_frame=50 + f)
+        x.sync()
+    assert np.array_equal(r.read_accum(), r2.read_accum())

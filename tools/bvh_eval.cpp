@@ -116,6 +116,78 @@ static bool traverse(const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any
     return hit;
 }
 
+// ---- what a WIDER node would buy (offline only: BVH_EVAL_WIDE=8): the builder's binary tree folded into W-wide nodes with the same rule as
+// the product's 4-wide collapse (largest child opened first), EXACT child boxes, the same traversal rules and the same rays ---------------
+struct WNode { float lo[8][3], hi[8][3]; int ref[8], cnt[8], n; };   // ref >= 0: wide node index; ref < 0: leaf ~first, cnt triangles
+struct WideTree {
+    std::vector<WNode> nodes;
+    const std::vector<float>* bin = nullptr;
+    int W = 8;
+    static int geti(const float* p) { int v; memcpy(&v, p, 4); return v; }
+    struct Slot { float lo[3], hi[3]; int ref, count; };
+    void children_of(int b, Slot& x, Slot& y) const {
+        const float* q = &(*bin)[(size_t)b * 16];
+        for (int k = 0; k < 3; k++) { x.lo[k] = q[k]; x.hi[k] = q[4 + k]; y.lo[k] = q[8 + k]; y.hi[k] = q[12 + k]; }
+        x.ref = geti(q + 3); y.ref = geti(q + 7); x.count = geti(q + 11); y.count = geti(q + 15);
+    }
+    static float area(const Slot& s) { const float dx = s.hi[0] - s.lo[0], dy = s.hi[1] - s.lo[1], dz = s.hi[2] - s.lo[2]; return dx * dy + dy * dz + dz * dx; }
+    int emit(int bnode) {
+        Slot s[8]; int n = 2;
+        children_of(bnode, s[0], s[1]);
+        while (n < W) {
+            int best = -1; float ba = -1;
+            for (int i = 0; i < n; i++) if (s[i].ref >= 0 && area(s[i]) > ba) { ba = area(s[i]); best = i; }
+            if (best < 0) break;
+            Slot a, b; children_of(s[best].ref, a, b); s[best] = a; s[n++] = b;
+        }
+        const int id = (int)nodes.size();
+        nodes.emplace_back();
+        for (int i = 0; i < n; i++) { const int r = s[i].ref >= 0 ? emit(s[i].ref) : s[i].ref; WNode& w = nodes[id]; for (int k = 0; k < 3; k++) { w.lo[i][k] = s[i].lo[k]; w.hi[i][k] = s[i].hi[k]; } w.ref[i] = r; w.cnt[i] = s[i].ref >= 0 ? 0 : s[i].count; }
+        nodes[id].n = n;
+        return id;
+    }
+};
+struct WStats { double nodes = 0, tri_steps = 0, rays = 0, depth_hist[64] = {0}; };
+static bool wtraverse(const WideTree& T, const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any, WStats& st) {
+    struct E { int ref, cnt; };
+    E stack[512]; int sp = 0, sp_max = 0;
+    E cur{0, 0};
+    float best = tmax; bool hit = false;
+    const float inv[3] = {1.0f / (std::fabs(d.x) > 1e-20f ? d.x : 1e-20f), 1.0f / (std::fabs(d.y) > 1e-20f ? d.y : 1e-20f), 1.0f / (std::fabs(d.z) > 1e-20f ? d.z : 1e-20f)};
+    const float oo[3] = {o.x, o.y, o.z};
+    st.rays++;
+    while (true) {
+        sp_max = std::max(sp_max, sp);
+        if (cur.ref < 0) {
+            const int first = ~cur.ref;
+            for (int t = first; t < first + cur.cnt; t++) {
+                uint32_t flp = 0;
+                if (t > first) memcpy(&flp, &B.pairs[(size_t)(t - 1) * 16 + 15], 4);
+                if (!(flp & 1u)) st.tri_steps++;
+                float th;
+                if (tri_hit(&B.tris[(size_t)t * 16], o, d, tmin, best, th)) { best = th; hit = true; if (any) { st.depth_hist[std::min(sp_max, 63)]++; return true; } }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+            continue;
+        }
+        st.nodes++;
+        const WNode& w = T.nodes[(size_t)cur.ref];
+        float key[8]; E rf[8]; int n = 0;
+        for (int i = 0; i < w.n; i++) {
+            float t0 = tmin, t1 = best;
+            for (int k = 0; k < 3; k++) { float a = (w.lo[i][k] - oo[k]) * inv[k], b = (w.hi[i][k] - oo[k]) * inv[k]; if (a > b) std::swap(a, b); t0 = std::max(t0, a); t1 = std::min(t1, b); }
+            if (t0 <= t1 * 1.0000004f) { key[n] = t0; rf[n] = E{w.ref[i], w.cnt[i]}; n++; }
+        }
+        for (int i = 1; i < n; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(rf[j], rf[j - 1]); }
+        if (n == 0) { if (sp == 0) break; cur = stack[--sp]; continue; }
+        for (int i = n - 1; i >= 1; i--) stack[sp++] = rf[i];
+        cur = rf[0];
+    }
+    st.depth_hist[std::min(sp_max, 63)]++;
+    return hit;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: bvh_eval mesh.bin [rays]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
@@ -188,6 +260,55 @@ int main(int argc, char** argv) {
             printf("  K=%d %.3f/%.3f", K, hot / total, first / total);
         }
         printf("\n");
+    }
+    if (const char* wenv = getenv("BVH_EVAL_WIDE")) {
+        Lbvh bin;   // the binary tree the builder emits before the collapse (its triangle order is B's before the pairing: rebuild B's records for it)
+        Builder bb(m, bin);
+        bb.run();
+        for (int W : {4, atoi(wenv)}) {
+            WideTree T; T.bin = &bin.nodes; T.W = W;
+            T.emit(0);
+            // the pair flags of `bin`'s own triangle order
+            Lbvh tmp; tmp.nodes.assign(16, 0.0f); tmp.tris = bin.tris; tmp.tri_orig = bin.tri_orig;
+            // a flat list of leaves for make_fan_pairs: fake one 4-wide node per leaf range is overkill -- pair greedily inside the wide tree's leaves instead
+            tmp.pairs.assign(tmp.tris.size(), 0.0f);
+            for (const WNode& w : T.nodes) for (int i = 0; i < w.n; i++) if (w.ref[i] < 0) {
+                const int first = ~w.ref[i];
+                for (int t = first; t + 1 < first + w.cnt[i]; t++) {
+                    const float* A = &tmp.tris[(size_t)t * 16]; const float* Bq = &tmp.tris[(size_t)(t + 1) * 16];
+                    uint32_t prev = 0; if (t > first) memcpy(&prev, &tmp.pairs[(size_t)(t - 1) * 16 + 15], 4);
+                    if (!(prev & 1u) && memcmp(A, Bq, 12) == 0 && memcmp(A + 8, Bq + 4, 12) == 0) { uint32_t one = 1u; memcpy(&tmp.pairs[(size_t)t * 16 + 15], &one, 4); }
+                }
+            }
+            WStats wc, ws;
+            std::mt19937_64 rng2(12345);
+            std::uniform_real_distribution<double> U2(0.0, 1.0);
+            auto sp2 = [&](V3& P, V3& N) {
+                const double r = U2(rng2) * acc;
+                int t = (int)(std::lower_bound(cdf.begin(), cdf.end(), r) - cdf.begin());
+                t = std::min(t, nt - 1);
+                float a = (float)U2(rng2), b = (float)U2(rng2);
+                if (a + b > 1) { a = 1 - a; b = 1 - b; }
+                P = vert(t, 0) * (1 - a - b) + vert(t, 1) * a + vert(t, 2) * b;
+                N = norm(cross(vert(t, 1) - vert(t, 0), vert(t, 2) - vert(t, 0)));
+            };
+            for (int i = 0; i < n_rays; i++) {
+                V3 P, N; sp2(P, N);
+                if (U2(rng2) < 0.5) N = N * -1.0f;
+                const float r1 = (float)U2(rng2), r2 = (float)U2(rng2), rr = std::sqrt(r1), ph = 6.2831853f * r2;
+                V3 b1 = std::fabs(N.x) > std::fabs(N.z) ? norm(V3{-N.y, N.x, 0}) : norm(V3{0, -N.z, N.y});
+                V3 b2 = cross(b1, N);
+                V3 d = norm(b1 * (rr * std::cos(ph)) + b2 * (rr * std::sin(ph)) + N * std::sqrt(std::max(0.0f, 1 - r1)));
+                wtraverse(T, tmp, P, d, 1e-3f, 1e16f, false, wc);
+                V3 Q, M; sp2(Q, M);
+                V3 dv = Q - P; const float len = std::sqrt(dot(dv, dv));
+                if (len > 1e-4f) wtraverse(T, tmp, P, dv * (1.0f / len), 1e-3f, len - 1e-3f, true, ws);
+            }
+            double c9 = 0, c15 = 0, tot = 0;
+            for (int i = 0; i < 64; i++) { tot += wc.depth_hist[i] + ws.depth_hist[i]; if (i <= 9) c9 += wc.depth_hist[i] + ws.depth_hist[i]; if (i <= 15) c15 += wc.depth_hist[i] + ws.depth_hist[i]; }
+            printf("W = %d (exact child boxes): %zu nodes; closest: node visits %.2f, steps %.2f; shadow: node visits %.2f, steps %.2f; rays whose stack stays <= 9 / <= 15 entries: %.4f / %.4f\n",
+                   W, T.nodes.size(), wc.nodes / wc.rays, (wc.nodes + wc.tri_steps) / wc.rays, ws.nodes / ws.rays, (ws.nodes + ws.tri_steps) / ws.rays, c9 / tot, c15 / tot);
+        }
     }
     {   // traversal-stack depth (entries held): cumulative share of the rays whose maximum / of the node visits made at depth <= N
         double rays = 0, steps = 0;

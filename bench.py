@@ -95,7 +95,7 @@ def spawn_ranks(n: int, argv, script: str = None, out=None) -> int:
     return rc
 
 
-def host_cpus():
+def host_cpus(cgroup_root="/sys/fs/cgroup"):
     """The CPUs this process can really run on: the smallest of os.cpu_count(), the scheduler affinity mask and the cgroup CPU quota
     (v2 `cpu.max`, v1 `cpu.cfs_quota_us`).  A one-GPU box of the pool shows all 256 hardware threads of its host in os.cpu_count() but
     is given a 16-CPU share of them: 256 oracle threads then run like 11, and a baseline labelled "256 cores" misleads (round-5 review)."""
@@ -106,13 +106,13 @@ def host_cpus():
         pass
     quota = None
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
         if q != "max":
             quota = int(q) / int(per)
     except (OSError, ValueError):
         try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            q = int(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            per = int(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
             if q > 0:
                 quota = q / per
         except (OSError, ValueError):

@@ -188,6 +188,88 @@ static bool wtraverse(const WideTree& T, const Lbvh& B, V3 o, V3 d, float tmin, 
     return hit;
 }
 
+// ---- "open once": every 4-wide node with its largest internal child opened in place (up to 7 children whose refs are still 4-wide node
+// ids / leaf refs, so that the tails could go on with the 4-wide records); the opened child's boxes re-quantised OUTWARD on the parent's
+// 8-bit grid, as a device record would hold them (BVH_EVAL_OPEN1=1) ---------------------------------------------------------------------
+struct ONode { float lo[7][3], hi[7][3]; uint32_t ref[7]; int n; };
+static void decode4(const Lbvh& B, uint32_t node, float org[3], float sc[3], float lo[4][3], float hi[4][3], uint32_t ref[4]) {
+    uint32_t w[16]; memcpy(w, &B.nodes[(size_t)node * 16], sizeof(w));
+    memcpy(org, w, 12);
+    for (int k = 0; k < 3; k++) { const uint32_t e = ((w[3] >> (8 * k)) & 0xffu) << 23; memcpy(&sc[k], &e, 4); }
+    for (int i = 0; i < 4; i++) {
+        ref[i] = w[10 + i];
+        for (int k = 0; k < 3; k++) { lo[i][k] = org[k] + (float)((w[4 + k] >> (8 * i)) & 0xffu) * sc[k]; hi[i][k] = org[k] + (float)((w[7 + k] >> (8 * i)) & 0xffu) * sc[k]; }
+    }
+}
+static std::vector<ONode> open_once(const Lbvh& B) {
+    const size_t n = B.nodes.size() / 16;
+    std::vector<ONode> out(n);
+    for (size_t nd = 0; nd < n; nd++) {
+        float org[3], sc[3], lo[4][3], hi[4][3]; uint32_t ref[4];
+        decode4(B, (uint32_t)nd, org, sc, lo, hi, ref);
+        int best = -1; float ba = -1;
+        for (int i = 0; i < 4; i++) if (ref[i] != 0x80000000u && !(ref[i] & 0x80000000u)) { const float dx = hi[i][0] - lo[i][0], dy = hi[i][1] - lo[i][1], dz = hi[i][2] - lo[i][2]; const float a = dx * dy + dy * dz + dz * dx; if (a > ba) { ba = a; best = i; } }
+        ONode& o = out[nd]; o.n = 0;
+        for (int i = 0; i < 4; i++) {
+            if (ref[i] == 0x80000000u || i == best) continue;
+            for (int k = 0; k < 3; k++) { o.lo[o.n][k] = lo[i][k]; o.hi[o.n][k] = hi[i][k]; }
+            o.ref[o.n++] = ref[i];
+        }
+        if (best >= 0) {
+            float org2[3], sc2[3], lo2[4][3], hi2[4][3]; uint32_t ref2[4];
+            decode4(B, ref[best], org2, sc2, lo2, hi2, ref2);
+            for (int i = 0; i < 4; i++) {
+                if (ref2[i] == 0x80000000u) continue;
+                for (int k = 0; k < 3; k++) {   // outward on the PARENT's grid
+                    const float a = std::floor((lo2[i][k] - org[k]) / sc[k]), b = std::ceil((hi2[i][k] - org[k]) / sc[k]);
+                    o.lo[o.n][k] = org[k] + std::max(0.0f, std::min(255.0f, a)) * sc[k]; o.hi[o.n][k] = org[k] + std::max(0.0f, std::min(255.0f, b)) * sc[k];
+                }
+                o.ref[o.n++] = ref2[i];
+            }
+        }
+    }
+    return out;
+}
+static bool otraverse(const std::vector<ONode>& T, const Lbvh& B, V3 o, V3 d, float tmin, float tmax, bool any, bool sorted, WStats& st) {
+    uint32_t stack[512]; int sp = 0, sp_max = 0;
+    uint32_t cur = 0;
+    float best = tmax; bool hit = false;
+    const float inv[3] = {1.0f / (std::fabs(d.x) > 1e-20f ? d.x : 1e-20f), 1.0f / (std::fabs(d.y) > 1e-20f ? d.y : 1e-20f), 1.0f / (std::fabs(d.z) > 1e-20f ? d.z : 1e-20f)};
+    const float oo[3] = {o.x, o.y, o.z};
+    st.rays++;
+    while (true) {
+        sp_max = std::max(sp_max, sp);
+        if (cur & 0x80000000u) {
+            const int first = (int)((cur & 0x7fffffffu) >> 3), cnt = (int)(cur & 7u);
+            for (int t = first; t < first + cnt; t++) {
+                uint32_t flp = 0;
+                if (t > first) memcpy(&flp, &B.pairs[(size_t)(t - 1) * 16 + 15], 4);
+                if (!(flp & 1u)) st.tri_steps++;
+                float th;
+                if (tri_hit(&B.tris[(size_t)t * 16], o, d, tmin, best, th)) { best = th; hit = true; if (any) { st.depth_hist[std::min(sp_max, 63)]++; return true; } }
+            }
+            if (sp == 0) break;
+            cur = stack[--sp];
+            continue;
+        }
+        st.nodes++;
+        const ONode& w = T[cur];
+        float key[7]; uint32_t rf[7]; int n = 0;
+        for (int i = 0; i < w.n; i++) {
+            float t0 = tmin, t1 = best;
+            for (int k = 0; k < 3; k++) { float a = (w.lo[i][k] - oo[k]) * inv[k], b = (w.hi[i][k] - oo[k]) * inv[k]; if (a > b) std::swap(a, b); t0 = std::max(t0, a); t1 = std::min(t1, b); }
+            if (t0 <= t1 * 1.0000004f) { key[n] = t0; rf[n] = w.ref[i]; n++; }
+        }
+        if (n == 0) { if (sp == 0) break; cur = stack[--sp]; continue; }
+        if (sorted) { for (int i = 1; i < n; i++) for (int j = i; j > 0 && key[j] < key[j - 1]; j--) { std::swap(key[j], key[j - 1]); std::swap(rf[j], rf[j - 1]); } }
+        else { int m = 0; for (int i = 1; i < n; i++) if (key[i] < key[m]) m = i; std::swap(key[0], key[m]); std::swap(rf[0], rf[m]); }   // nearest first, the others as they come
+        for (int i = n - 1; i >= 1; i--) stack[sp++] = rf[i];
+        cur = rf[0];
+    }
+    st.depth_hist[std::min(sp_max, 63)]++;
+    return hit;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: bvh_eval mesh.bin [rays]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb");
@@ -260,6 +342,39 @@ int main(int argc, char** argv) {
             printf("  K=%d %.3f/%.3f", K, hot / total, first / total);
         }
         printf("\n");
+    }
+    if (getenv("BVH_EVAL_OPEN1")) {
+        const std::vector<ONode> T = open_once(B);
+        for (int sorted = 1; sorted >= 0; sorted--) {
+            WStats wc, ws;
+            std::mt19937_64 rng2(12345);
+            std::uniform_real_distribution<double> U2(0.0, 1.0);
+            auto sp2 = [&](V3& P, V3& N) {
+                const double r = U2(rng2) * acc;
+                int t = (int)(std::lower_bound(cdf.begin(), cdf.end(), r) - cdf.begin());
+                t = std::min(t, nt - 1);
+                float a = (float)U2(rng2), b = (float)U2(rng2);
+                if (a + b > 1) { a = 1 - a; b = 1 - b; }
+                P = vert(t, 0) * (1 - a - b) + vert(t, 1) * a + vert(t, 2) * b;
+                N = norm(cross(vert(t, 1) - vert(t, 0), vert(t, 2) - vert(t, 0)));
+            };
+            for (int i = 0; i < n_rays; i++) {
+                V3 P, N; sp2(P, N);
+                if (U2(rng2) < 0.5) N = N * -1.0f;
+                const float r1 = (float)U2(rng2), r2 = (float)U2(rng2), rr = std::sqrt(r1), ph = 6.2831853f * r2;
+                V3 b1 = std::fabs(N.x) > std::fabs(N.z) ? norm(V3{-N.y, N.x, 0}) : norm(V3{0, -N.z, N.y});
+                V3 b2 = cross(b1, N);
+                V3 d = norm(b1 * (rr * std::cos(ph)) + b2 * (rr * std::sin(ph)) + N * std::sqrt(std::max(0.0f, 1 - r1)));
+                otraverse(T, B, P, d, 1e-3f, 1e16f, false, sorted != 0, wc);
+                V3 Q, M; sp2(Q, M);
+                V3 dv = Q - P; const float len = std::sqrt(dot(dv, dv));
+                if (len > 1e-4f) otraverse(T, B, P, dv * (1.0f / len), 1e-3f, len - 1e-3f, true, sorted != 0, ws);
+            }
+            double c9 = 0, c12 = 0, tot = 0;
+            for (int i = 0; i < 64; i++) { tot += wc.depth_hist[i] + ws.depth_hist[i]; if (i <= 9) c9 += wc.depth_hist[i] + ws.depth_hist[i]; if (i <= 12) c12 += wc.depth_hist[i] + ws.depth_hist[i]; }
+            printf("open once (<= 7 children, parent's grid), %s push: closest: node visits %.2f, steps %.2f; shadow: node visits %.2f, steps %.2f; rays whose stack stays <= 9 / <= 12 entries: %.4f / %.4f\n",
+                   sorted ? "sorted" : "nearest-first + unsorted", wc.nodes / wc.rays, (wc.nodes + wc.tri_steps) / wc.rays, ws.nodes / ws.rays, (ws.nodes + ws.tri_steps) / ws.rays, c9 / tot, c12 / tot);
+        }
     }
     if (const char* wenv = getenv("BVH_EVAL_WIDE")) {
         Lbvh bin;   // the binary tree the builder emits before the collapse (its triangle order is B's before the pairing: rebuild B's records for it)
